@@ -1,0 +1,127 @@
+"""ctypes binding of libgpar_hip.so (C ABI: include/gpar_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or does not export the ABI the header
+declares, importing the binding raises.  The library lives in-tree next to this file (built by
+`__graft_entry__.build()` / `python -m gpar_amd.build`).
+"""
+import ctypes
+import os
+
+GPAR_MAX_DIMS = 96
+GPAR_MAX_FACTORS = 12
+GPAR_MAX_TERMS = 8
+
+EMBED_ID, EMBED_SIN, EMBED_COS = 0, 1, 2
+K_EQ, K_RQ, K_LINEAR = 0, 1, 2
+
+GRAM_LOWER = 1
+GEMM_C_LOWER = 1
+GEMM_A_LOWER = 2
+
+ABI_VERSION = 1
+
+LIB_NAME = "libgpar_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+class FSpec(ctypes.Structure):
+    _fields_ = [
+        ("dz", ctypes.c_int32),
+        ("pad_", ctypes.c_int32),
+        ("col", ctypes.c_int32 * GPAR_MAX_DIMS),
+        ("embed", ctypes.c_int32 * GPAR_MAX_DIMS),
+        ("inv_scale", ctypes.c_double * GPAR_MAX_DIMS),
+        ("freq", ctypes.c_double * GPAR_MAX_DIMS),
+    ]
+
+
+class Factor(ctypes.Structure):
+    _fields_ = [
+        ("type", ctypes.c_int32),
+        ("term", ctypes.c_int32),
+        ("off", ctypes.c_int32),
+        ("nd", ctypes.c_int32),
+        ("alpha", ctypes.c_double),
+    ]
+
+
+class KSpec(ctypes.Structure):
+    _fields_ = [
+        ("nterms", ctypes.c_int32),
+        ("nfactors", ctypes.c_int32),
+        ("coef", ctypes.c_double * GPAR_MAX_TERMS),
+        ("factor", Factor * GPAR_MAX_FACTORS),
+    ]
+
+
+_c_int = ctypes.c_int
+_c_dbl = ctypes.c_double
+_ptr = ctypes.c_void_p
+_u64 = ctypes.c_uint64
+
+# name -> (restype, argtypes); every symbol include/gpar_hip.h declares
+SIGNATURES = {
+    "gpar_abi_version": (_c_int, []),
+    "gpar_sizeof_fspec": (ctypes.c_size_t, []),
+    "gpar_sizeof_kspec": (ctypes.c_size_t, []),
+    "gpar_featurize": (_c_int, [ctypes.POINTER(FSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
+    "gpar_gram": (
+        _c_int,
+        [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr, _c_dbl, _ptr],
+    ),
+    "gpar_gram_diag": (_c_int, [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "gpar_potrf": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    "gpar_trsm_rlt": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),
+    "gpar_trsm_rln": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),
+    "gpar_gemm": (
+        _c_int,
+        [_c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _ptr, _c_int, _ptr, _c_int, _c_dbl, _ptr, _c_int, _c_int, _ptr],
+    ),
+    "gpar_logpdf_finalize": (_c_int, [_ptr, _ptr, _c_dbl, _c_int, _ptr, _ptr]),
+    "gpar_copy_strided": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _ptr]),
+    "gpar_fill": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_dbl, _ptr]),
+    "gpar_dot": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
+    "gpar_randn": (_c_int, [_u64, _u64, _ptr, _c_int, _c_int, _c_int, _ptr]),
+    "gpar_profile_enable": (_c_int, [_c_int]),
+    "gpar_profile_read": (_c_int, [ctypes.POINTER(_c_int), ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_dbl), _c_int]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgpar_hip.so (once) and bind every declared symbol.  Raises HipLibraryError loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  gpar_amd has no CPU fallback."
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.gpar_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {lib.gpar_abi_version()}, binding {ABI_VERSION}")
+    if lib.gpar_sizeof_fspec() != ctypes.sizeof(FSpec) or lib.gpar_sizeof_kspec() != ctypes.sizeof(KSpec):
+        raise HipLibraryError("struct layout mismatch between include/gpar_hip.h and gpar_amd/_lib.py")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed with status {rc}")

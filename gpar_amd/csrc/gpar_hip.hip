@@ -1,0 +1,200 @@
+// libgpar_hip.so — C ABI (include/gpar_hip.h) over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC gpar_hip.hip -o ../libgpar_hip.so
+#include "common.h"
+#include "gemm_f64.h"
+#include "potrf.h"
+#include "gram.h"
+
+namespace gpar {
+
+__global__ void logpdf_finalize_kernel(const double* __restrict__ logdet, const double* __restrict__ quad,
+                                       double quad_sign, int n, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double log2pi = 1.8378770664093454835606594728112;
+        out[0] = -0.5 * (logdet[0] + (double)n * log2pi + quad_sign * quad[0]);
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_strided_kernel(const double* __restrict__ src, long lds, double* __restrict__ dst,
+                                                           long ldd, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[(size_t)i * ldd] = src[(size_t)i * lds];
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(double* __restrict__ dst, int rows, int cols, int ldd, double value) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (r < rows && c < cols) dst[(size_t)r * ldd + c] = value;
+}
+
+// single-workgroup, fixed-order reduction: deterministic
+__global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x, long incx, const double* __restrict__ y,
+                                                   long incy, int n, double* __restrict__ out, int accumulate) {
+    __shared__ double part[1024];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) s = fma(x[(size_t)i * incx], y[(size_t)i * incy], s);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + part[0];
+}
+
+// Philox-4x32-10 (Salmon et al. 2011).  counter = (pair index lo, hi, offset lo, hi), key = seed.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&r)[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(uint64_t seed, uint64_t offset, double* __restrict__ out, int rows,
+                                                    int cols, int ldo) {
+    const size_t total = (size_t)rows * cols;
+    const size_t pair = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair * 2 >= total) return;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    const uint64_t a = ((uint64_t)r[1] << 32) | r[0], b = ((uint64_t)r[3] << 32) | r[2];
+    const double u1 = ((double)(a >> 11) + 0.5) * 1.1102230246251565404e-16;  // (0, 1)
+    const double u2 = ((double)(b >> 11) + 0.5) * 1.1102230246251565404e-16;
+    const double rad = sqrt(-2.0 * log(u1));
+    const double ang = 6.283185307179586476925286766559 * u2;
+    const double zv[2] = {rad * cos(ang), rad * sin(ang)};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const size_t idx = pair * 2 + e;
+        if (idx < total) {
+            const size_t rr = idx / cols, cc = idx - rr * cols;
+            out[rr * ldo + cc] = zv[e];
+        }
+    }
+}
+
+}  // namespace gpar
+
+using namespace gpar;
+
+extern "C" {
+
+int gpar_abi_version(void) { return GPAR_ABI_VERSION; }
+size_t gpar_sizeof_fspec(void) { return sizeof(gpar_fspec_t); }
+size_t gpar_sizeof_kspec(void) { return sizeof(gpar_kspec_t); }
+
+int gpar_featurize(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* z, int ldz, void* stream) {
+    if (!fs || fs->dz < 0 || fs->dz > GPAR_MAX_DIMS) return GPAR_ARG_ERROR(2);
+    if (n <= 0 || fs->dz == 0) return 0;
+    const long total = (long)n * fs->dz;
+    hipLaunchKernelGGL(featurize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *fs, x, n,
+                       ldx, z, ldz);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz,
+              double* K, int ldk, int flags, const double* diag_add, double diag_const, void* stream) {
+    if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS)
+        return GPAR_ARG_ERROR(3);
+    if (dz < 0 || dz > GPAR_MAX_DIMS) return GPAR_ARG_ERROR(4);
+    if (n1 <= 0 || n2 <= 0) return 0;
+    const int sym = (z1 == z2 && n1 == n2) ? 1 : 0;
+    if ((flags & GPAR_GRAM_LOWER) && !sym) return GPAR_ARG_ERROR(5);
+    const size_t lds = (size_t)2 * (dz > 0 ? dz : 1) * GRAM_LD * sizeof(double);
+    dim3 grid(gpar_ceil_div(n2, GRAM_T), gpar_ceil_div(n1, GRAM_T));
+    hipLaunchKernelGGL(gram_kernel, grid, dim3(256), lds, (hipStream_t)stream, *ks, z1, n1, ldz1, z2, n2, ldz2, dz, K, ldk,
+                       flags, diag_add, diag_const, sym);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_gram_diag(const gpar_kspec_t* ks, const double* z, int n, int ldz, int dz, double* out, void* stream) {
+    (void)dz;
+    if (!ks) return GPAR_ARG_ERROR(3);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gram_diag_kernel, dim3(gpar_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, *ks, z, n, ldz, out);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, void* stream) {
+    if (N <= 0 || nf <= 0) return 0;
+    return potrf_run(A, N, nf, lda, logdet, info, (hipStream_t)stream);
+}
+
+int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream) {
+    return trsm_rlt_run(L, n, ldl, B, nrows, ldb, (hipStream_t)stream);
+}
+
+int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream) {
+    return trsm_rln_run(L, n, ldl, B, nrows, ldb, (hipStream_t)stream);
+}
+
+int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B, int ldb,
+              double beta, double* C, int ldc, int flags, void* stream) {
+    return gemm_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, (hipStream_t)stream);
+}
+
+int gpar_logpdf_finalize(const double* logdet, const double* quad, double quad_sign, int n, double* out, void* stream) {
+    hipLaunchKernelGGL(logpdf_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logdet, quad, quad_sign, n, out);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_copy_strided(const double* src, int lds, double* dst, int ldd, int n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(copy_strided_kernel, dim3(gpar_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (long)lds, dst,
+                       (long)ldd, n);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_fill(double* dst, int rows, int cols, int ldd, double value, void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(gpar_ceil_div(cols, 256), rows), dim3(256), 0, (hipStream_t)stream, dst, rows, cols, ldd,
+                       value);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_dot(const double* x, int incx, const double* y, int incy, int n, double* out, int accumulate, void* stream) {
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)incx, y, (long)incy, n, out, accumulate);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, int ldo, void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const size_t pairs = ((size_t)rows * cols + 1) / 2;
+    hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, offset, out,
+                       rows, cols, ldo);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_profile_enable(int on) {
+    g_prof.on = on != 0;
+    return 0;
+}
+
+int gpar_profile_read(int* launches, double* ms, double* flops, int reset) {
+    profile_collect();
+    if (launches) *launches = g_prof.launches;
+    if (ms) *ms = g_prof.ms_done;
+    if (flops) *flops = g_prof.flops;
+    if (reset) { g_prof.launches = 0; g_prof.ms_done = 0.0; g_prof.flops = 0.0; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+"""Thin torch-tensor front end of the C ABI: tensors in, raw device pointers across the boundary.
+
+PyTorch is used only as the device-memory allocator and stream provider; every numerical operation here is a
+call into libgpar_hip.so on the tensor's `data_ptr()`.  All matrices are float64, row-major with unit inner
+stride (`stride(1) == 1`); the leading dimension is `stride(0)`.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+__all__ = [
+    "stream_ptr",
+    "alloc_matrix",
+    "featurize",
+    "gram",
+    "gram_diag",
+    "potrf_",
+    "trsm_rlt_",
+    "trsm_rln_",
+    "gemm",
+    "logpdf_finalize",
+    "copy_strided_",
+    "fill_",
+    "dot",
+    "randn",
+]
+
+
+def _check_mat(a, name):
+    if a.dtype != torch.float64 or not a.is_cuda:
+        raise TypeError(f"{name} must be a float64 tensor on the GPU (got {a.dtype} on {a.device})")
+    if a.dim() == 2:
+        if a.shape[1] > 1 and a.stride(1) != 1:
+            raise ValueError(f"{name} must have unit inner stride")
+    elif a.dim() != 1:
+        raise ValueError(f"{name} must be a vector or a matrix")
+
+
+def _ld(a):
+    if a.dim() == 1:
+        return 1
+    # a single-row matrix may report any stride(0); make it safe for the kernels' index math
+    return max(int(a.stride(0)), int(a.shape[1]), 1) if a.shape[0] > 1 else max(int(a.shape[1]), 1)
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def alloc_matrix(rows, cols, device, zero=False):
+    """rows x cols view into a buffer whose leading dimension is padded to a multiple of 16 doubles (128-byte
+    rows: every row start is aligned for the 16-byte vector paths and full-line stores)."""
+    ld = max(16, (cols + 15) // 16 * 16)
+    buf = (torch.zeros if zero else torch.empty)((max(rows, 1), ld), dtype=torch.float64, device=device)
+    return buf[:rows, :cols]
+
+
+def featurize(ck, x):
+    """z = features(x) for a CompiledKernel `ck`; x: n x width."""
+    _check_mat(x, "x")
+    lib = _lib.load()
+    n = x.shape[0]
+    z = alloc_matrix(n, max(ck.dz, 1), x.device)
+    if ck.dz == 0:
+        z.zero_()
+        return z
+    _lib.check(
+        lib.gpar_featurize(ctypes.byref(ck.fspec), x.data_ptr(), n, _ld(x), z.data_ptr(), _ld(z), stream_ptr(x.device)),
+        "gpar_featurize",
+    )
+    return z
+
+
+def gram(ck, z1, z2=None, out=None, lower=False, diag_add=None, diag_const=0.0):
+    """K = k(z1, z2) (z2 None: symmetric, optionally lower-only, + diag_add + diag_const on the diagonal)."""
+    lib = _lib.load()
+    sym = z2 is None
+    if sym:
+        z2 = z1
+    _check_mat(z1, "z1")
+    _check_mat(z2, "z2")
+    n1, n2 = z1.shape[0], z2.shape[0]
+    if out is None:
+        out = alloc_matrix(n1, n2, z1.device)
+    _check_mat(out, "out")
+    flags = _lib.GRAM_LOWER if (lower and sym) else 0
+    dptr = None
+    if diag_add is not None:
+        if not sym:
+            raise ValueError("diag_add requires the symmetric Gram")
+        _check_mat(diag_add, "diag_add")
+        diag_add = diag_add.contiguous()
+        dptr = diag_add.data_ptr()
+    _lib.check(
+        lib.gpar_gram(
+            ctypes.byref(ck.kspec), z1.data_ptr(), n1, _ld(z1), z2.data_ptr(), n2, _ld(z2), ck.dz,
+            out.data_ptr(), _ld(out), flags, dptr, float(diag_const), stream_ptr(z1.device),
+        ),
+        "gpar_gram",
+    )
+    return out
+
+
+def gram_diag(ck, z):
+    lib = _lib.load()
+    _check_mat(z, "z")
+    out = torch.empty(z.shape[0], dtype=torch.float64, device=z.device)
+    _lib.check(
+        lib.gpar_gram_diag(ctypes.byref(ck.kspec), z.data_ptr(), z.shape[0], _ld(z), ck.dz, out.data_ptr(), stream_ptr(z.device)),
+        "gpar_gram_diag",
+    )
+    return out
+
+
+def potrf_(A, nf=None, logdet=None, info=None):
+    """In-place (partial) Cholesky of the lower triangle of the square matrix A; returns (logdet, info) device
+    scalars (logdet accumulates, info is sticky: pass fresh zeros)."""
+    lib = _lib.load()
+    _check_mat(A, "A")
+    N = A.shape[0]
+    if A.shape[1] != N:
+        raise ValueError("A must be square")
+    nf = N if nf is None else int(nf)
+    if logdet is None:
+        logdet = torch.zeros(1, dtype=torch.float64, device=A.device)
+    if info is None:
+        info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    _lib.check(
+        lib.gpar_potrf(A.data_ptr(), N, nf, _ld(A), logdet.data_ptr(), info.data_ptr(), stream_ptr(A.device)), "gpar_potrf"
+    )
+    return logdet, info
+
+
+def trsm_rlt_(L, B):
+    """B <- B L^-T (rows of B solved by forward substitution)."""
+    lib = _lib.load()
+    _check_mat(L, "L")
+    _check_mat(B, "B")
+    n = L.shape[0]
+    if B.shape[1] != n:
+        raise ValueError("B must have as many columns as L has rows")
+    _lib.check(lib.gpar_trsm_rlt(L.data_ptr(), n, _ld(L), B.data_ptr(), B.shape[0], _ld(B), stream_ptr(B.device)), "gpar_trsm_rlt")
+    return B
+
+
+def trsm_rln_(L, B):
+    """B <- B L^-1 (rows of B solved by backward substitution)."""
+    lib = _lib.load()
+    _check_mat(L, "L")
+    _check_mat(B, "B")
+    n = L.shape[0]
+    if B.shape[1] != n:
+        raise ValueError("B must have as many columns as L has rows")
+    _lib.check(lib.gpar_trsm_rln(L.data_ptr(), n, _ld(L), B.data_ptr(), B.shape[0], _ld(B), stream_ptr(B.device)), "gpar_trsm_rln")
+    return B
+
+
+def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False, a_lower=False):
+    """out <- alpha op(A) op(B) + beta out;  ta: A stored k x m;  tb: B stored n x k."""
+    lib = _lib.load()
+    _check_mat(A, "A")
+    _check_mat(B, "B")
+    m, k = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
+    n, kb = (B.shape[0], B.shape[1]) if tb else (B.shape[1], B.shape[0])
+    if k != kb:
+        raise ValueError(f"inner dimensions differ: {k} vs {kb}")
+    if out is None:
+        out = alloc_matrix(m, n, A.device)
+        if beta != 0.0:
+            raise ValueError("beta != 0 needs an `out`")
+    _check_mat(out, "out")
+    flags = (_lib.GEMM_C_LOWER if c_lower else 0) | (_lib.GEMM_A_LOWER if a_lower else 0)
+    _lib.check(
+        lib.gpar_gemm(
+            int(ta), int(tb), m, n, k, float(alpha), A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), float(beta),
+            out.data_ptr(), _ld(out), flags, stream_ptr(A.device),
+        ),
+        "gpar_gemm",
+    )
+    return out
+
+
+def logpdf_finalize(logdet, quad, quad_sign, n):
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float64, device=logdet.device)
+    _lib.check(
+        lib.gpar_logpdf_finalize(logdet.data_ptr(), quad.data_ptr(), float(quad_sign), int(n), out.data_ptr(), stream_ptr(logdet.device)),
+        "gpar_logpdf_finalize",
+    )
+    return out
+
+
+def copy_strided_(src, src_inc, dst, dst_inc, n):
+    lib = _lib.load()
+    _lib.check(
+        lib.gpar_copy_strided(src.data_ptr(), int(src_inc), dst.data_ptr(), int(dst_inc), int(n), stream_ptr(dst.device)),
+        "gpar_copy_strided",
+    )
+    return dst
+
+
+def fill_(dst, value):
+    lib = _lib.load()
+    _check_mat(dst, "dst")
+    rows, cols = (1, dst.shape[0]) if dst.dim() == 1 else dst.shape
+    _lib.check(lib.gpar_fill(dst.data_ptr(), rows, cols, _ld(dst), float(value), stream_ptr(dst.device)), "gpar_fill")
+    return dst
+
+
+def dot(x, incx, y, incy, n, out=None, accumulate=False):
+    lib = _lib.load()
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float64, device=x.device)
+    _lib.check(
+        lib.gpar_dot(x.data_ptr(), int(incx), y.data_ptr(), int(incy), int(n), out.data_ptr(), int(accumulate), stream_ptr(x.device)),
+        "gpar_dot",
+    )
+    return out
+
+
+def randn(seed, offset, rows, cols, device):
+    lib = _lib.load()
+    out = alloc_matrix(rows, cols, device)
+    _lib.check(
+        lib.gpar_randn(int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), out.data_ptr(), rows, cols, _ld(out), stream_ptr(device)),
+        "gpar_randn",
+    )
+    return out

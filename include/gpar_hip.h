@@ -1,0 +1,154 @@
+/*
+ * gpar_hip.h — C ABI of libgpar_hip.so: the MI355X (gfx950) implementation of GPAR's
+ * per-layer GP inference hot path.
+ *
+ * What this boundary replaces.  The reference (wesselb/gpar 0.3.2) contains no native code: every
+ * Gram matrix, Cholesky factorisation and triangular solve is executed inside third-party Python
+ * packages (stheno / mlkernels / matrix / lab -> torch CPU fp64 -> LAPACK), reached from
+ *   - gpar/model.py:226      f.measure.logpdf(obs)            (Gram + potrf + trsv, per layer)
+ *   - gpar/model.py:298-301  (f | obs).mean(x_)               (posterior mean)
+ *   - gpar/model.py:264,270  f(x[, noise]).sample()           (posterior covariance + potrf + sample)
+ *   - gpar/model.py:286-289  Obs / PseudoObs construction     (dense / inducing-point observations)
+ *   - gpar/regression.py:92-180  kernel algebra of one layer  (which Gram matrix is built)
+ *   - gpar/regression.py:459 minimise_l_bfgs_b(objective...)  (objective + gradient)
+ * Each entry point below cites the call site whose arithmetic it performs.  A binding a maintainer of
+ * the reference would add (ctypes) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - All matrices are ROW-MAJOR IEEE fp64 in device (HBM) memory with an explicit leading dimension
+ *     (elements between consecutive rows).  For symmetric matrices the LOWER triangle is authoritative;
+ *     the strict upper triangle is never read and may hold anything.
+ *   - Plain pointers and sizes only.  The caller owns every buffer, including workspace; the library
+ *     never allocates or frees device memory and never synchronises the device, so every call is
+ *     asynchronous on `stream` (a hipStream_t passed as void*) and hipGraph-capturable.
+ *   - Return value: 0 = launched OK; < 0 = -(hipError_t) or -1000-x for argument errors.  Numerical
+ *     failure (non-positive pivot) is reported LAPACK-style through a device-side `info` word
+ *     (1-based index of the first bad pivot, 0 = success) so that no host sync is forced.
+ *   - Pointers should be 16-byte aligned and leading dimensions even for the vectorised paths; other
+ *     values are accepted and take a slower scalar path.
+ */
+#ifndef GPAR_HIP_H
+#define GPAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPAR_ABI_VERSION 1
+
+/* ---- kernel specification -------------------------------------------------------------------
+ * A GPAR layer kernel (gpar/regression.py:92-180) is a sum of products of elementary kernels applied
+ * to selected, rescaled (and possibly periodically embedded) input columns.  It is handed over in two
+ * flat structs:
+ *   gpar_fspec_t : how a raw design row x (m inputs + previous outputs, gpar/model.py:320) becomes a
+ *                  feature row z:  z[q] = embed_q(x[col[q]]) * inv_scale[q]
+ *                  embed 0: identity   1: sin(freq*x)   2: cos(freq*x)   (mlkernels .periodic()).
+ *   gpar_kspec_t : k(z, z') = sum_t coef[t] * prod_{f in term t} phi_f(z[off:off+nd], z'[off:off+nd])
+ *                  phi EQ: exp(-r2/2); RQ: (1 + r2/(2 alpha))^-alpha; LINEAR: <z, z'>; r2 = |z - z'|^2.
+ *                  A term without factors is the constant kernel `coef`.
+ */
+#define GPAR_MAX_DIMS 96
+#define GPAR_MAX_FACTORS 12
+#define GPAR_MAX_TERMS 8
+
+#define GPAR_EMBED_ID 0
+#define GPAR_EMBED_SIN 1
+#define GPAR_EMBED_COS 2
+
+#define GPAR_K_EQ 0
+#define GPAR_K_RQ 1
+#define GPAR_K_LINEAR 2
+
+typedef struct {
+    int32_t dz;                      /* number of feature dims (<= GPAR_MAX_DIMS) */
+    int32_t pad_;
+    int32_t col[GPAR_MAX_DIMS];      /* source column of x */
+    int32_t embed[GPAR_MAX_DIMS];    /* GPAR_EMBED_* */
+    double inv_scale[GPAR_MAX_DIMS]; /* 1 / length scale */
+    double freq[GPAR_MAX_DIMS];      /* 2*pi / period (periodic dims only) */
+} gpar_fspec_t;
+
+typedef struct {
+    int32_t type; /* GPAR_K_* */
+    int32_t term; /* index of the product term this factor multiplies into */
+    int32_t off;  /* first feature dim */
+    int32_t nd;   /* number of feature dims (0 allowed: EQ/RQ -> 1, LINEAR -> 0) */
+    double alpha; /* RQ shape */
+} gpar_factor_t;
+
+typedef struct {
+    int32_t nterms;
+    int32_t nfactors;
+    double coef[GPAR_MAX_TERMS];
+    gpar_factor_t factor[GPAR_MAX_FACTORS];
+} gpar_kspec_t;
+
+/* flags */
+#define GPAR_GRAM_LOWER 1  /* symmetric Gram (z1 == z2): write only tiles that touch the lower triangle */
+#define GPAR_GEMM_C_LOWER 1 /* C is square-aligned: compute/store only elements with col <= row */
+#define GPAR_GEMM_A_LOWER 2 /* treat op(A) as lower triangular (entries with k > m are zero) */
+
+int gpar_abi_version(void);
+size_t gpar_sizeof_fspec(void);
+size_t gpar_sizeof_kspec(void);
+
+/* z = features(x).  x: n x (>= max col+1) ldx; z: n x dz ldz.   [mlkernels stretch/periodic/select,
+ * reached from gpar/regression.py:110,127-129,138,146,166,178] */
+int gpar_featurize(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* z, int ldz, void* stream);
+
+/* K[a][b] = k(z1[a], z2[b]) (+ diag_add[a] + diag_const if a == b and z1 == z2).
+ * [mlkernels K(x, y); f(x, noise / w) adds diag(noise / w): gpar/model.py:287-289; lab's B.epsilon jitter] */
+int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2,
+              int dz, double* K, int ldk, int flags, const double* diag_add, double diag_const, void* stream);
+
+/* out[a] = k(z[a], z[a])   [kernel diagonal; VFE trace term, posterior marginal variances] */
+int gpar_gram_diag(const gpar_kspec_t* ks, const double* z, int n, int ldz, int dz, double* out, void* stream);
+
+/* Partial right-looking blocked Cholesky of the leading `nf` columns of the symmetric N x N matrix A
+ * (lower triangle).  On exit A[:, :nf] holds L (N x nf, lower trapezoid) and A[nf:, nf:] holds the Schur
+ * complement A22 - L21 L21^T.  nf == N is the ordinary potrf.  logdet (device, optional) += 2*sum log L_jj;
+ * info (device, optional) = first non-positive pivot (1-based), untouched on success (zero it first).
+ * Appending rows below K turns this one routine into the whole exact-GP computation:
+ *   row  [y^T, 0]      -> z^T = (L^-1 y)^T and -|z|^2          (log marginal likelihood, gpar/model.py:226)
+ *   rows [K_*x, K_**]  -> V^T = K_*x L^-T and K_** - V^T V      (posterior covariance, gpar/model.py:264,270)
+ * [matrix.cholesky -> torch.linalg.cholesky (LAPACK dpotrf)] */
+int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, void* stream);
+
+/* B <- B L^-T  (right side, lower, transposed: forward substitution on the rows of B; B is nrows x n).
+ * [solve_triangular inside matrix.iqf_diag / PosteriorKernel, reached from gpar/model.py:226,264,298] */
+int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);
+/* B <- B L^-1  (right side, lower, not transposed: backward substitution on the rows of B). */
+int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);
+
+/* C <- alpha * op(A) op(B) + beta * C with op(A) m x k, op(B) k x n.  ta: A is stored k x m (transposed);
+ * tb: B is stored n x k (transposed).  fp64 on the matrix cores (v_mfma_f64_4x4x4_4b).
+ * [B.matmul in lab: K_*x alpha, V^T V, chol(var) z] */
+int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
+              int ldb, double beta, double* C, int ldc, int flags, void* stream);
+
+/* Small device-side utilities used by the fused paths (all asynchronous). */
+/* out[0] = -0.5 * (logdet[0] + n*log(2*pi) + quad_sign * quad[0])   [Normal.logpdf] */
+int gpar_logpdf_finalize(const double* logdet, const double* quad, double quad_sign, int n, double* out, void* stream);
+/* dst[i*ldd] = src[i*lds], i < n  (strided vector copy: y into the augmented row, diagonals out) */
+int gpar_copy_strided(const double* src, int lds, double* dst, int ldd, int n, void* stream);
+/* dst[r][c] = value for r < rows, c < cols */
+int gpar_fill(double* dst, int rows, int cols, int ldd, double value, void* stream);
+/* out[0] (+)= sum_i x[i*incx]*y[i*incy] */
+int gpar_dot(const double* x, int incx, const double* y, int incy, int n, double* out, int accumulate, void* stream);
+/* Standard normals from Philox-4x32-10 + Box-Muller: out[r][c], element index = r*cols + c in the stream
+ * identified by (seed, offset).   [B.randn in Normal.sample] */
+int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, int ldo, void* stream);
+
+/* Profiling hook for bench.py: when enabled, every trailing-update SYRK launched by gpar_potrf is
+ * bracketed by hipEvents on its own stream; the accumulated (launches, milliseconds, flops) can be read
+ * back (this call synchronises the recorded events). */
+int gpar_profile_enable(int on);
+int gpar_profile_read(int* launches, double* ms, double* flops, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPAR_HIP_H */

@@ -1,0 +1,235 @@
+"""GPU parity of the C-ABI primitives against numpy/scipy fp64 (oracle) on seeded inputs.
+
+Tolerances (fp64): GEMM-type results are compared with rtol 1e-12 scaled by the magnitude of the summands
+(different summation order than numpy's BLAS); Cholesky factors / solves of well-conditioned matrices with
+rtol 1e-10; Philox uniforms are bit-exact so normals agree to ~1e-14.
+"""
+import numpy as np
+import pytest
+import scipy.linalg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from gpar_amd import hip
+
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+
+    def to_dev(a, pad=True):
+        a = np.asarray(a, dtype=np.float64)
+        if a.ndim == 1:
+            return torch.tensor(a, dtype=torch.float64, device=dev)
+        if pad:
+            out = hip.alloc_matrix(a.shape[0], a.shape[1], dev)
+            out.copy_(torch.tensor(a, dtype=torch.float64))
+            return out
+        return torch.tensor(a, dtype=torch.float64, device=dev)
+
+    return torch, hip, dev, to_dev
+
+
+def _spd(rng, n, cond=1e3):
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    d = np.exp(rng.uniform(0, np.log(cond), n))
+    return (q * d) @ q.T
+
+
+@pytest.mark.parametrize("ta", [False, True])
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("mnk", [(1, 1, 1), (5, 7, 3), (128, 128, 16), (130, 257, 33), (300, 64, 200), (64, 515, 129)])
+@pytest.mark.parametrize("pad", [True, False])
+def test_gemm(env, ta, tb, mnk, pad):
+    torch, hip, dev, to_dev = env
+    m, n, k = mnk
+    rng = np.random.default_rng(m * 1000 + n * 10 + k)
+    A = rng.standard_normal((k, m) if ta else (m, k))
+    B = rng.standard_normal((n, k) if tb else (k, n))
+    C = rng.standard_normal((m, n))
+    opA = A.T if ta else A
+    opB = B.T if tb else B
+    ref = 0.7 * opA @ opB - 1.3 * C
+    dC = to_dev(C, pad)
+    hip.gemm(to_dev(A, pad), to_dev(B, pad), ta=ta, tb=tb, alpha=0.7, beta=-1.3, out=dC)
+    scale = np.abs(opA) @ np.abs(opB) + np.abs(C)
+    assert np.all(np.abs(dC.cpu().numpy() - ref) <= 1e-13 * scale + 1e-300)
+    # beta = 0 must not read C (NaN-filled output buffer)
+    dC2 = to_dev(np.full((m, n), np.nan), pad)
+    hip.gemm(to_dev(A, pad), to_dev(B, pad), ta=ta, tb=tb, alpha=1.0, beta=0.0, out=dC2)
+    assert np.all(np.abs(dC2.cpu().numpy() - opA @ opB) <= 1e-13 * scale)
+
+
+def test_gemm_asymmetric_identity(env):
+    # A = I against an asymmetric B catches transposed / permuted output maps
+    torch, hip, dev, to_dev = env
+    n = 200
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    out = hip.gemm(to_dev(np.eye(n)), to_dev(B)).cpu().numpy()
+    assert np.array_equal(out, B)
+    out = hip.gemm(to_dev(np.eye(n)), to_dev(B), tb=True).cpu().numpy()
+    assert np.array_equal(out, B.T)
+
+
+@pytest.mark.parametrize("n", [70, 256, 300])
+def test_gemm_lower_flags(env, n):
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    P = rng.standard_normal((n, 40))
+    C = rng.standard_normal((n, n))
+    dC = to_dev(C)
+    hip.gemm(to_dev(P), to_dev(P), tb=True, alpha=-1.0, beta=1.0, out=dC, c_lower=True)
+    got = dC.cpu().numpy()
+    ref = C - P @ P.T
+    il = np.tril_indices(n)
+    iu = np.triu_indices(n, 1)
+    assert np.allclose(got[il], ref[il], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(got[iu], C[iu])  # strict upper triangle untouched
+    # triangular op(A): out = tril(L) @ Z with junk above the diagonal of L
+    L = rng.standard_normal((n, n))
+    Z = rng.standard_normal((n, 9))
+    got = hip.gemm(to_dev(L), to_dev(Z), a_lower=True).cpu().numpy()
+    assert np.allclose(got, np.tril(L) @ Z, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 64, 65, 127, 128, 129, 200, 513, 1000, 1700])
+def test_potrf_full(env, n):
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    A = _spd(rng, n)
+    dA = to_dev(np.tril(A) + np.triu(np.full((n, n), np.nan), 1))  # upper triangle must never be read
+    logdet, info = hip.potrf_(dA)
+    L = np.tril(dA.cpu().numpy())
+    Lref = np.linalg.cholesky(A)
+    assert int(info.item()) == 0
+    assert np.allclose(L, Lref, rtol=1e-10, atol=1e-12)
+    assert np.isclose(logdet.item(), 2 * np.sum(np.log(np.diag(Lref))), rtol=1e-12)
+
+
+def test_potrf_not_pd_reports_info(env):
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(0)
+    n = 150
+    A = _spd(rng, n)
+    A[100, 100] = -5.0
+    _, info = hip.potrf_(to_dev(A))
+    assert int(info.item()) == 101
+
+
+@pytest.mark.parametrize("N,nf", [(10, 4), (130, 64), (300, 257), (700, 300), (1400, 1399)])
+def test_potrf_partial_schur(env, N, nf):
+    """Factor the leading nf columns; the trailing block must hold the Schur complement (this is what turns
+    one routine into logpdf + posterior mean + posterior covariance)."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(N + nf)
+    A = _spd(rng, N)
+    dA = to_dev(A)
+    hip.potrf_(dA, nf=nf)
+    got = dA.cpu().numpy()
+    L11 = np.linalg.cholesky(A[:nf, :nf])
+    L21 = scipy.linalg.solve_triangular(L11, A[:nf, nf:], lower=True).T
+    S = A[nf:, nf:] - L21 @ L21.T
+    assert np.allclose(np.tril(got[:nf, :nf]), L11, rtol=1e-10, atol=1e-12)
+    assert np.allclose(got[nf:, :nf], L21, rtol=1e-9, atol=1e-11)
+    il = np.tril_indices(N - nf)
+    assert np.allclose(got[nf:, nf:][il], S[il], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,rows", [(1, 1), (50, 3), (64, 64), (200, 1), (333, 130), (1000, 70)])
+def test_trsm(env, n, rows):
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n + rows)
+    L = np.linalg.cholesky(_spd(rng, n))
+    B = rng.standard_normal((rows, n))
+    dL = to_dev(L + np.triu(np.full((n, n), np.nan), 1))
+    X = hip.trsm_rlt_(dL, to_dev(B)).cpu().numpy()
+    assert np.allclose(X, scipy.linalg.solve_triangular(L, B.T, lower=True).T, rtol=1e-9, atol=1e-11)
+    X = hip.trsm_rln_(dL, to_dev(B)).cpu().numpy()
+    assert np.allclose(X, scipy.linalg.solve_triangular(L, B.T, lower=True, trans="T").T, rtol=1e-9, atol=1e-11)
+
+
+def test_randn_matches_philox_oracle(env):
+    torch, hip, dev, to_dev = env
+    from oracle import philox
+
+    for rows, cols, seed, off in [(1, 1, 1, 0), (7, 3, 42, 5), (100, 33, 2**40 + 3, 2**33)]:
+        got = hip.randn(seed, off, rows, cols, dev).cpu().numpy()
+        ref = philox.randn(seed, off, rows, cols)
+        assert np.allclose(got, ref, rtol=0, atol=1e-13)
+    z = hip.randn(3, 0, 2000, 500, dev).cpu().numpy()
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
+
+
+def test_small_utilities(env):
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(5)
+    x, y = rng.standard_normal(5000), rng.standard_normal(5000)
+    d = hip.dot(to_dev(x), 1, to_dev(y), 1, 5000)
+    assert np.isclose(d.item(), x @ y, rtol=1e-12)
+    A = to_dev(rng.standard_normal((40, 40)))
+    v = to_dev(np.zeros(40))
+    hip.copy_strided_(A, A.stride(0) + 1, v, 1, 40)
+    assert np.array_equal(v.cpu().numpy(), np.diag(A.cpu().numpy()))
+    hip.fill_(A, 2.5)
+    assert np.all(A.cpu().numpy() == 2.5)
+    out = hip.logpdf_finalize(to_dev(np.array([3.0])), to_dev(np.array([-4.0])), -1.0, 10)
+    assert np.isclose(out.item(), -0.5 * (3.0 + 10 * np.log(2 * np.pi) + 4.0))
+
+
+def _kernels(m, p_cols):
+    """A zoo of GPAR-shaped kernels over m inputs and the given output columns."""
+    from gpar_amd.kernels import EQ, RQ, Linear, ZeroKernel
+
+    rng = np.random.default_rng(m + len(p_cols))
+    mi = list(range(m))
+    s = lambda k: rng.uniform(0.5, 2.0, k)
+    zoo = {}
+    zoo["eq"] = (1.3 * EQ().stretch(s(m))).select(mi)
+    zoo["rq"] = (0.7 * RQ(0.4).stretch(s(m))).select(mi)
+    zoo["eq+lin+const"] = (2.0 * EQ().stretch(s(m)) + Linear().stretch(s(m)) + 0.5).select(mi)
+    zoo["locally-periodic"] = (
+        1.1 * EQ().stretch(s(m)) + 0.9 * EQ().stretch(s(2 * m)).periodic(s(m)) * EQ().stretch(10 * s(m))
+    ).select(mi)
+    if p_cols:
+        k_out = Linear().stretch(s(len(p_cols))) + 0.8 * EQ().stretch(s(len(p_cols)))
+        zoo["gpar-layer"] = (1.0 * EQ().stretch(s(m))).select(mi) + k_out.select(p_cols)
+        zoo["gpar-layer-rq"] = (1.0 * RQ(1.5).stretch(s(m))).select(mi) + (
+            Linear().stretch(s(len(p_cols))) + 0.8 * RQ(0.2).stretch(s(len(p_cols)))
+        ).select(p_cols)
+    # markov=0 quirk: output kernels over zero columns: EQ -> 1, Linear -> 0
+    zoo["zero-width-outputs"] = (1.0 * EQ().stretch(s(m))).select(mi) + (
+        Linear().stretch(np.zeros(0)) + 0.6 * EQ().stretch(np.zeros(0))
+    ).select([])
+    zoo["zero"] = ZeroKernel()
+    return zoo
+
+
+@pytest.mark.parametrize("m,p_cols", [(1, []), (2, [2]), (3, [3, 4, 5]), (4, [6, 7])])
+@pytest.mark.parametrize("n1,n2", [(1, 1), (50, 70), (64, 64), (129, 200)])
+def test_gram_matches_oracle(env, m, p_cols, n1, n2):
+    torch, hip, dev, to_dev = env
+    from gpar_amd.kernels import compile_kernel
+    from oracle import kernels as ok
+
+    width = m + (max(p_cols) - m + 1 if p_cols else 0)
+    rng = np.random.default_rng(n1 * 7 + n2)
+    x1, x2 = rng.standard_normal((n1, width)), rng.standard_normal((n2, width))
+    for name, k in _kernels(m, p_cols).items():
+        ck = compile_kernel(k, width)
+        spec = ok.spec_to_dict(k.resolve(width))
+        z1, z2 = hip.featurize(ck, to_dev(x1)), hip.featurize(ck, to_dev(x2))
+        got = hip.gram(ck, z1, z2).cpu().numpy()
+        ref = ok.gram(spec, x1, x2)
+        assert np.allclose(got, ref, rtol=1e-13, atol=1e-14), name
+        # symmetric, lower-only, with noise diagonal + jitter
+        noise = rng.uniform(0.01, 0.1, n1)
+        K = to_dev(np.full((n1, n1), np.nan))
+        hip.gram(ck, z1, None, out=K, lower=True, diag_add=to_dev(noise), diag_const=1e-12)
+        got = K.cpu().numpy()
+        ref = ok.gram(spec, x1, None, noise_diag=noise, jitter=1e-12)
+        il = np.tril_indices(n1)
+        assert np.allclose(got[il], ref[il], rtol=1e-13, atol=1e-14), name
+        assert np.allclose(hip.gram_diag(ck, z1).cpu().numpy(), ok.gram_diag(spec, x1), rtol=1e-13, atol=1e-14), name
