@@ -21,3 +21,12 @@ static inline int gpar_hip_status(hipError_t e) { return e == hipSuccess ? 0 : -
 static inline int gpar_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 static inline bool gpar_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// Broadcast lane `src` (compile-time constant after unrolling) of a double to the whole wave through SGPRs
+// (v_readlane_b32 x2) instead of the LDS crossbar (ds_bpermute) that __shfl lowers to.
+__device__ __forceinline__ double gpar_readlane_f64(double v, int src) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}

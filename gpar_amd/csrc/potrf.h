@@ -17,36 +17,51 @@ constexpr int POTRF_NBI = 64;   // inner block (diag / strip width)
 
 // ---------------------------------------------------------------------------------------------------
 // 64 x 64 (or smaller, cb <= 64) diagonal block, one wave.  A points at the block's (0,0).
+// Lane i owns row i in registers; step j: the pivot is broadcast with a wave shuffle (v_readlane), the
+// column is scaled by the reciprocal pivot (as LAPACK's dpotf2 does: DSCAL by 1/ajj), published through LDS
+// and applied as a rank-1 update.  Only the lower triangle is read or written.
 __global__ __launch_bounds__(64) void potrf_diag64_kernel(double* __restrict__ A, int lda, int cb, int col0,
                                                           double* __restrict__ logdet, int* __restrict__ info) {
+    __shared__ double T[64 * 65];
     __shared__ double colbuf[2][64];
     const int i = threadIdx.x;
+    {
+        double v[64];
+#pragma unroll
+        for (int r = 0; r < 64; ++r) v[r] = (r < cb && i < cb && i <= r) ? A[(size_t)r * lda + i] : ((r == i) ? 1.0 : 0.0);
+#pragma unroll
+        for (int r = 0; r < 64; ++r) T[r * 65 + i] = v[r];
+    }
+    __syncthreads();
     double a[64];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) a[j] = (i < cb && j < cb && j <= i) ? A[(size_t)i * lda + j] : ((i == j) ? 1.0 : 0.0);
+    for (int j = 0; j < 64; ++j) a[j] = T[i * 65 + j];
 
-    double ld = 0.0;
+    double mydiag = 1.0;
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-        if (j < cb) {
-            const double d = __shfl(a[j], j, 64);
-            if (!(d > 0.0) && bad == 0) bad = col0 + j + 1;
-            const double s = sqrt(d);
-            ld += 2.0 * log(s);
-            const double lij = (i == j) ? s : a[j] / s;
-            a[j] = lij;
-            colbuf[j & 1][i] = lij;
-            __syncthreads();
+        const double d = gpar_readlane_f64(a[j], j);
+        if (!(d > 0.0) && bad == 0 && j < cb) bad = col0 + j + 1;
+        const double s = sqrt(d);
+        const double rinv = 1.0 / s;
+        const double lij = (i == j) ? s : a[j] * rinv;
+        if (i == j) mydiag = s;
+        a[j] = lij;
+        colbuf[j & 1][i] = lij;
+        __syncthreads();
 #pragma unroll
-            for (int k = j + 1; k < 64; ++k) a[k] = fma(-lij, colbuf[j & 1][k], a[k]);
-        }
+        for (int k = j + 1; k < 64; ++k) a[k] = fma(-lij, colbuf[j & 1][k], a[k]);
     }
-    if (i < cb) {
 #pragma unroll
-        for (int j = 0; j < 64; ++j)
-            if (j < cb && j <= i) A[(size_t)i * lda + j] = a[j];
-    }
+    for (int j = 0; j < 64; ++j) T[i * 65 + j] = a[j];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 64; ++r)
+        if (r < cb && i <= r) A[(size_t)r * lda + i] = T[r * 65 + i];
+    double ld = (i < cb) ? 2.0 * log(mydiag) : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ld += __shfl_xor(ld, off, 64);
     if (i == 0) {
         if (logdet) atomicAdd(logdet, ld);
         if (bad && info) atomicCAS(info, 0, bad);
@@ -54,11 +69,70 @@ __global__ __launch_bounds__(64) void potrf_diag64_kernel(double* __restrict__ A
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Strip solve against a (cb <= 64) triangular block Ld, 64 rows of B per wave (one row per lane).
-//   FWD:  X Ld^T = B   (x_j = (b_j - sum_{k<j} x_k L[j][k]) / L[j][j], right-looking elimination)
-//   !FWD: X Ld   = B   (x_j = (b_j - sum_{i>j} x_i L[i][j]) / L[j][j], j descending)
-// LDS holds Ld^T (FWD) or Ld (!FWD) so that the coefficients needed after x_j is known are one contiguous,
-// wave-uniform (broadcast) row; B is staged through a padded LDS tile so global traffic is coalesced.
+// Strip solve against a full 64 x 64 lower-triangular block Ld, 64 rows of B per wave, one row per lane
+// held in registers.  Only rows of the lower triangle of Ld are read.
+//   FWD:  X Ld^T = B   left-looking:  x_j = (b_j - sum_{k<j} x_k L[j][k]) / L_jj   (4 partial sums)
+//   !FWD: X Ld   = B   right-looking, j descending: x_j = b_j / L_jj, then b_q -= x_j L[j][q] for q < j
+// Ld is staged once into LDS (one coalesced round trip); every coefficient is then a wave-uniform
+// (broadcast) LDS read, two per ds_read_b128.  Reciprocal pivots are computed one per lane and broadcast with
+// v_readlane, so there is no division on the dependency chain.  B goes through a padded LDS tile so global
+// traffic stays coalesced; all global loads of a phase are issued before the first is consumed.
+template <bool FWD>
+__global__ __launch_bounds__(64) void trsm_strip64_kernel(const double* __restrict__ Ld, int ldl,
+                                                          double* __restrict__ B, int ldb, int nrows) {
+    __shared__ __attribute__((aligned(16))) double Ls[64 * 64];
+    __shared__ double Bt[64 * 65];
+    const int lane = threadIdx.x;
+    const int row0 = blockIdx.x * 64;
+    {
+        double v[64];
+#pragma unroll
+        for (int r = 0; r < 64; ++r) v[r] = (lane <= r) ? Ld[(size_t)r * ldl + lane] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) Ls[r * 64 + lane] = v[r];
+#pragma unroll
+        for (int r = 0; r < 64; ++r) v[r] = (row0 + r < nrows) ? B[(size_t)(row0 + r) * ldb + lane] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) Bt[r * 65 + lane] = v[r];
+    }
+    __syncthreads();
+    const double my_rinv = 1.0 / Ls[lane * 64 + lane];
+    double a[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) a[j] = Bt[lane * 65 + j];
+    if (FWD) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            double s0 = a[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                const double c = Ls[j * 64 + k];
+                if ((k & 3) == 0) s0 = fma(-a[k], c, s0);
+                else if ((k & 3) == 1) s1 = fma(-a[k], c, s1);
+                else if ((k & 3) == 2) s2 = fma(-a[k], c, s2);
+                else s3 = fma(-a[k], c, s3);
+            }
+            a[j] = ((s0 + s1) + (s2 + s3)) * gpar_readlane_f64(my_rinv, j);
+        }
+    } else {
+#pragma unroll
+        for (int j = 63; j >= 0; --j) {
+            const double x = a[j] * gpar_readlane_f64(my_rinv, j);
+            a[j] = x;
+#pragma unroll
+            for (int q = 0; q < j; ++q) a[q] = fma(-x, Ls[j * 64 + q], a[q]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 64; ++j) Bt[lane * 65 + j] = a[j];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 64; ++r)
+        if (row0 + r < nrows) B[(size_t)(row0 + r) * ldb + lane] = Bt[r * 65 + lane];
+}
+
+// Generic (cb < 64) strip solve: coefficients staged in LDS with identity padding.  Only the ragged last
+// block of a matrix takes this path.
 template <bool FWD>
 __global__ __launch_bounds__(64) void trsm_strip_kernel(const double* __restrict__ Ld, int ldl, int cb,
                                                         double* __restrict__ B, int ldb, int nrows) {
@@ -67,15 +141,21 @@ __global__ __launch_bounds__(64) void trsm_strip_kernel(const double* __restrict
     const int lane = threadIdx.x;
     const int row0 = blockIdx.x * 64;
     // coefficient matrix: Ls[j][q] = FWD ? L[q][j] : L[j][q], identity outside cb
-    for (int r = 0; r < 64; ++r) {
-        double v = (r == lane) ? 1.0 : 0.0;
-        if (r < cb && lane < cb && lane <= r) v = Ld[(size_t)r * ldl + lane];   // L[r][lane], coalesced
-        if (FWD) Ls[lane * 65 + r] = v; else Ls[r * 65 + lane] = v;
-    }
-    for (int r = 0; r < 64; ++r) {
-        double v = 0.0;
-        if (row0 + r < nrows && lane < cb) v = B[(size_t)(row0 + r) * ldb + lane];
-        Bt[r * 65 + lane] = v;
+    {
+        double v[64];
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            v[r] = (r == lane) ? 1.0 : 0.0;
+            if (r < cb && lane < cb && lane <= r) v[r] = Ld[(size_t)r * ldl + lane];   // L[r][lane], coalesced
+        }
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            if (FWD) Ls[lane * 65 + r] = v[r]; else Ls[r * 65 + lane] = v[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 64; ++r) v[r] = (row0 + r < nrows && lane < cb) ? B[(size_t)(row0 + r) * ldb + lane] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) Bt[r * 65 + lane] = v[r];
     }
     __syncthreads();
     double a[64];
@@ -103,6 +183,14 @@ __global__ __launch_bounds__(64) void trsm_strip_kernel(const double* __restrict
     __syncthreads();
     for (int r = 0; r < 64; ++r)
         if (row0 + r < nrows && lane < cb) B[(size_t)(row0 + r) * ldb + lane] = Bt[r * 65 + lane];
+}
+
+template <bool FWD>
+static void launch_strip(const double* Ld, int ldl, int cb, double* B, int ldb, int nrows, hipStream_t stream) {
+    if (nrows <= 0) return;
+    const dim3 grid(gpar_ceil_div(nrows, 64)), block(64);
+    if (cb == 64) hipLaunchKernelGGL((trsm_strip64_kernel<FWD>), grid, block, 0, stream, Ld, ldl, B, ldb, nrows);
+    else hipLaunchKernelGGL((trsm_strip_kernel<FWD>), grid, block, 0, stream, Ld, ldl, cb, B, ldb, nrows);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -148,8 +236,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             const int r0 = c + cb;
             const int below = N - r0;
             if (below > 0) {
-                hipLaunchKernelGGL((trsm_strip_kernel<true>), dim3(gpar_ceil_div(below, 64)), dim3(64), 0, stream,
-                                   (const double*)Acc, lda, cb, A + (size_t)r0 * lda + c, lda, below);
+                launch_strip<true>(Acc, lda, cb, A + (size_t)r0 * lda + c, lda, below, stream);
                 const int ncols = kend - r0;   // remaining columns of this panel
                 if (ncols > 0) {
                     const double* P = A + (size_t)r0 * lda + c;
@@ -192,8 +279,7 @@ static int trsm_rlt_run(const double* L, int n, int ldl, double* B, int nrows, i
     if (nrows <= 0) return 0;
     for (int c = 0; c < n; c += POTRF_NBI) {
         const int cb = (n - c < POTRF_NBI) ? n - c : POTRF_NBI;
-        hipLaunchKernelGGL((trsm_strip_kernel<true>), dim3(gpar_ceil_div(nrows, 64)), dim3(64), 0, stream,
-                           L + (size_t)c * ldl + c, ldl, cb, B + c, ldb, nrows);
+        launch_strip<true>(L + (size_t)c * ldl + c, ldl, cb, B + c, ldb, nrows, stream);
         const int rest = n - (c + cb);
         if (rest > 0) {
             int rc = gemm_launch(0, 1, nrows, rest, cb, -1.0, B + c, ldb, L + (size_t)(c + cb) * ldl + c, ldl, 1.0,
@@ -213,8 +299,7 @@ static int trsm_rln_run(const double* L, int n, int ldl, double* B, int nrows, i
     for (int b = nblk - 1; b >= 0; --b) {
         const int c = b * POTRF_NBI;
         const int cb = (n - c < POTRF_NBI) ? n - c : POTRF_NBI;
-        hipLaunchKernelGGL((trsm_strip_kernel<false>), dim3(gpar_ceil_div(nrows, 64)), dim3(64), 0, stream,
-                           L + (size_t)c * ldl + c, ldl, cb, B + c, ldb, nrows);
+        launch_strip<false>(L + (size_t)c * ldl + c, ldl, cb, B + c, ldb, nrows, stream);
         if (c > 0) {
             int rc = gemm_launch(0, 0, nrows, c, cb, -1.0, B + c, ldb, L + (size_t)c * ldl, ldl, 1.0, B, ldb, 0, stream);
             if (rc) return rc;

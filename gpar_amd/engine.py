@@ -1,0 +1,127 @@
+"""The linear-algebra seam of gpar_amd: the set of device primitives the GP layer objects are written against.
+
+In the reference this seam is `lab` + `matrix` + `mlkernels` dispatching to torch-CPU/LAPACK;
+here the ONLY implementation shipped in the package is `HipEngine`, which forwards every primitive to
+libgpar_hip.so (hand-written gfx950 kernels) on torch-allocated HBM buffers.  There is no CPU implementation in
+this package and no fallback: constructing the default engine without the shared library or without a GPU
+raises.  (The test-suite's CPU oracle implements the same small interface in numpy under `oracle/` so that the
+host orchestration can be exercised without a GPU and the HIP results can be checked against it; it is never
+imported from here.)
+
+Primitive set (all tensors float64, row-major, lower triangles authoritative):
+    tensor(x)                         host/array-like -> device tensor
+    compile(kernel, width)            kernel algebra -> device kernel spec
+    features(ck, x)                   z = stretch(periodic(select(x)))
+    gram(ck, z1, z2=None, ...)        fused Gram (+ noise diagonal + jitter), optionally lower-only
+    gram_diag(ck, z)                  k(x_i, x_i)
+    new_matrix(r, c, zero=False)      workspace with aligned, padded rows
+    potrf_(A, nf=None)                (partial) Cholesky -> (logdet, info) device scalars
+    trsm_rlt_(L, B) / trsm_rln_(L, B) B L^-T / B L^-1
+    gemm(A, B, ta, tb, alpha, beta, out, c_lower, a_lower)
+    randn(rows, cols)                 counter-based standard normals
+"""
+import torch
+
+from . import _lib, hip
+from .kernels import compile_kernel
+
+__all__ = ["HipEngine", "get_engine", "set_engine", "NotPositiveDefiniteError"]
+
+
+class NotPositiveDefiniteError(ArithmeticError):
+    """Cholesky hit a non-positive pivot (LAPACK info > 0)."""
+
+    def __init__(self, info):
+        super().__init__(f"matrix is not positive definite: pivot {info} is not positive")
+        self.info = info
+
+
+class HipEngine:
+    name = "hip"
+
+    def __init__(self, device=None, seed=0, epsilon=1e-12):
+        _lib.load()  # raises HipLibraryError if libgpar_hip.so is missing: no fallback
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "gpar_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is False and there is no CPU fallback"
+            )
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.epsilon = float(epsilon)  # lab's B.epsilon: diagonal jitter added before every Cholesky
+        self._seed = int(seed)
+        self._calls = 0
+
+    # ---- memory ----------------------------------------------------------------------------------
+    def tensor(self, x):
+        if isinstance(x, torch.Tensor):
+            return x.detach().to(device=self.device, dtype=torch.float64)
+        return torch.as_tensor(x, dtype=torch.float64).to(self.device)
+
+    def new_matrix(self, rows, cols, zero=False):
+        return hip.alloc_matrix(rows, cols, self.device, zero=zero)
+
+    def _mat(self, a):
+        """Make `a` acceptable to the kernels (float64, on device, unit inner stride)."""
+        if a.dim() == 2 and a.shape[1] > 1 and a.stride(1) != 1:
+            a = a.contiguous()
+        return a
+
+    # ---- kernels ---------------------------------------------------------------------------------
+    def compile(self, kernel, width):
+        return compile_kernel(kernel, width)
+
+    def features(self, ck, x):
+        return hip.featurize(ck, self._mat(x))
+
+    def gram(self, ck, z1, z2=None, lower=False, diag_add=None, diag_const=0.0, out=None):
+        return hip.gram(ck, z1, z2, out=out, lower=lower, diag_add=diag_add, diag_const=diag_const)
+
+    def gram_diag(self, ck, z):
+        return hip.gram_diag(ck, z)
+
+    def potrf_(self, A, nf=None):
+        return hip.potrf_(A, nf=nf)
+
+    def trsm_rlt_(self, L, B):
+        return hip.trsm_rlt_(L, B)
+
+    def trsm_rln_(self, L, B):
+        return hip.trsm_rln_(L, B)
+
+    def gemm(self, A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False, a_lower=False):
+        return hip.gemm(self._mat(A), self._mat(B), ta=ta, tb=tb, alpha=alpha, beta=beta, out=out, c_lower=c_lower, a_lower=a_lower)
+
+    # ---- randomness ------------------------------------------------------------------------------
+    def seed(self, seed):
+        self._seed = int(seed)
+        self._calls = 0
+
+    def randn(self, rows, cols):
+        out = hip.randn(self._seed, self._calls, rows, cols, self.device)
+        self._calls += 1
+        return out
+
+    # ---- status ----------------------------------------------------------------------------------
+    @staticmethod
+    def check_info(info):
+        """Synchronise on the device-side LAPACK-style info word and raise if a pivot failed."""
+        code = int(info.item())
+        if code != 0:
+            raise NotPositiveDefiniteError(code)
+
+
+_engine = None
+
+
+def get_engine():
+    """The process-wide engine; created on first use as a HipEngine on the current GPU (raises without one)."""
+    global _engine
+    if _engine is None:
+        _engine = HipEngine()
+    return _engine
+
+
+def set_engine(engine):
+    """Install an engine object (used by the test-suite to inject its CPU oracle, and to pick a device)."""
+    global _engine
+    previous, _engine = _engine, engine
+    return previous

@@ -1,0 +1,252 @@
+"""GPAR: the autoregressive stack of GP layers (drop-in for /root/reference/gpar/model.py).
+
+Same public surface as the reference module — `GPAR(replace, impute, x_ind)` with `.add_layer`, `.copy`,
+`gpar | (x, y, w)`, `.logpdf(...)`, `.sample(...)`, and the helpers `merge`, `construct_model`, `last`,
+`per_output` — but the layers are `gpar_amd.gp.GP` objects whose Gram / Cholesky / solve work runs in the HIP
+library.  Layer i models output i given the inputs and the previous outputs: its design matrix is
+`[x, y_0 .. y_{i-1}]`, where a previous output column holds observed values, or posterior means where
+`impute` (missing rows) / `replace` (observed rows) ask for it (reference: model.py:291-322).
+
+Tensors are torch float64 on the engine's device; numpy inputs are accepted and converted.
+"""
+import numpy as np
+import torch
+
+from .engine import get_engine
+from .gp import Obs, PseudoObs
+
+__all__ = ["GPAR", "merge", "construct_model", "last", "per_output"]
+
+
+def _is_torch(a):
+    return isinstance(a, torch.Tensor)
+
+
+def _isnan(a):
+    return torch.isnan(a) if _is_torch(a) else np.isnan(a)
+
+
+def _any_along_rows(a):
+    return a.any(dim=1) if _is_torch(a) else a.any(axis=1)
+
+
+def merge(x, updates, to_update):
+    """Return `x` with the entries flagged by the boolean vector `to_update` replaced, in order, by `updates`.
+    (reference: model.py:14-44; known answers in tests/test_model.py:30-38)"""
+    if _is_torch(x):
+        out = x.clone()
+        mask = to_update if _is_torch(to_update) else torch.as_tensor(np.asarray(to_update), device=x.device)
+        out[mask] = updates if _is_torch(updates) else torch.as_tensor(updates, dtype=x.dtype, device=x.device)
+        return out
+    out = np.array(x, copy=True)
+    out[np.asarray(to_update, dtype=bool)] = np.asarray(updates)
+    return out
+
+
+def construct_model(f, noise):
+    """A layer is a zero-argument callable giving `(latent process, noise variance)` (reference: model.py:47-57)."""
+
+    def model():
+        return f, noise
+
+    return model
+
+
+def last(xs, select=None):
+    """Iterate `(is_last, x)` over `xs`, optionally keeping only the positions in `select`; `is_last` refers to the
+    position in the full sequence (reference: model.py:60-93; known answers tests/test_model.py:46-52)."""
+    wanted = None if select is None else set(select)
+    it = iter(xs)
+    try:
+        current = next(it)
+    except StopIteration:
+        return
+    index = 0
+    for upcoming in it:
+        if wanted is None or index in wanted:
+            yield False, current
+        current, index = upcoming, index + 1
+    if wanted is None or index in wanted:
+        yield True, current
+
+
+def per_output(y, w=None, keep=False):
+    """Per layer: `(y_i (n_i x 1), w_i (n_i,), mask_i)` where `mask_i` selects, among the rows that survived
+    layer i-1, those observed at output i (or, with `keep`, at any later output: rows needed to keep the data
+    closed downwards).  A dict `{keep: [items...]}` is accepted in place of `y` as a precomputed cache.
+    (reference: model.py:325-368; known answers tests/test_model.py:55-105)"""
+    if isinstance(y, dict):
+        yield from y[keep]
+        return
+    p = y.shape[1]
+    available = ~_isnan(y)
+    for i in range(p):
+        mask = available[:, i]
+        if keep and i < p - 1:
+            mask = mask | _any_along_rows(available[:, i + 1 :])
+        yield y[mask, i : i + 1], w[mask, i], mask
+        y, w, available = y[mask], w[mask], available[mask]
+
+
+class GPAR:
+    """Gaussian process autoregressive model.
+
+    Args:
+        replace (bool): feed posterior means instead of observations to later layers.
+        impute (bool): fill missing observations with posterior means so the data stay closed downwards.
+        x_ind (tensor, optional): inducing-point locations; enables the sparse (VFE) path.
+    """
+
+    def __init__(self, replace=False, impute=False, x_ind=None):
+        self.replace = replace
+        self.impute = impute
+        self.layers = []
+        self.sparse = x_ind is not None
+        self.x_ind = x_ind
+
+    def copy(self):
+        return GPAR(replace=self.replace, impute=self.impute, x_ind=self.x_ind)
+
+    def add_layer(self, model_constructor):
+        out = self.copy()
+        out.layers = self.layers + [model_constructor]
+        return out
+
+    # ---- conversions ---------------------------------------------------------------------------
+    @staticmethod
+    def _prep(x, y, w):
+        eng = get_engine()
+        x = eng.tensor(x)
+        if x.dim() == 1:
+            x = x[:, None]
+        if not isinstance(y, dict):
+            y = eng.tensor(y)
+            w = eng.tensor(w)
+        return x, y, w
+
+    def _prep_ind(self, x_ind):
+        if x_ind is None:
+            return None
+        t = get_engine().tensor(x_ind)
+        return t[:, None] if t.dim() == 1 else t
+
+    # ---- conditioning ----------------------------------------------------------------------------
+    def __or__(self, x_y_w):
+        """Posterior GPAR given data (x, y, w)."""
+        x, y, w = self._prep(*x_y_w)
+        x_ind = self._prep_ind(self.x_ind)
+        post = self.copy()
+        for is_last, ((yi, wi, mask), model) in last(zip(per_output(y, w, keep=self.impute), self.layers)):
+            x = x[mask]
+            f, noise = model()
+            obs = self._obs(x, x_ind, yi, wi, f, noise)
+            post.layers.append(construct_model(f | obs, noise))
+            if not is_last:
+                x, x_ind = self._update_inputs(x, x_ind, yi, f, obs)
+        return post
+
+    # ---- log marginal likelihood -------------------------------------------------------------------
+    def logpdf(self, x, y, w, only_last_layer=False, sample_missing=False, return_inputs=False, x_ind=None, outputs=None):
+        """Sum over layers of log N(y_i; 0, K_i([x, y_<i]) + noise_i / w_i) (the VFE bound with inducing points).
+
+        `outputs` restricts the layers visited, `x_ind` resumes a computation and `return_inputs` returns the
+        design matrix (and inducing inputs) reached after the last visited layer instead of the value — the
+        three together let `fit` precompute the inputs of a layer once (reference: model.py:178-243)."""
+        x, y, w = self._prep(x, y, w)
+        x_ind = self._prep_ind(self.x_ind if x_ind is None else x_ind)
+        total = torch.zeros((), dtype=torch.float64)
+        items = per_output(y, w, keep=self.impute or sample_missing)
+        for is_last, ((yi, wi, mask), model) in last(zip(items, self.layers), select=outputs):
+            x = x[mask]
+            f, noise = model()
+            obs = self._obs(x, x_ind, yi, wi, f, noise)
+            if not only_last_layer or is_last:
+                total = total + f.measure.logpdf(obs)
+            if not is_last:
+                missing = torch.isnan(yi[:, 0])
+                if sample_missing and bool(missing.any()):
+                    f_post = f | obs
+                    drawn = f_post(x[missing], self._noise_over(noise, wi[missing])).sample()
+                    yi = merge(yi, drawn, missing)
+                x, x_ind = self._update_inputs(x, x_ind, yi, f, obs)
+        return (x, x_ind) if return_inputs else total
+
+    # ---- sampling ----------------------------------------------------------------------------------
+    def sample(self, x, w, latent=False):
+        """One ancestral sample, n x p (reference: model.py:245-277).  With `latent` the noise-free function
+        values are returned while the noisy values are what is fed to the next layer."""
+        eng = get_engine()
+        x = eng.tensor(x)
+        if x.dim() == 1:
+            x = x[:, None]
+        w = eng.tensor(w)
+        columns = []
+        x_ind = self._prep_ind(self.x_ind)
+        for i, (is_last, model) in enumerate(last(self.layers)):
+            f, noise = model()
+            if latent:
+                f_sample = f(x).sample()
+                std = torch.sqrt(self._noise_over(noise, w[:, i : i + 1]))
+                y_sample = f_sample + std * eng.randn(f_sample.shape[0], 1)
+                columns.append(f_sample)
+            else:
+                y_sample = f(x, self._noise_over(noise, w[:, i])).sample()
+                columns.append(y_sample)
+            if not is_last:
+                x, x_ind = self._update_inputs(x, x_ind, y_sample, f, None)
+        if not columns:
+            return torch.zeros(x.shape[0], 0, dtype=torch.float64, device=x.device)
+        return torch.cat(columns, dim=1)
+
+    def sample_many(self, x, w, num_samples, latent=False):
+        """`num_samples` independent ancestral samples (the loop of reference regression.py:559-563)."""
+        return [self.sample(x, w, latent=latent) for _ in range(num_samples)]
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    @staticmethod
+    def _noise_over(noise, w):
+        """noise / w on w's device (noise is a Python float or a CPU 0-d tensor)."""
+        if _is_torch(noise):
+            noise = noise.detach().to(dtype=torch.float64)
+            if noise.dim() == 0 or noise.numel() == 1:
+                return float(noise) / w
+            return noise.to(w.device) / w
+        return float(noise) / w
+
+    def _obs(self, x, x_ind, y, w, f, noise):
+        eng = get_engine()
+        x, y, w = eng.tensor(x), eng.tensor(y), eng.tensor(w)
+        available = ~torch.isnan(y[:, 0])
+        x, y, w = x[available], y[available], w[available]
+        if self.sparse:
+            return PseudoObs(f(x_ind), f(x, self._noise_arg(noise, w)), y)
+        return Obs(f(x, self._noise_arg(noise, w)), y)
+
+    @staticmethod
+    def _noise_arg(noise, w):
+        """noise / w, keeping the autograd graph of `noise` when it has one (used by the training objective)."""
+        if _is_torch(noise) and noise.requires_grad:
+            return noise / w if noise.device == w.device or noise.dim() == 0 else noise.to(w.device) / w
+        return GPAR._noise_over(noise, w)
+
+    def _update_inputs(self, x, x_ind, y, f, obs):
+        """Append output column y to the design matrix (and the estimated output to the inducing inputs)."""
+        eng = get_engine()
+        x, y = eng.tensor(x), eng.tensor(y)
+        x_ind = None if x_ind is None else eng.tensor(x_ind)
+        available = ~torch.isnan(y[:, 0])
+        post = (f | obs) if obs else None
+
+        def estimate(x_):
+            return post.mean(x_) if post is not None else f.mean(x_)
+
+        if self.sparse:
+            x_ind = torch.cat([x_ind, estimate(x_ind)], dim=1)
+        if self.impute and self.replace:
+            y = estimate(x)
+        else:
+            if self.impute and bool((~available).any()):
+                y = merge(y, estimate(x[~available]), ~available)
+            if self.replace and bool(available.any()):
+                y = merge(y, estimate(x[available]), available)
+        return torch.cat([x, y], dim=1), x_ind

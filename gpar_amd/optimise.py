@@ -1,0 +1,68 @@
+"""L-BFGS-B driver over a `Vars` store (counterpart of `varz.torch.minimise_l_bfgs_b`, which the reference calls
+at /root/reference/gpar/regression.py:459).
+
+The objective receives the variable store and returns a torch scalar; its gradient with respect to the selected
+latent (unconstrained) variables is obtained by back-propagation — for the GP layers that is the analytic
+gradient computed on the GPU (gpar_amd/gp.py: `_LogMarginal`), chained through the bound transforms by torch.
+"""
+import logging
+
+import numpy as np
+import scipy.optimize
+import torch
+
+from .engine import NotPositiveDefiniteError
+
+__all__ = ["minimise_l_bfgs_b"]
+
+log = logging.getLogger(__name__)
+
+
+def minimise_l_bfgs_b(f, vs, names=None, iters=1000, f_calls=10000, trace=False):
+    """Minimise `f(vs)` over the variables whose names match `names` (globs allowed; default: all).
+
+    Returns the final objective value; the optimum is written back into `vs`.
+    """
+    patterns = names
+
+    def select():
+        return vs.match(patterns) if patterns is not None else vs.names
+
+    names = select()
+    if not names:
+        # the objective creates its variables lazily (reference regression.py:92-180): evaluate once
+        with torch.no_grad():
+            f(vs)
+        names = select()
+    latents = vs.get_vars(*names)
+    if not latents:
+        raise ValueError("no variables to optimise")
+    x0 = vs.get_vector(names)
+
+    def fg(x):
+        vs.set_vector(x, names)
+        previous = [t.requires_grad for t in latents]
+        for t in latents:
+            t.requires_grad_(True)
+            t.grad = None
+        try:
+            value = f(vs)
+            value.backward()
+            grad = np.concatenate(
+                [(t.grad if t.grad is not None else torch.zeros_like(t)).detach().numpy().reshape(-1) for t in latents]
+            )
+            val = float(value.detach())
+        except (NotPositiveDefiniteError, ArithmeticError) as e:  # as varz: report NaN and let the line search back off
+            log.warning("objective evaluation failed (%s); returning NaN", e)
+            val, grad = np.nan, np.zeros_like(x)
+        finally:
+            for t, r in zip(latents, previous):
+                t.requires_grad_(r)
+                t.grad = None
+        if trace:
+            print(f"  objective {val:.6e}  |grad| {np.linalg.norm(grad):.3e}")
+        return val, grad
+
+    x_opt, val, _ = scipy.optimize.fmin_l_bfgs_b(fg, x0, maxiter=iters, maxfun=f_calls)
+    vs.set_vector(x_opt, names)
+    return val

@@ -1,0 +1,266 @@
+"""GPARRegressor: sklearn-style front end (drop-in for /root/reference/gpar/regression.py).
+
+Same constructor keywords and defaults (reference regression.py:264-286), attributes (:288-326) and methods —
+`get_variables`, `condition`, `fit`, `logpdf`, `sample`, `predict` — with the same argument meaning, return
+types and exceptions.  What differs is underneath: the per-layer kernels are `gpar_amd.kernels` objects lowered
+to one fused device kernel, and every Gram / Cholesky / solve runs in libgpar_hip.so on the MI355X.
+
+Hyper-parameter names, initialisations and bounds follow reference regression.py:92-180 exactly (table in
+SURVEY.md Appendix C), so `get_variables()` dictionaries are interchangeable.
+"""
+import numpy as np
+import torch
+
+from .engine import get_engine
+from .gp import GP, Measure
+from .kernels import EQ, RQ, Linear, ZeroKernel
+from .model import GPAR, per_output
+from .optimise import minimise_l_bfgs_b
+from .vars import Vars
+
+__all__ = ["GPARRegressor", "log_transform", "squishing_transform"]
+
+
+def _xp(x):
+    return torch if isinstance(x, torch.Tensor) else np
+
+
+#: Log transform for the data: (transform, inverse).
+log_transform = (lambda x: _xp(x).log(x), lambda x: _xp(x).exp(x))
+
+#: Squishing transform for the data: sign(x) log(1 + |x|) and its inverse.
+squishing_transform = (
+    lambda x: _xp(x).sign(x) * _xp(x).log(1 + _xp(x).abs(x)),
+    lambda x: _xp(x).sign(x) * (_xp(x).exp(_xp(x).abs(x)) - 1),
+)
+
+
+def _vector_from_init(init, length):
+    """Broadcast a scalar initialisation, or take the first `length` entries of a vector one
+    (reference regression.py:31-46; known answers tests/test_regression.py:43-49)."""
+    if np.size(init) == 1:
+        return init * np.ones(length)
+    squeezed = np.squeeze(init)
+    if np.ndim(squeezed) != 1:
+        raise ValueError(f"Incorrect shape {np.shape(init)} of hyperparameters.")
+    if np.size(squeezed) < length:
+        raise ValueError("Not enough hyperparameters specified.")
+    return np.array(squeezed)[:length]
+
+
+def _determine_indices(m, pi, markov):
+    """Columns of the design matrix used by layer `pi`: the m inputs and the last `markov` previous outputs
+    (all of them for markov=None).  (reference regression.py:49-59; table tests/test_regression.py:52-83)"""
+    p_last = pi - 1
+    p_start = 0 if markov is None else max(p_last - (markov - 1), 0)
+    p_num = p_last - p_start + 1
+    return list(range(m)), list(range(m + p_start, m + p_last + 1)), p_num
+
+
+def _to_torch(x):
+    if x is None or isinstance(x, torch.Tensor):
+        return x
+    return torch.tensor(np.asarray(x))
+
+
+def _uprank(x):
+    if x.dim() == 0:
+        return x.reshape(1, 1)
+    if x.dim() == 1:
+        return x[:, None]
+    return x
+
+
+def _model_generator(vs, m, pi, scale, scale_tie, per, per_period, per_scale, per_decay, input_linear,
+                     input_linear_scale, linear, linear_scale, nonlinear, nonlinear_scale, rq, markov, noise):
+    """Constructor of layer `pi`: kernel over the inputs + kernel over the selected previous outputs, and the
+    observation-noise variance; hyper-parameters are created in `vs` on first use (reference regression.py:72-182)."""
+
+    def model():
+        m_inds, p_inds, p_num = _determine_indices(m, pi, markov)
+        k_in, k_out = ZeroKernel(), ZeroKernel()
+
+        def nonlinear_kernel(prefix):
+            return RQ(vs.bnd(name=f"{prefix}/alpha", init=1e-2, lower=1e-3, upper=1e3)) if rq else EQ()
+
+        # nonlinear kernel over the inputs
+        var = vs.bnd(name=f"{pi}/input/var", init=1.0)
+        scales = vs.bnd(name=f"{0 if scale_tie else pi}/input/scales", init=_vector_from_init(scale, m))
+        k_in = k_in + var * nonlinear_kernel(f"{pi}/input").stretch(scales)
+
+        # locally periodic kernel over the inputs
+        if per:
+            var = vs.bnd(name=f"{pi}/input/per/var", init=1.0)
+            scales = vs.bnd(name=f"{pi}/input/per/scales", init=_vector_from_init(per_scale, 2 * m))
+            periods = vs.bnd(name=f"{pi}/input/per/pers", init=_vector_from_init(per_period, m))
+            decays = vs.bnd(name=f"{pi}/input/per/decay", init=_vector_from_init(per_decay, m))
+            k_in = k_in + var * EQ().stretch(scales).periodic(periods) * EQ().stretch(decays)
+
+        # linear kernel (plus constant) over the inputs
+        if input_linear:
+            scales = vs.bnd(name=f"{pi}/input/lin/scales", init=_vector_from_init(input_linear_scale, m))
+            const = vs.get(name=f"{pi}/input/lin/const", init=1.0)
+            k_in = k_in + (Linear().stretch(scales) + const)
+
+        # linear dependencies on the previous outputs
+        if linear and pi > 0:
+            scales = vs.bnd(name=f"{pi}/output/lin/scales", init=_vector_from_init(linear_scale, p_num))
+            k_out = k_out + Linear().stretch(scales)
+
+        # nonlinear dependencies on the previous outputs
+        if nonlinear and pi > 0:
+            var = vs.bnd(name=f"{pi}/output/nonlin/var", init=1.0)
+            scales = vs.bnd(name=f"{pi}/output/nonlin/scales", init=_vector_from_init(nonlinear_scale, p_num))
+            k_out = k_out + var * nonlinear_kernel(f"{pi}/output/nonlin").stretch(scales)
+
+        noise_variance = vs.bnd(name=f"{pi}/noise", init=_vector_from_init(noise, pi + 1)[pi], lower=1e-8)
+        f = GP(k_in.select(m_inds) + k_out.select(p_inds), measure=Measure())
+        return f, noise_variance
+
+    return model
+
+
+def _construct_gpar(reg, vs, m, p):
+    gpar = GPAR(replace=reg.replace, impute=reg.impute, x_ind=reg.x_ind)
+    for pi in range(p):
+        gpar = gpar.add_layer(_model_generator(vs, m, pi, **reg.model_config))
+    return gpar
+
+
+def _init_weights(w, y):
+    if w is None:
+        return torch.ones(*y.shape, dtype=torch.float64)
+    return _uprank(_to_torch(w))
+
+
+class GPARRegressor:
+    """GPAR regressor.  See the reference docstring (regression.py:200-262) for the meaning of every keyword;
+    signature and defaults are identical."""
+
+    def __init__(self, replace=False, impute=True, scale=1.0, scale_tie=False, per=False, per_period=1.0,
+                 per_scale=1.0, per_decay=10.0, input_linear=False, input_linear_scale=100.0, linear=True,
+                 linear_scale=100.0, nonlinear=False, nonlinear_scale=1.0, rq=False, markov=None, noise=0.1,
+                 x_ind=None, normalise_y=True, transform_y=(lambda x: x, lambda x: x)):
+        self.replace = replace
+        self.impute = impute
+        self.sparse = x_ind is not None
+        self.x_ind = None if x_ind is None else _uprank(_to_torch(x_ind))
+        self.model_config = {
+            "scale": scale, "scale_tie": scale_tie, "per": per, "per_period": per_period, "per_scale": per_scale,
+            "per_decay": per_decay, "input_linear": input_linear, "input_linear_scale": input_linear_scale,
+            "linear": linear, "linear_scale": linear_scale, "nonlinear": nonlinear,
+            "nonlinear_scale": nonlinear_scale, "rq": rq, "markov": markov, "noise": noise,
+        }
+        self.vs = Vars(dtype=torch.float64)
+        self.is_conditioned = False
+        self.x = self.y = self.w = None
+        self.n = self.m = self.p = None
+        self.normalise_y = normalise_y
+        self._unnormalise_y, self._normalise_y = (lambda x: x), (lambda x: x)
+        self._transform_y, self._untransform_y = transform_y
+
+    def get_variables(self):
+        """Dictionary name -> value of every hyper-parameter instantiated so far."""
+        return {name: self.vs[name].detach().numpy() for name in self.vs.names}
+
+    def condition(self, x, y, w=None):
+        """Store (and transform / normalise) the training data without training (reference regression.py:339-389)."""
+        self.x = _uprank(_to_torch(x))
+        self.y = self._transform_y(_uprank(_to_torch(y)))
+        self.w = _init_weights(w, self.y)
+        self.n, self.m = self.x.shape
+        self.p = self.y.shape[1]
+        if self.normalise_y:
+            means, stds = [], []
+            for i in range(self.p):
+                y_i = self.y[~torch.isnan(self.y[:, i]), i]
+                means.append(torch.mean(y_i))
+                std = torch.std(y_i, unbiased=False)  # population std, as lab's B.std
+                stds.append(std if std > 0 else torch.ones_like(std))
+            means, stds = torch.stack(means)[None, :], torch.stack(stds)[None, :]
+
+            def normalise_y(y_):
+                return (y_ - means.to(y_.device)) / stds.to(y_.device)
+
+            def unnormalise_y(y_):
+                return y_ * stds.to(y_.device) + means.to(y_.device)
+
+            self._normalise_y, self._unnormalise_y = normalise_y, unnormalise_y
+            self.y = normalise_y(self.y)
+        self.is_conditioned = True
+
+    def fit(self, x, y, w=None, greedy=False, fix=True, **kw_args):
+        """Train layer by layer with L-BFGS-B on the negative log marginal likelihood; keyword arguments go to
+        `minimise_l_bfgs_b` (`iters`, `f_calls`, `trace`).  (reference regression.py:391-459)"""
+        self.condition(x, y, w)
+        if greedy:
+            raise NotImplementedError("Greedy search is not implemented yet.")
+        eng = get_engine()
+        x_dev, y_dev, w_dev = eng.tensor(self.x), eng.tensor(self.y), eng.tensor(self.w)
+        y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
+        for pi in range(self.p):
+            if fix:
+                gpar = _construct_gpar(self, self.vs, self.m, pi + 1)
+                fixed_x, fixed_x_ind = gpar.logpdf(
+                    x_dev, y_cached, None, only_last_layer=True, outputs=list(range(pi)), return_inputs=True
+                )
+
+            def objective(vs):
+                gpar = _construct_gpar(self, vs, self.m, pi + 1)
+                if fix:
+                    return -gpar.logpdf(fixed_x, y_cached, None, only_last_layer=True, outputs=[pi], x_ind=fixed_x_ind)
+                return -gpar.logpdf(x_dev, y_cached, None, only_last_layer=False)
+
+            names = [f"{pi}/*"] if fix else [f"{i}/*" for i in range(pi + 1)]
+            minimise_l_bfgs_b(objective, self.vs, names=names, **kw_args)
+
+    def logpdf(self, x, y, w=None, sample_missing=False, posterior=False):
+        """Log-density of observations under the prior (or, with `posterior`, the conditioned model).  Returns a
+        numpy scalar unless x or y was a torch tensor (reference regression.py:461-506)."""
+        any_torch = isinstance(x, torch.Tensor) or isinstance(y, torch.Tensor)
+        x = _uprank(_to_torch(x))
+        y = self._unnormalise_y(self._transform_y(_uprank(_to_torch(y))))  # sic: reference regression.py:483
+        w = _init_weights(w, y)
+        m, p = x.shape[1], y.shape[1]
+        if posterior and not self.is_conditioned:
+            raise RuntimeError("Must condition or fit model before computing the logpdf under the posterior.")
+        gpar = _construct_gpar(self, self.vs, m, p)
+        if posterior:
+            gpar = gpar | (self.x, self.y, self.w)
+        value = gpar.logpdf(x, y, w, only_last_layer=False, sample_missing=sample_missing)
+        if not any_torch:
+            value = value.detach().numpy()
+        return value
+
+    def sample(self, x, w=None, p=None, posterior=False, num_samples=1, latent=False):
+        """Draw samples from the prior or the posterior at inputs x; a single ndarray for num_samples=1, otherwise
+        a list (reference regression.py:508-564)."""
+        x = _uprank(_to_torch(x))
+        if posterior and not self.is_conditioned:
+            raise RuntimeError("Must condition or fit model before sampling from the posterior.")
+        elif not posterior and p is None:
+            raise ValueError("Must specify number of outputs to sample.")
+        if w is None:
+            w = torch.ones(x.shape[0], self.p if posterior else p, dtype=torch.float64)
+        else:
+            w = _uprank(_to_torch(w))
+        if posterior:
+            gpar = _construct_gpar(self, self.vs, self.m, self.p)
+            gpar = gpar | (self.x, self.y, self.w)
+        else:
+            gpar = _construct_gpar(self, self.vs, x.shape[1], p)
+
+        def undo_transforms(y_):
+            return self._untransform_y(self._unnormalise_y(y_))
+
+        samples = [undo_transforms(s).detach().cpu().numpy() for s in gpar.sample_many(x, w, num_samples, latent=latent)]
+        return samples[0] if num_samples == 1 else samples
+
+    def predict(self, x, w=None, num_samples=100, latent=False, credible_bounds=False):
+        """Monte-Carlo predictive mean (and central 95% marginal bounds) from posterior samples
+        (reference regression.py:566-597)."""
+        samples = self.sample(x, w, num_samples=num_samples, latent=latent, posterior=True)
+        mean = np.mean(samples, axis=0)
+        if credible_bounds:
+            return mean, np.percentile(samples, 2.5, axis=0), np.percentile(samples, 100 - 2.5, axis=0)
+        return mean

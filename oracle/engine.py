@@ -1,0 +1,166 @@
+"""Oracle (TEST INFRASTRUCTURE): numpy/scipy fp64 implementation of the engine seam (gpar_amd/engine.py).
+
+It lets the test-suite (i) run the host orchestration (gpar_amd.model / regression / gp) without a GPU, so the
+reference's behavioural tests can be ported to CPU, and (ii) compare every HIP primitive and every end-to-end
+quantity against an independent fp64 computation.  It is installed explicitly with
+`gpar_amd.engine.set_engine(OracleEngine())` by tests, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` only; the product never imports this module and never falls back to it.
+
+Algorithms restated: LAPACK dpotrf / dtrtrs semantics via scipy.linalg (the reference reaches the same routines
+through matrix -> lab -> torch.linalg.cholesky / solve_triangular), partial Cholesky =
+Schur complement, kernels as in oracle/kernels.py.
+"""
+import numpy as np
+import scipy.linalg
+import torch
+
+from . import kernels as ok
+from . import philox
+
+__all__ = ["OracleEngine"]
+
+
+class _Compiled:
+    def __init__(self, kernel, width):
+        self.kernel = kernel.resolve(width)
+        self.width = width
+        self.spec = ok.spec_to_dict(self.kernel)
+
+
+class OracleNotPositiveDefinite(ArithmeticError):
+    def __init__(self, info):
+        super().__init__(f"matrix is not positive definite: pivot {info} is not positive")
+        self.info = info
+
+
+def _np(t):
+    return t.detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)
+
+
+class OracleEngine:
+    name = "oracle"
+
+    def __init__(self, seed=0, epsilon=1e-12):
+        self.device = torch.device("cpu")
+        self.epsilon = float(epsilon)
+        self._seed = int(seed)
+        self._calls = 0
+
+    # ---- memory ----------------------------------------------------------------------------------
+    def tensor(self, x):
+        if isinstance(x, torch.Tensor):
+            return x.detach().to(device="cpu", dtype=torch.float64)
+        return torch.as_tensor(np.asarray(x, dtype=np.float64))
+
+    def new_matrix(self, rows, cols, zero=False):
+        # NaN-filled unless zeroed: anything the host code reads without having written shows up in tests
+        return torch.zeros(rows, cols, dtype=torch.float64) if zero else torch.full((rows, cols), float("nan"), dtype=torch.float64)
+
+    # ---- kernels ---------------------------------------------------------------------------------
+    def compile(self, kernel, width):
+        return _Compiled(kernel, width)
+
+    def features(self, ck, x):
+        return x  # the oracle evaluates kernels on the raw design matrix
+
+    def gram(self, ck, z1, z2=None, lower=False, diag_add=None, diag_const=0.0, out=None):
+        K = ok.gram(ck.spec, _np(z1), None if z2 is None else _np(z2),
+                    noise_diag=None if diag_add is None else _np(diag_add), jitter=diag_const)
+        if out is None:
+            return torch.from_numpy(K)
+        o = out.numpy()
+        if lower and z2 is None:
+            il = np.tril_indices(K.shape[0])
+            o[il] = K[il]
+        else:
+            o[...] = K
+        return out
+
+    def gram_diag(self, ck, z):
+        return torch.from_numpy(ok.gram_diag(ck.spec, _np(z)))
+
+    def kernel_grads(self, ck, x, W):
+        """1/2 sum_ab W_ab dK_ab/dtheta for every kernel parameter (W given by its lower triangle)."""
+        w = np.tril(_np(W))
+        w = w + np.tril(w, -1).T
+        return ok.kernel_grads(ck.spec, _np(x), w)
+
+    # ---- factorisations ----------------------------------------------------------------------------
+    def potrf_(self, A, nf=None):
+        a = A.numpy()
+        N = a.shape[0]
+        nf = N if nf is None else int(nf)
+        low = np.tril(a)
+        full = low + np.tril(low, -1).T
+        logdet = torch.zeros(1, dtype=torch.float64)
+        info = torch.zeros(1, dtype=torch.int32)
+        if nf == 0:
+            return logdet, info
+        try:
+            L11 = np.linalg.cholesky(full[:nf, :nf])
+        except np.linalg.LinAlgError:
+            # locate the first failing pivot as LAPACK would report it
+            k = 1
+            while k <= nf:
+                try:
+                    np.linalg.cholesky(full[:k, :k])
+                except np.linalg.LinAlgError:
+                    break
+                k += 1
+            info[0] = k
+            return logdet, info
+        logdet[0] = 2.0 * np.sum(np.log(np.diag(L11)))
+        il = np.tril_indices(nf)
+        a[:nf, :nf][il] = L11[il]
+        if nf < N:
+            L21 = scipy.linalg.solve_triangular(L11, full[:nf, nf:], lower=True).T
+            a[nf:, :nf] = L21
+            S = full[nf:, nf:] - L21 @ L21.T
+            il2 = np.tril_indices(N - nf)
+            a[nf:, nf:][il2] = S[il2]
+        return logdet, info
+
+    def trsm_rlt_(self, L, B):
+        if B.shape[0] and B.shape[1]:
+            b = B.numpy()
+            b[...] = scipy.linalg.solve_triangular(np.tril(L.numpy()), b.T, lower=True).T
+        return B
+
+    def trsm_rln_(self, L, B):
+        if B.shape[0] and B.shape[1]:
+            b = B.numpy()
+            b[...] = scipy.linalg.solve_triangular(np.tril(L.numpy()), b.T, lower=True, trans="T").T
+        return B
+
+    def gemm(self, A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False, a_lower=False):
+        a, b = _np(A), _np(B)
+        opa = a.T if ta else a
+        if a_lower:
+            opa = np.tril(opa)
+        opb = b.T if tb else b
+        prod = alpha * (opa @ opb)
+        if out is None:
+            return torch.from_numpy(np.ascontiguousarray(prod))
+        o = out.numpy()
+        if c_lower:
+            il = np.tril_indices(prod.shape[0], 0, prod.shape[1])
+            o[il] = prod[il] + (beta * o[il] if beta != 0.0 else 0.0)
+        else:
+            o[...] = prod + (beta * o if beta != 0.0 else 0.0)
+        return out
+
+    # ---- randomness ------------------------------------------------------------------------------
+    def seed(self, seed):
+        self._seed = int(seed)
+        self._calls = 0
+
+    def randn(self, rows, cols):
+        out = torch.from_numpy(philox.randn(self._seed, self._calls, rows, cols))
+        self._calls += 1
+        return out
+
+    @staticmethod
+    def check_info(info):
+        code = int(info.item())
+        if code != 0:
+            raise OracleNotPositiveDefinite(code)

@@ -1,7 +1,7 @@
 """Quick potrf / gemm timing on the GPU box (development aid)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpar_amd import hip, _lib
 
 dev = torch.device("cuda:0")
