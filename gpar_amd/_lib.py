@@ -17,6 +17,7 @@ K_EQ, K_RQ, K_LINEAR = 0, 1, 2
 GRAM_LOWER = 1
 GEMM_C_LOWER = 1
 GEMM_A_LOWER = 2
+GRAD_NACC = GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS
 
 ABI_VERSION = 1
 
@@ -70,6 +71,12 @@ SIGNATURES = {
         [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr, _c_dbl, _ptr],
     ),
     "gpar_gram_diag": (_c_int, [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "gpar_featurize_dfreq": (_c_int, [ctypes.POINTER(FSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
+    "gpar_grad_nacc": (_c_int, []),
+    "gpar_gram_grad": (
+        _c_int,
+        [ctypes.POINTER(KSpec), _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr],
+    ),
     "gpar_potrf": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "gpar_trsm_rlt": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),
     "gpar_trsm_rln": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),

@@ -128,6 +128,45 @@ int gpar_gram_diag(const gpar_kspec_t* ks, const double* z, int n, int ldz, int 
     return 0;
 }
 
+int gpar_featurize_dfreq(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* zd, int ldz, void* stream) {
+    if (!fs || fs->dz < 0 || fs->dz > GPAR_MAX_DIMS) return GPAR_ARG_ERROR(2);
+    if (n <= 0 || fs->dz == 0) return 0;
+    const long total = (long)n * fs->dz;
+    hipLaunchKernelGGL(featurize_dfreq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *fs, x,
+                       n, ldx, zd, ldz);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_grad_nacc(void) { return GRAD_NACC; }
+
+int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, int n, int ldz, int dz, const double* W,
+                   int ldw, double* workspace, int nblocks, double* out, void* stream) {
+    if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS)
+        return GPAR_ARG_ERROR(3);
+    if (dz < 0 || dz > GPAR_MAX_DIMS || nblocks <= 0) return GPAR_ARG_ERROR(4);
+    {   // the pass handles at most GRAD_MAXF factors per product term
+        int cnt[GPAR_MAX_TERMS] = {0};
+        for (int f = 0; f < ks->nfactors; ++f) {
+            const int t = ks->factor[f].term;
+            if (t < 0 || t >= ks->nterms || ++cnt[t] > GRAD_MAXF) return GPAR_ARG_ERROR(6);
+        }
+    }
+    const size_t lds = ((size_t)4 * (dz > 0 ? dz : 1) * GRAM_LD + 4 * GRAD_NACC) * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (lds > 160 * 1024) return GPAR_ARG_ERROR(7);
+    hipLaunchKernelGGL(gram_grad_kernel, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, *ks, z, zd, n, ldz, dz, W, ldw,
+                       workspace);
+    hipLaunchKernelGGL(gram_grad_reduce_kernel, dim3(gpar_ceil_div(GRAD_NACC, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)workspace, nblocks, out);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
 int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, void* stream) {
     if (N <= 0 || nf <= 0) return 0;
     return potrf_run(A, N, nf, lda, logdet, info, (hipStream_t)stream);

@@ -90,6 +90,34 @@ class HipEngine:
     def gemm(self, A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False, a_lower=False):
         return hip.gemm(self._mat(A), self._mat(B), ta=ta, tb=tb, alpha=alpha, beta=beta, out=out, c_lower=c_lower, a_lower=a_lower)
 
+    def kernel_grads(self, ck, x, W):
+        """1/2 sum_ab W_ab dK_ab/dtheta for every parameter of the compiled kernel (W: lower triangle of a symmetric
+        matrix).  One fused device pass produces per-term / per-factor / per-feature moment sums (csrc/gram.h); the
+        chain rule from features to length scales, periods and alphas is applied here on the host."""
+        import numpy as np
+
+        x = self._mat(x)
+        z = hip.featurize(ck, x)
+        periodic = any(f.periods is not None for t in ck.kernel.terms for f in t.factors)
+        zd = hip.featurize_dfreq(ck, x) if periodic else None
+        raw = hip.gram_grad(ck, z, zd, W).cpu().numpy()
+        nT, nF, nD = _lib.GPAR_MAX_TERMS, _lib.GPAR_MAX_FACTORS, _lib.GPAR_MAX_DIMS
+        C, Al = raw[:nT], raw[nT : nT + nF]
+        A, P = raw[nT + nF : nT + nF + nD], raw[nT + nF + nD :]
+        out = {"coef": [0.5 * C[t] for t in range(len(ck.kernel.terms))], "factors": [[] for _ in ck.kernel.terms]}
+        for flat, (ti, fi, off, nd) in enumerate(ck.layout):
+            f = ck.kernel.terms[ti].factors[fi]
+            scales = f.scales_value()
+            g = {"scales": -A[off : off + nd] / scales, "periods": None, "alpha": None}
+            if f.type == "rq":
+                g["alpha"] = 0.5 * Al[flat]
+            if f.periods is not None:
+                periods = f.periods_value()
+                ncol = len(f.cols)
+                g["periods"] = -(P[off : off + ncol] + P[off + ncol : off + 2 * ncol]) * 2.0 * np.pi / periods**2
+            out["factors"][ti].append(g)
+        return out
+
     # ---- randomness ------------------------------------------------------------------------------
     def seed(self, seed):
         self._seed = int(seed)

@@ -228,3 +228,45 @@ def randn(seed, offset, rows, cols, device):
         "gpar_randn",
     )
     return out
+
+
+def featurize_dfreq(ck, x):
+    """zd = d features / d freq (zero for non-periodic features)."""
+    _check_mat(x, "x")
+    lib = _lib.load()
+    n = x.shape[0]
+    zd = alloc_matrix(n, max(ck.dz, 1), x.device, zero=True)
+    if ck.dz:
+        _lib.check(
+            lib.gpar_featurize_dfreq(ctypes.byref(ck.fspec), x.data_ptr(), n, _ld(x), zd.data_ptr(), _ld(zd), stream_ptr(x.device)),
+            "gpar_featurize_dfreq",
+        )
+    return zd
+
+
+def gram_grad(ck, z, zd, W, nblocks=None):
+    """Raw gradient moment sums (length GRAD_NACC, device tensor) of 1/2 sum W dK/dtheta; see csrc/gram.h."""
+    lib = _lib.load()
+    _check_mat(z, "z")
+    _check_mat(W, "W")
+    n = z.shape[0]
+    nt = (n + 63) // 64
+    ntiles = nt * (nt + 1) // 2
+    if nblocks is None:
+        nblocks = max(1, min(ntiles, 1024))
+    work = torch.empty(nblocks * _lib.GRAD_NACC, dtype=torch.float64, device=z.device)
+    out = torch.empty(_lib.GRAD_NACC, dtype=torch.float64, device=z.device)
+    zdp = None
+    if zd is not None:
+        _check_mat(zd, "zd")
+        if _ld(zd) != _ld(z):
+            raise ValueError("z and zd must share a leading dimension")
+        zdp = zd.data_ptr()
+    _lib.check(
+        lib.gpar_gram_grad(
+            ctypes.byref(ck.kspec), z.data_ptr(), zdp, n, _ld(z), ck.dz, W.data_ptr(), _ld(W), work.data_ptr(), nblocks,
+            out.data_ptr(), stream_ptr(z.device),
+        ),
+        "gpar_gram_grad",
+    )
+    return out

@@ -107,6 +107,21 @@ int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const 
 /* out[a] = k(z[a], z[a])   [kernel diagonal; VFE trace term, posterior marginal variances] */
 int gpar_gram_diag(const gpar_kspec_t* ks, const double* z, int n, int ldz, int dz, double* out, void* stream);
 
+/* zd[q] = d z[q] / d freq[q] (zero for non-periodic features): the feature derivative the period gradients need. */
+int gpar_featurize_dfreq(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* zd, int ldz, void* stream);
+
+/* Gradient moment sums of  1/2 sum_ab W_ab dK_ab/dtheta  for every kernel parameter, one fused pass over the lower
+ * triangle of the symmetric n x n matrix W (= alpha alpha^T - K^-1 for the log marginal likelihood).
+ * out[GPAR_GRAD_NACC]: [0, MAX_TERMS) C_t; then [MAX_FACTORS) Al_f; then [MAX_DIMS) A_q; then [MAX_DIMS) P_q
+ * (definitions: gpar_amd/csrc/gram.h).  workspace: nblocks * GPAR_GRAD_NACC doubles; nblocks = grid size (<= tiles).
+ * zd may be NULL when the kernel has no periodic features.  At most 4 factors per product term.
+ * [replaces torch autograd through exp / pw_dists2 / cholesky / solve_triangular inside
+ *  varz.minimise_l_bfgs_b, gpar/regression.py:459] */
+#define GPAR_GRAD_NACC (GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS)
+int gpar_grad_nacc(void);
+int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, int n, int ldz, int dz, const double* W,
+                   int ldw, double* workspace, int nblocks, double* out, void* stream);
+
 /* Partial right-looking blocked Cholesky of the leading `nf` columns of the symmetric N x N matrix A
  * (lower triangle).  On exit A[:, :nf] holds L (N x nf, lower trapezoid) and A[nf:, nf:] holds the Schur
  * complement A22 - L21 L21^T.  nf == N is the ordinary potrf.  logdet (device, optional) += 2*sum log L_jj;

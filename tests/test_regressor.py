@@ -1,0 +1,287 @@
+"""Behavioural spec of gpar_amd.regression (what /root/reference/tests/test_regression.py pins for
+gpar/regression.py): helper known answers, hyper-parameter naming, prior / posterior logpdf against a by-hand GP
+computation, differentiability, sampling / prediction, normalisation, training smoke tests, feature flags.
+Runs on the CPU oracle engine and, unchanged, through the HIP library (`-m gpu`)."""
+import numpy as np
+import pytest
+import torch
+
+from gpar_amd.regression import (
+    GPARRegressor,
+    _construct_gpar,
+    _determine_indices,
+    _vector_from_init,
+    log_transform,
+    squishing_transform,
+)
+
+from .conftest import close, columns_all_different, to_np
+
+
+@pytest.fixture(params=[(10,), (10, 1), (10, 2)])
+def x(request):
+    return np.random.default_rng(len(request.param) * 7 + request.param[-1]).standard_normal(request.param)
+
+
+@pytest.fixture(params=[True, False])
+def w(request):
+    return np.random.default_rng(2).random((10, 2)) + 1 if request.param else None
+
+
+# ---- helpers: exact known answers (reference tests/test_regression.py:31-89) -------------------------------
+
+@pytest.mark.parametrize("pair,positive", [(log_transform, True), (squishing_transform, False)])
+@pytest.mark.parametrize("as_torch", [False, True])
+def test_transforms_invert(pair, positive, as_torch):
+    v = np.random.default_rng(0).standard_normal(5)
+    v = np.abs(v) + 0.1 if positive else v
+    f, f_inv = pair
+    arg = torch.tensor(v) if as_torch else v
+    close(f(f_inv(arg)), v)
+    close(f_inv(f(arg)), v)
+
+
+def test_vector_from_init_known_answers():
+    close(_vector_from_init(2, 2), np.array([2, 2]))
+    close(_vector_from_init(np.array([1, 2, 3]), 2), np.array([1, 2]))
+    with pytest.raises(ValueError):
+        _vector_from_init(np.zeros((2, 2)), 1)
+    with pytest.raises(ValueError):
+        _vector_from_init(np.array([1, 2]), 3)
+
+
+MARKOV_TABLE = {
+    None: {(1, 0): ([0], [], 0), (1, 1): ([0], [1], 1), (1, 2): ([0], [1, 2], 2),
+           (2, 0): ([0, 1], [], 0), (2, 1): ([0, 1], [2], 1), (2, 2): ([0, 1], [2, 3], 2)},
+    0: {(1, 0): ([0], [], 0), (1, 1): ([0], [], 0), (1, 2): ([0], [], 0),
+        (2, 0): ([0, 1], [], 0), (2, 1): ([0, 1], [], 0), (2, 2): ([0, 1], [], 0)},
+    1: {(1, 0): ([0], [], 0), (1, 1): ([0], [1], 1), (1, 2): ([0], [2], 1),
+        (2, 0): ([0, 1], [], 0), (2, 1): ([0, 1], [2], 1), (2, 2): ([0, 1], [3], 1)},
+    2: {(1, 0): ([0], [], 0), (1, 1): ([0], [1], 1), (1, 2): ([0], [1, 2], 2),
+        (2, 0): ([0, 1], [], 0), (2, 1): ([0, 1], [2], 1), (2, 2): ([0, 1], [2, 3], 2)},
+}
+
+
+def test_determine_indices_table():
+    for markov, rows in MARKOV_TABLE.items():
+        for (m, pi), expected in rows.items():
+            assert _determine_indices(m, pi, markov) == expected, (markov, m, pi)
+
+
+def test_get_variables_roundtrip():
+    reg = GPARRegressor()
+    reg.vs.get(init=1.0, name="variable")
+    assert list(reg.get_variables().items()) == [("variable", 1.0)]
+
+
+def test_constructor_defaults_match_reference_signature():
+    reg = GPARRegressor()
+    assert (reg.replace, reg.impute, reg.sparse, reg.x_ind, reg.normalise_y, reg.is_conditioned) == (False, True, False, None, True, False)
+    assert reg.model_config == {
+        "scale": 1.0, "scale_tie": False, "per": False, "per_period": 1.0, "per_scale": 1.0, "per_decay": 10.0,
+        "input_linear": False, "input_linear_scale": 100.0, "linear": True, "linear_scale": 100.0,
+        "nonlinear": False, "nonlinear_scale": 1.0, "rq": False, "markov": None, "noise": 0.1,
+    }
+    assert all(getattr(reg, a) is None for a in ("x", "y", "w", "n", "m", "p"))
+
+
+def test_inducing_points_are_upranked():
+    reg = GPARRegressor(x_ind=np.linspace(0, 10, 20))
+    assert reg.sparse and reg.x_ind.dim() == 2 and tuple(reg.x_ind.shape) == (20, 1)
+
+
+# ---- logpdf (reference tests/test_regression.py:92-158) ---------------------------------------------------
+
+def test_logpdf_prior_and_posterior_against_manual_gps(engine, x, w):
+    reg = GPARRegressor(replace=False, impute=False, nonlinear=True, nonlinear_scale=0.1, linear=True,
+                        linear_scale=10.0, noise=1e-2, normalise_y=False)
+    y = reg.sample(x, w, p=2, latent=True)
+    x2d = x if x.ndim == 2 else x[:, None]
+    gpar = _construct_gpar(reg, reg.vs, x2d.shape[1], 2)
+    f1, n1 = gpar.layers[0]()
+    f2, n2 = gpar.layers[1]()
+    n1, n2 = float(n1), float(n2)
+    if w is not None:
+        n1, n2 = n1 / w[:, 0], n2 / w[:, 1]
+    x1 = x2d
+    x2 = np.concatenate([x2d, y[:, 0:1]], axis=1)
+    close(reg.logpdf(x, y, w), f1(x1, n1).logpdf(y[:, 0]) + f2(x2, n2).logpdf(y[:, 1]), atol=1e-6)
+
+    p1 = f1 | (f1(x1, n1), y[:, 0])
+    p2 = f2 | (f2(x2, n2), y[:, 1])
+    with pytest.raises(RuntimeError):
+        reg.logpdf(x, y, w, posterior=True)
+    reg.condition(x, y, w)
+    close(reg.logpdf(x, y, w, posterior=True), p1(x1, n1).logpdf(y[:, 0]) + p2(x2, n2).logpdf(y[:, 1]), atol=1e-6)
+
+    y = y.copy()
+    y[::2, 0] = np.nan
+    columns_all_different(reg.logpdf(x, y, w, sample_missing=True), reg.logpdf(x, y, w, sample_missing=True))
+
+
+def test_logpdf_return_type_follows_inputs(engine):
+    reg = GPARRegressor(normalise_y=False)
+    xs = np.linspace(0, 1, 6)
+    ys = np.stack([np.sin(xs), np.cos(xs)], axis=1)
+    assert isinstance(reg.logpdf(xs, ys), np.ndarray) and reg.logpdf(xs, ys).shape == ()
+    assert isinstance(reg.logpdf(torch.tensor(xs), ys), torch.Tensor)
+
+
+def test_logpdf_is_differentiable_in_every_variable(engine, x, w):
+    reg = GPARRegressor(replace=False, impute=False, linear=True, linear_scale=1.0, nonlinear=False, noise=1e-8,
+                        normalise_y=False)
+    y = reg.sample(x, w, p=2, latent=True)
+    reg.vs.requires_grad(True)
+    assert all(v.grad is None for v in reg.vs.get_vars())
+    reg.logpdf(torch.tensor(x), torch.tensor(y)).backward()
+    assert all(v.grad is not None for v in reg.vs.get_vars())
+
+
+def test_analytic_gradient_matches_finite_differences(engine):
+    """Every hyper-parameter of a full-featured two-layer model (per + input_linear + rq + linear + nonlinear),
+    chained through the bound transforms, against central differences of the logpdf itself."""
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((14, 2))
+    w = rng.random((14, 2)) + 1
+    reg = GPARRegressor(replace=False, impute=False, per=True, input_linear=True, rq=True, linear=True,
+                        nonlinear=True, noise=0.05, normalise_y=False)
+    y = reg.sample(x, w, p=2)
+    reg.vs.requires_grad(True)
+    reg.logpdf(torch.tensor(x), torch.tensor(y), w).backward()
+    names = reg.vs.names
+    grad = np.concatenate([v.grad.numpy().reshape(-1) for v in reg.vs.get_vars()])
+    x0 = reg.vs.get_vector(names)
+    fd = np.zeros_like(x0)
+    for i in range(len(x0)):
+        e = np.zeros_like(x0)
+        e[i] = 1e-6
+        reg.vs.set_vector(x0 + e, names)
+        up = float(reg.logpdf(x, y, w))
+        reg.vs.set_vector(x0 - e, names)
+        fd[i] = (up - float(reg.logpdf(x, y, w))) / 2e-6
+    reg.vs.set_vector(x0, names)
+    assert len(grad) == 38
+    np.testing.assert_allclose(grad, fd, rtol=1e-5, atol=1e-6 * np.max(np.abs(grad)))
+
+
+# ---- sample / predict (reference tests/test_regression.py:161-208) ------------------------------------------
+
+def test_sample_and_predict(engine, x, w):
+    reg = GPARRegressor(replace=False, impute=False, linear=True, linear_scale=1.0, nonlinear=False, noise=1e-8,
+                        normalise_y=False, transform_y=squishing_transform)
+    with pytest.raises(ValueError):
+        reg.sample(x, w)
+    with pytest.raises(RuntimeError):
+        reg.sample(x, w, posterior=True)
+    assert isinstance(reg.sample(x, w, p=2), np.ndarray)
+    many = reg.sample(x, w, p=2, num_samples=2)
+    assert isinstance(many, list) and len(many) == 2 and many[0].shape == (10, 2)
+    columns_all_different(reg.sample(x, w, p=2), reg.sample(x, w, p=2))
+    columns_all_different(reg.sample(x, w, p=2, latent=True), reg.sample(x, w, p=2, latent=True))
+
+    y = reg.sample(x, w, p=2)
+    reg.condition(x, y, w)
+    close(y, np.mean(reg.sample(x, w, posterior=True, num_samples=100), axis=0), atol=5e-2)
+    close(y, np.mean(reg.sample(x, w, latent=True, posterior=True, num_samples=100), axis=0), atol=5e-2)
+    close(y, reg.predict(x, w, num_samples=100), atol=5e-2)
+    close(y, reg.predict(x, w, latent=True, num_samples=100), atol=5e-2)
+    _, lo, hi = reg.predict(x, w, num_samples=100, credible_bounds=True)
+    close(hi, lo, atol=5e-2)
+
+
+# ---- condition / fit (reference tests/test_regression.py:211-273) -------------------------------------------
+
+def test_condition_normalises_and_fit_runs(engine, x, w):
+    reg = GPARRegressor(replace=False, impute=False, normalise_y=True, transform_y=squishing_transform)
+    y = reg.sample(x, w, p=2)
+    reg.condition(x, y, w)
+    assert (reg.n, reg.p) == (10, 2) and reg.m == (1 if x.ndim == 1 else x.shape[1]) and reg.is_conditioned
+    close(reg.y.mean(dim=0), np.zeros(2), atol=1e-12)
+    close(reg.y.std(dim=0, unbiased=False), np.ones(2))
+
+    flat = y.copy()
+    flat[:, 0] = 1  # zero-variance column must not produce NaNs
+    reg.condition(x, flat, w)
+    assert not torch.isnan(reg.y).any()
+
+    z = np.stack([np.linspace(-1, 1, 10), 2 * np.linspace(-1, 1, 10)], axis=1)
+    close(reg._untransform_y(reg._transform_y(z)), z)
+    close(reg._unnormalise_y(reg._normalise_y(torch.tensor(z))), z)
+
+    snapshot = reg.vs.copy(detach=True)
+    before = float(reg.logpdf(x, y, w))
+    reg.fit(x, y, w, fix=False, iters=15)
+    reg.vs = snapshot
+    reg.fit(x, y, w, fix=True, iters=15)
+    assert np.isfinite(float(reg.logpdf(x, y, w))) and np.isfinite(before)
+    with pytest.raises(NotImplementedError):
+        reg.fit(x, y, w, greedy=True)
+
+
+def test_fit_increases_the_training_objective(engine):
+    rng = np.random.default_rng(4)
+    x = np.linspace(0, 1, 30)
+    y = np.stack([np.sin(6 * x), np.sin(6 * x) ** 2 + x], axis=1) + 0.05 * rng.standard_normal((30, 2))
+    reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, nonlinear_scale=0.5, noise=0.5, normalise_y=True)
+    reg.condition(x, y)
+    y_norm = to_np(reg.y)
+
+    def objective():
+        return float(_construct_gpar(reg, reg.vs, 1, 2).logpdf(to_np(reg.x), y_norm, np.ones((30, 2))))
+
+    before = objective()
+    reg.fit(x, y, iters=30)
+    assert objective() > before + 1.0
+
+
+def test_all_kernel_features_train(engine):
+    reg = GPARRegressor(replace=True, scale=1.0, per=True, per_period=1.0, per_decay=10.0, input_linear=True,
+                        input_linear_scale=0.1, linear=True, linear_scale=1.0, nonlinear=True, nonlinear_scale=1.0,
+                        rq=True, noise=0.1)
+    x = np.stack([np.linspace(0, 10, 20), np.linspace(10, 20, 20)], axis=1)
+    y = reg.sample(x, p=2)
+    reg.fit(x, y, iters=10)
+    names = set(reg.get_variables())
+    for expected in ["0/input/alpha", "0/input/per/var", "0/input/per/scales", "0/input/per/pers", "0/input/per/decay",
+                     "0/input/lin/scales", "0/input/lin/const", "1/output/lin/scales", "1/output/nonlin/var",
+                     "1/output/nonlin/scales", "1/output/nonlin/alpha", "1/noise"]:
+        assert expected in names
+    assert reg.get_variables()["0/input/per/scales"].shape == (4,)
+
+
+def test_scale_tying_shares_one_variable(engine, x, w):
+    reg = GPARRegressor(scale_tie=True)
+    reg.sample(x, w, p=2)
+    names = reg.get_variables()
+    assert "0/input/scales" in names and "1/input/scales" not in names
+
+
+def test_markov_zero_adds_constant_output_term(engine):
+    """with markov=0 the output kernels are built over zero columns: EQ -> all-ones (a live
+    variance), Linear -> zero.  The layer-1 logpdf equals that of k_in + var * 1."""
+    from gpar_amd.gp import GP
+    from gpar_amd.kernels import EQ
+
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((9, 1))
+    y = rng.standard_normal((9, 2))
+    reg = GPARRegressor(markov=0, linear=True, nonlinear=True, noise=0.1, normalise_y=False, impute=False)
+    total = float(reg.logpdf(x, y))
+    f_a = GP(1.0 * EQ().stretch(np.ones(1)))
+    f_b = GP(1.0 * EQ().stretch(np.ones(1)) + 1.0)
+    manual = float(f_a(x, 0.1).logpdf(y[:, 0]) + f_b(x, 0.1).logpdf(y[:, 1]))
+    assert "1/output/nonlin/var" in reg.get_variables()
+    close(total, manual, rtol=1e-10)
+
+
+def test_sparse_regressor_runs_end_to_end(engine):
+    rng = np.random.default_rng(11)
+    x = np.sort(rng.random(40))
+    y = np.stack([np.sin(6 * x), np.cos(6 * x) * np.sin(6 * x)], axis=1) + 0.05 * rng.standard_normal((40, 2))
+    reg = GPARRegressor(x_ind=np.linspace(0, 1, 12), scale=0.3, noise=0.05, nonlinear=True, normalise_y=False)
+    dense = GPARRegressor(scale=0.3, noise=0.05, nonlinear=True, normalise_y=False)
+    bound, exact = float(reg.logpdf(x, y)), float(dense.logpdf(x, y))
+    assert np.isfinite(bound) and bound <= exact + 1e-8  # VFE is a lower bound on every layer
+    reg.condition(x, y)
+    mean = reg.predict(x, num_samples=30)
+    assert mean.shape == (40, 2) and np.sqrt(np.mean((mean - y) ** 2)) < 0.3
