@@ -206,12 +206,13 @@ class GPAR:
     @staticmethod
     def _noise_over(noise, w):
         """noise / w on w's device (noise is a Python float or a CPU 0-d tensor)."""
+        # NB: `python_float / tensor` is evaluated by torch as `tensor.reciprocal() * float`, which is not the
+        # correctly rounded quotient; the reference divides two tensors, so do the same.
         if _is_torch(noise):
-            noise = noise.detach().to(dtype=torch.float64)
-            if noise.dim() == 0 or noise.numel() == 1:
-                return float(noise) / w
-            return noise.to(w.device) / w
-        return float(noise) / w
+            noise = noise.detach().to(device=w.device, dtype=torch.float64)
+        else:
+            noise = torch.tensor(float(noise), dtype=torch.float64, device=w.device)
+        return torch.true_divide(noise, w)
 
     def _obs(self, x, x_ind, y, w, f, noise):
         eng = get_engine()

@@ -1,0 +1,147 @@
+"""Layer-parallel GPAR over the GPUs of one node: one process per GPU, `torch.distributed` (backend "nccl" = RCCL
+over xGMI on the MI355X box, "gloo" in the CPU tests).
+
+The p autoregressive layers are the units of work: layer i is owned by rank i mod G.  What has to travel between
+ranks is decided by the model, exactly as in /root/reference/gpar/model.py:291-322:
+
+  * `replace=False`, nothing to impute, no inducing points: layer i's design matrix is `[x, observed y_<i]`, which
+    every rank already holds -> layers are independent, the data path has NO collective; only the p scalar
+    log-likelihoods are summed (one 8-byte all-reduce).
+  * otherwise (posterior means are fed forward): the owner of layer i computes the new input column (and the new
+    inducing-input column) and broadcasts it — n x 8 bytes per layer, latency-bound — before layer i+1 can start.
+
+`fit(fix=True)` trains each layer on its owner (the optimiser only touches names "{i}/*", reference
+regression.py:453-454) and then broadcasts the trained latent variables so every rank holds the same `Vars`.
+`predict` conditions every layer on every rank and splits the Monte-Carlo samples across ranks.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .engine import get_engine
+from .model import last, per_output
+
+__all__ = ["world", "sharded_logpdf", "sharded_fit", "sharded_sample"]
+
+
+def world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _needs_estimate(gpar, yi):
+    missing = bool(torch.isnan(yi[:, 0]).any())
+    return gpar.sparse or gpar.replace or (gpar.impute and missing)
+
+
+def sharded_logpdf(gpar, x, y, w, group=None):
+    """`GPAR.logpdf(x, y, w)` with the layers divided over the ranks of `group`; every rank returns the total."""
+    rank, size = world(group)
+    eng = get_engine()
+    x, y, w = gpar._prep(x, y, w)
+    x_ind = gpar._prep_ind(gpar.x_ind)
+    local = torch.zeros((), dtype=torch.float64)
+    for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(per_output(y, w, keep=gpar.impute), gpar.layers))):
+        x = x[mask]
+        mine = (i % size) == rank
+        f = obs = None
+        if mine:
+            f, noise = model()
+            obs = gpar._obs(x, x_ind, yi, wi, f, noise)
+            local = local + f.measure.logpdf(obs)
+        if is_last:
+            break
+        if not _needs_estimate(gpar, yi):
+            x = torch.cat([x, yi], dim=1)  # observed data: already on every rank
+            continue
+        # dependent chain: the owner computes the forwarded column(s), everyone else receives them
+        n_i = x.shape[0]
+        col = torch.empty(n_i, 1, dtype=torch.float64, device=x.device)
+        ind_col = None if x_ind is None else torch.empty(x_ind.shape[0], 1, dtype=torch.float64, device=x.device)
+        if mine:
+            x_new, x_ind_new = gpar._update_inputs(x, x_ind, yi, f, obs)
+            col.copy_(x_new[:, -1:])
+            if ind_col is not None:
+                ind_col.copy_(x_ind_new[:, -1:])
+        if size > 1:
+            dist.broadcast(col, src=_global_rank(i % size, group), group=group)
+            if ind_col is not None:
+                dist.broadcast(ind_col, src=_global_rank(i % size, group), group=group)
+        x = torch.cat([x, col], dim=1)
+        if ind_col is not None:
+            x_ind = torch.cat([x_ind, ind_col], dim=1)
+    if size > 1:
+        buf = local.detach().to(device=eng.device, dtype=torch.float64).reshape(1).clone()
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        local = buf[0].cpu()
+    return local
+
+
+def _global_rank(group_rank, group):
+    if group is None:
+        return group_rank
+    return dist.get_global_rank(group, group_rank)
+
+
+def sharded_fit(reg, x, y, w=None, group=None, **kw_args):
+    """`GPARRegressor.fit(x, y, w, fix=True)` with layer pi trained on rank pi mod G, then synchronised."""
+    from .optimise import minimise_l_bfgs_b
+    from .regression import _construct_gpar
+
+    rank, size = world(group)
+    eng = get_engine()
+    reg.condition(x, y, w)
+    x_dev, y_dev, w_dev = eng.tensor(reg.x), eng.tensor(reg.y), eng.tensor(reg.w)
+    y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
+    independent = not (reg.replace or reg.sparse or (reg.impute and bool(torch.isnan(y_dev).any())))
+    if not independent:
+        # inputs of layer pi depend on the trained layers < pi: the chain is sequential; train replicated
+        reg.fit(x, y, w, fix=True, **kw_args)
+        return
+    # instantiate every variable on every rank (lazy creation, reference regression.py:92-180)
+    with torch.no_grad():
+        _construct_gpar(reg, reg.vs, reg.m, reg.p).logpdf(x_dev[:2], y_dev[:2], w_dev[:2])
+    for pi in range(reg.p):
+        if pi % size != rank:
+            continue
+        gpar = _construct_gpar(reg, reg.vs, reg.m, pi + 1)
+        fixed_x, fixed_x_ind = gpar.logpdf(x_dev, y_cached, None, only_last_layer=True, outputs=list(range(pi)), return_inputs=True)
+
+        def objective(vs, pi=pi, fixed_x=fixed_x, fixed_x_ind=fixed_x_ind):
+            g = _construct_gpar(reg, vs, reg.m, pi + 1)
+            return -g.logpdf(fixed_x, y_cached, None, only_last_layer=True, outputs=[pi], x_ind=fixed_x_ind)
+
+        minimise_l_bfgs_b(objective, reg.vs, names=[f"{pi}/*"], **kw_args)
+    if size > 1:
+        for pi in range(reg.p):
+            names = reg.vs.match([f"{pi}/*"])
+            if not names:
+                continue
+            vec = torch.as_tensor(reg.vs.get_vector(names), dtype=torch.float64).to(eng.device)
+            dist.broadcast(vec, src=_global_rank(pi % size, group), group=group)
+            reg.vs.set_vector(vec.cpu().numpy(), names)
+
+
+def sharded_sample(reg, x, w=None, num_samples=100, latent=False, group=None):
+    """Posterior samples split over ranks (each rank conditions all layers, draws its share with its own Philox
+    stream, and the shares are all-gathered).  Returns the full list of `num_samples` arrays on every rank."""
+    rank, size = world(group)
+    eng = get_engine()
+    counts = [num_samples // size + (1 if r < num_samples % size else 0) for r in range(size)]
+    eng.seed(getattr(eng, "_seed", 0) * 1000003 + rank + 1)
+    mine = reg.sample(x, w, posterior=True, num_samples=max(counts[rank], 1), latent=latent)
+    mine = [mine] if isinstance(mine, np.ndarray) else list(mine)
+    mine = mine[: counts[rank]]
+    if size == 1:
+        return mine
+    rows = int(np.shape(x)[0])
+    local = torch.zeros(max(counts), rows, reg.p, dtype=torch.float64, device=eng.device)
+    for k, s in enumerate(mine):
+        local[k] = torch.as_tensor(s, dtype=torch.float64)
+    gathered = [torch.empty_like(local) for _ in range(size)]
+    dist.all_gather(gathered, local, group=group)
+    out = []
+    for r in range(size):
+        out.extend(gathered[r][k].cpu().numpy() for k in range(counts[r]))
+    return out

@@ -1,0 +1,84 @@
+"""Oracle (TEST INFRASTRUCTURE): a self-contained numpy GPAR log marginal likelihood and posterior-mean chain.
+
+Restates the orchestration of /root/reference/gpar/model.py:178-243 (`GPAR.logpdf`), :279-322 (`_obs`,
+`_update_inputs`), :325-362 (`per_output`) and the per-layer kernel of /root/reference/gpar/regression.py:92-180
+directly from a `{name: value}` dictionary of hyper-parameters (the dictionary `GPARRegressor.get_variables()`
+returns), without importing anything from the product.  Dense (no inducing points) path only.
+"""
+import numpy as np
+
+from . import gp_ref
+
+__all__ = ["layer_spec", "gpar_logpdf"]
+
+
+def _indices(m, pi, markov):
+    p_last = pi - 1
+    p_start = 0 if markov is None else max(p_last - (markov - 1), 0)
+    return list(range(m)), list(range(m + p_start, m + p_last + 1))
+
+
+def layer_spec(hypers, m, pi, config):
+    """Kernel dict (oracle/kernels.py format) and noise variance of layer `pi` (regression.py:92-180)."""
+    g = lambda name: np.asarray(hypers[name], dtype=np.float64)
+    m_inds, p_inds = _indices(m, pi, config.get("markov"))
+    rq = config.get("rq", False)
+    terms = []
+
+    def nonlin(prefix, cols, scales):
+        f = {"type": "rq" if rq else "eq", "cols": cols, "scales": list(np.atleast_1d(scales)), "periods": None, "alpha": 0.0}
+        if rq:
+            f["alpha"] = float(g(f"{prefix}/alpha"))
+        return f
+
+    tie = 0 if config.get("scale_tie", False) else pi
+    terms.append({"coef": float(g(f"{pi}/input/var")), "factors": [nonlin(f"{pi}/input", m_inds, g(f"{tie}/input/scales"))]})
+    if config.get("per", False):
+        terms.append(
+            {
+                "coef": float(g(f"{pi}/input/per/var")),
+                "factors": [
+                    {"type": "eq", "cols": m_inds, "scales": list(g(f"{pi}/input/per/scales")),
+                     "periods": list(np.atleast_1d(g(f"{pi}/input/per/pers"))), "alpha": 0.0},
+                    {"type": "eq", "cols": m_inds, "scales": list(np.atleast_1d(g(f"{pi}/input/per/decay"))), "periods": None, "alpha": 0.0},
+                ],
+            }
+        )
+    if config.get("input_linear", False):
+        terms.append({"coef": 1.0, "factors": [{"type": "linear", "cols": m_inds, "scales": list(np.atleast_1d(g(f"{pi}/input/lin/scales"))), "periods": None, "alpha": 0.0}]})
+        terms.append({"coef": float(g(f"{pi}/input/lin/const")), "factors": []})
+    if config.get("linear", True) and pi > 0:
+        terms.append({"coef": 1.0, "factors": [{"type": "linear", "cols": p_inds, "scales": list(np.atleast_1d(g(f"{pi}/output/lin/scales"))), "periods": None, "alpha": 0.0}]})
+    if config.get("nonlinear", False) and pi > 0:
+        terms.append({"coef": float(g(f"{pi}/output/nonlin/var")), "factors": [nonlin(f"{pi}/output/nonlin", p_inds, g(f"{pi}/output/nonlin/scales"))]})
+    return {"terms": terms}, float(g(f"{pi}/noise"))
+
+
+def gpar_logpdf(x, y, w, hypers, config, impute=False, replace=False, eps=1e-12):
+    """Sum over layers of log N(y_i; 0, K_i([x, y_<i]) + noise_i / w_i) with the reference's missing-data rules."""
+    x = np.asarray(x, dtype=np.float64)
+    x = x[:, None] if x.ndim == 1 else x
+    y = np.asarray(y, dtype=np.float64)
+    w = np.ones_like(y) if w is None else np.asarray(w, dtype=np.float64)
+    m, p = x.shape[1], y.shape[1]
+    available = ~np.isnan(y)
+    total = 0.0
+    for i in range(p):
+        mask = available[:, i].copy()
+        if impute and i < p - 1:
+            mask |= available[:, i + 1 :].any(axis=1)
+        x, yi, wi = x[mask], y[mask, i], w[mask, i]
+        y, w, available = y[mask], w[mask], available[mask]
+        spec, noise = layer_spec(hypers, m, i, config)
+        have = ~np.isnan(yi)
+        total += gp_ref.logpdf(spec, x[have], yi[have], noise / wi[have], eps=eps)
+        if i < p - 1:
+            col = yi.copy()
+            if (impute and (~have).any()) or (replace and have.any()):
+                mean, _ = gp_ref.posterior(spec, x[have], yi[have], noise / wi[have], x, eps=eps)
+                if impute:
+                    col[~have] = mean[~have]
+                if replace:
+                    col[have] = mean[have]
+            x = np.concatenate([x, col[:, None]], axis=1)
+    return total

@@ -1,0 +1,119 @@
+"""Generates tests/golden/gpar_cases.json: small, fully specified GPAR problems with their expected values.
+
+Expected values come from the CPU oracle's closed-form route (oracle/gp_ref.py, oracle/gpar_ref.py: slogdet +
+solve, no Cholesky), evaluated in fp64 in the build container.  The reference implementation itself cannot be
+imported (its stheno / lab / matrix / varz dependencies are not installable offline, see oracle/__init__.py),
+so these vectors pin the *restated* algorithm; they travel to the GPU box as plain data.
+
+    python tests/golden/make_golden.py          # rewrites gpar_cases.json deterministically
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import gp_ref, gpar_ref  # noqa: E402
+
+
+def hypers_for(m, p, config, rng):
+    """Hyper-parameter dictionary with the reference's names, random values."""
+    h = {}
+    for pi in range(p):
+        _, p_inds = gpar_ref._indices(m, pi, config.get("markov"))
+        pn = len(p_inds)
+        h[f"{pi}/input/var"] = rng.uniform(0.5, 2.0)
+        if not (config.get("scale_tie") and pi > 0):
+            h[f"{pi}/input/scales"] = rng.uniform(0.5, 2.0, m).tolist()
+        if config.get("rq"):
+            h[f"{pi}/input/alpha"] = rng.uniform(0.3, 3.0)
+        if config.get("per"):
+            h[f"{pi}/input/per/var"] = rng.uniform(0.5, 2.0)
+            h[f"{pi}/input/per/scales"] = rng.uniform(0.5, 2.0, 2 * m).tolist()
+            h[f"{pi}/input/per/pers"] = rng.uniform(0.7, 1.5, m).tolist()
+            h[f"{pi}/input/per/decay"] = rng.uniform(3.0, 10.0, m).tolist()
+        if config.get("input_linear"):
+            h[f"{pi}/input/lin/scales"] = rng.uniform(1.0, 5.0, m).tolist()
+            h[f"{pi}/input/lin/const"] = rng.uniform(0.1, 1.0)
+        if config.get("linear", True) and pi > 0:
+            h[f"{pi}/output/lin/scales"] = rng.uniform(1.0, 5.0, pn).tolist()
+        if config.get("nonlinear") and pi > 0:
+            h[f"{pi}/output/nonlin/var"] = rng.uniform(0.5, 2.0)
+            h[f"{pi}/output/nonlin/scales"] = rng.uniform(0.5, 2.0, pn).tolist()
+            if config.get("rq"):
+                h[f"{pi}/output/nonlin/alpha"] = rng.uniform(0.3, 3.0)
+        h[f"{pi}/noise"] = rng.uniform(0.02, 0.2)
+    return h
+
+
+CASES = [
+    ("eq-linear-2out", dict(n=12, m=1, p=2, config=dict(linear=True), impute=False, replace=False, missing=0.0, weights=False)),
+    ("paper-synthetic-shape", dict(n=25, m=1, p=3, config=dict(linear=True, nonlinear=True), impute=True, replace=False, missing=0.0, weights=False)),
+    ("weights-2in", dict(n=16, m=2, p=3, config=dict(linear=True, nonlinear=True), impute=False, replace=False, missing=0.0, weights=True)),
+    ("markov2-4out", dict(n=14, m=2, p=4, config=dict(linear=True, nonlinear=True, markov=2), impute=False, replace=False, missing=0.0, weights=True)),
+    ("markov0-igp", dict(n=10, m=1, p=3, config=dict(linear=True, nonlinear=True, markov=0), impute=False, replace=False, missing=0.0, weights=False)),
+    ("rq-per-inputlinear", dict(n=18, m=2, p=2, config=dict(linear=True, nonlinear=True, rq=True, per=True, input_linear=True), impute=False, replace=False, missing=0.0, weights=True)),
+    ("scale-tie", dict(n=11, m=2, p=3, config=dict(linear=True, scale_tie=True), impute=False, replace=False, missing=0.0, weights=False)),
+    ("missing-impute", dict(n=20, m=1, p=3, config=dict(linear=True, nonlinear=True), impute=True, replace=False, missing=0.25, weights=True)),
+    ("missing-noimpute", dict(n=20, m=1, p=3, config=dict(linear=True, nonlinear=True), impute=False, replace=False, missing=0.25, weights=False)),
+    ("replace", dict(n=15, m=1, p=3, config=dict(linear=True, nonlinear=True), impute=True, replace=True, missing=0.15, weights=False)),
+]
+
+
+def main():
+    rng = np.random.default_rng(20260928)
+    out = {"gpar_logpdf": [], "single_gp": [], "vfe": []}
+    for name, c in CASES:
+        n, m, p = c["n"], c["m"], c["p"]
+        x = rng.uniform(-1.5, 1.5, (n, m))
+        y = rng.standard_normal((n, p))
+        if c["missing"]:
+            y[rng.random((n, p)) < c["missing"]] = np.nan
+            y[0] = rng.standard_normal(p)  # at least one complete row
+        w = (rng.random((n, p)) + 0.5) if c["weights"] else None
+        hypers = hypers_for(m, p, c["config"], rng)
+        value = gpar_ref.gpar_logpdf(x, y, w, hypers, c["config"], impute=c["impute"], replace=c["replace"])
+        out["gpar_logpdf"].append(
+            {
+                "name": name, "config": c["config"], "impute": c["impute"], "replace": c["replace"],
+                "x": x.tolist(), "y": [[None if np.isnan(v) else v for v in row] for row in y.tolist()],
+                "w": None if w is None else w.tolist(), "hypers": hypers, "logpdf": value,
+            }
+        )
+    # single-layer posterior moments for each kernel family
+    for name, config in [("eq", dict(linear=False)), ("rq", dict(linear=False, rq=True)),
+                         ("per", dict(linear=False, per=True)), ("inlin", dict(linear=False, input_linear=True))]:
+        n, m = 14, 2
+        x, xs = rng.uniform(-1, 1, (n, m)), rng.uniform(-1, 1, (6, m))
+        y = rng.standard_normal(n)
+        noise = rng.uniform(0.05, 0.2, n)
+        hypers = hypers_for(m, 1, config, rng)
+        spec, _ = gpar_ref.layer_spec(hypers, m, 0, config)
+        mean, cov = gp_ref.posterior(spec, x, y, noise, xs)
+        out["single_gp"].append({"name": name, "config": config, "hypers": hypers, "x": x.tolist(), "y": y.tolist(),
+                                 "noise": noise.tolist(), "xs": xs.tolist(), "logpdf": gp_ref.logpdf(spec, x, y, noise),
+                                 "mean": mean.tolist(), "cov": cov.tolist()})
+    # inducing points
+    for name, nz in [("vfe-few", 5), ("vfe-many", 12)]:
+        n, m = 30, 1
+        config = dict(linear=False)
+        x, xs, z = rng.uniform(-2, 2, (n, m)), rng.uniform(-2, 2, (7, m)), np.linspace(-2, 2, nz)[:, None]
+        y = np.sin(2 * x[:, 0]) + 0.1 * rng.standard_normal(n)
+        noise = rng.uniform(0.05, 0.1, n)
+        hypers = hypers_for(m, 1, config, rng)
+        spec, _ = gpar_ref.layer_spec(hypers, m, 0, config)
+        mean, cov = gp_ref.vfe_posterior(spec, x, y, noise, z, xs)
+        out["vfe"].append({"name": name, "config": config, "hypers": hypers, "x": x.tolist(), "y": y.tolist(), "noise": noise.tolist(),
+                           "z": z.tolist(), "xs": xs.tolist(), "bound": gp_ref.vfe_bound(spec, x, y, noise, z),
+                           "mean": mean.tolist(), "cov": cov.tolist()})
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpar_cases.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

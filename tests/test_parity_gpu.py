@@ -1,0 +1,250 @@
+"""GPU parity proper: everything below runs through the C ABI (libgpar_hip.so) on cuda:0 and is compared with
+
+  (a) the committed golden vectors (tests/golden/gpar_cases.json; closed-form CPU values),
+  (b) the CPU oracle engine on the same seeded inputs at sizes the oracle finishes in seconds,
+  (c) size-independent properties at the benchmark sizes (BASELINE.json configs): L L^T v = K v, the
+      log-likelihood chain rule, VFE tightness at Z = X, Schur-complement identities.
+
+Tolerances (fp64, stated per SURVEY.md §7(vi)): log marginal likelihood rtol 1e-10 against the oracle for
+well-conditioned problems (noise >= 1e-2 of the signal); posterior moments rtol 1e-8 / atol 1e-10; samples with a
+shared Philox stream atol 1e-8; trained hyper-parameters after identical L-BFGS-B iteration counts rtol 1e-5.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from .conftest import make_engine, to_np
+from .test_oracle import GOLDEN, _kernel_from_spec, _nan_array, regressor_from_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def hip():
+    from gpar_amd.engine import set_engine
+
+    eng = make_engine("hip")
+    previous = set_engine(eng)
+    yield eng
+    set_engine(previous)
+
+
+def _golden():
+    with open(GOLDEN) as f:
+        return json.load(f)
+
+
+def _on(kind, fn, seed=77):
+    """Run fn() with the given engine installed."""
+    from gpar_amd.engine import set_engine
+
+    eng = make_engine(kind, seed=seed)
+    previous = set_engine(eng)
+    try:
+        return fn()
+    finally:
+        set_engine(previous)
+
+
+@pytest.mark.parametrize("case", _golden()["gpar_logpdf"], ids=lambda c: c["name"])
+def test_golden_gpar_logpdf(case, hip):
+    x, y = np.array(case["x"]), _nan_array(case["y"])
+    w = None if case["w"] is None else np.array(case["w"])
+    got = float(regressor_from_case(case).logpdf(x, y, w))
+    assert abs(got - case["logpdf"]) <= 1e-10 * abs(case["logpdf"]), (got, case["logpdf"])
+
+
+@pytest.mark.parametrize("case", _golden()["single_gp"], ids=lambda c: c["name"])
+def test_golden_posterior_moments(case, hip):
+    from gpar_amd.gp import GP, Obs
+    from oracle import gpar_ref
+
+    spec, _ = gpar_ref.layer_spec(case["hypers"], 2, 0, case["config"])
+    f = GP(_kernel_from_spec(spec))
+    x, y, noise, xs = (np.array(case[k]) for k in ("x", "y", "noise", "xs"))
+    assert abs(float(f(x, noise).logpdf(y)) - case["logpdf"]) <= 1e-10 * abs(case["logpdf"])
+    post = f | Obs(f(x, noise), y)
+    np.testing.assert_allclose(to_np(post.mean(xs))[:, 0], case["mean"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(to_np(post(xs).var()), case["cov"], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("case", _golden()["vfe"], ids=lambda c: c["name"])
+def test_golden_inducing_points(case, hip):
+    from gpar_amd.gp import GP, PseudoObs
+    from oracle import gpar_ref
+
+    spec, _ = gpar_ref.layer_spec(case["hypers"], 1, 0, case["config"])
+    f = GP(_kernel_from_spec(spec))
+    x, y, noise, z, xs = (np.array(case[k]) for k in ("x", "y", "noise", "z", "xs"))
+    obs = PseudoObs(f(z), f(x, noise), y)
+    assert abs(float(obs.logpdf()) - case["bound"]) <= 1e-8 * abs(case["bound"])
+    post = f | obs
+    np.testing.assert_allclose(to_np(post.mean(xs))[:, 0], case["mean"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(to_np(post(xs).var()), case["cov"], rtol=1e-6, atol=1e-8)
+
+
+def _problem(n, m, p, seed, missing=0.0):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 1, (n, m))
+    cols = []
+    for i in range(p):
+        base = np.sin(2 * np.pi * (x @ rng.uniform(0.5, 1.5, m)) + i)
+        if cols:
+            base = base + 0.5 * cols[-1] ** 2
+        cols.append(base + 0.1 * rng.standard_normal(n))
+    y = np.stack(cols, axis=1)
+    y = (y - y.mean(0)) / y.std(0)
+    if missing:
+        y[rng.random(y.shape) < missing] = np.nan
+    return x, y
+
+
+CONFIGS = {
+    "C1-paper-synthetic": (dict(scale=0.1, linear=True, linear_scale=10.0, nonlinear=True, nonlinear_scale=0.1, noise=0.1, impute=True, replace=False, normalise_y=False), 25, 1, 3, 0.0),
+    "C2-shape": (dict(scale=0.5, linear=True, nonlinear=False, noise=0.1), 384, 2, 4, 0.0),
+    "C3-shape-markov2": (dict(scale=0.5, linear=True, nonlinear=True, markov=2, noise=0.1), 300, 4, 8, 0.0),
+    "C5-shape-per-rq": (dict(scale=0.5, per=True, rq=True, linear=True, nonlinear=True, noise=0.1), 200, 3, 5, 0.0),
+    "missing-impute": (dict(scale=0.5, linear=True, nonlinear=True, noise=0.1, impute=True), 257, 2, 3, 0.2),
+    "replace": (dict(scale=0.5, linear=True, nonlinear=True, noise=0.1, impute=True, replace=True), 190, 2, 3, 0.1),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_logpdf_condition_predict_match_oracle(name):
+    from gpar_amd.regression import GPARRegressor
+
+    kw, n, m, p, missing = CONFIGS[name]
+    x, y = _problem(n, m, p, seed=len(name), missing=missing)
+    xs = np.random.default_rng(1).uniform(0, 1, (40, m))
+
+    def run():
+        reg = GPARRegressor(**kw)
+        prior = float(reg.logpdf(x, y))
+        reg.condition(x, y)
+        post = float(reg.logpdf(x, y, posterior=True)) if not missing else 0.0
+        samples = reg.sample(xs, posterior=True, num_samples=3, latent=True)
+        return prior, post, np.stack(samples)
+
+    ref = _on("oracle", run)
+    got = _on("hip", run)
+    assert abs(got[0] - ref[0]) <= 1e-10 * abs(ref[0]), (got[0], ref[0])
+    assert abs(got[1] - ref[1]) <= 1e-8 * max(1.0, abs(ref[1])), (got[1], ref[1])
+    np.testing.assert_allclose(got[2], ref[2], rtol=1e-6, atol=1e-7)
+
+
+def test_sparse_path_matches_oracle():
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(600, 2, 3, seed=4)
+    z = np.random.default_rng(2).uniform(0, 1, (48, 2))
+    xs = np.random.default_rng(3).uniform(0, 1, (30, 2))
+
+    def run():
+        reg = GPARRegressor(x_ind=z, scale=0.5, linear=True, nonlinear=True, noise=0.1)
+        bound = float(reg.logpdf(x, y))
+        reg.condition(x, y)
+        return bound, np.stack(reg.sample(xs, posterior=True, num_samples=2, latent=True))
+
+    ref, got = _on("oracle", run), _on("hip", run)
+    assert abs(got[0] - ref[0]) <= 1e-9 * abs(ref[0])
+    np.testing.assert_allclose(got[1], ref[1], rtol=1e-5, atol=1e-6)
+
+
+def test_fit_matches_oracle_training():
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(120, 1, 3, seed=12)
+
+    def run():
+        reg = GPARRegressor(scale=0.3, linear=True, nonlinear=True, nonlinear_scale=0.5, noise=0.3)
+        reg.fit(x, y, iters=12)
+        return reg.get_variables(), float(reg.logpdf(x, y))
+
+    (vr, lr), (vg, lg) = _on("oracle", run), _on("hip", run)
+    assert sorted(vr) == sorted(vg)
+    for k in vr:
+        np.testing.assert_allclose(vg[k], vr[k], rtol=1e-5, atol=1e-8, err_msg=k)
+    assert abs(lg - lr) <= 1e-7 * abs(lr)
+
+
+def test_gradient_matches_oracle(hip):
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(150, 2, 3, seed=21)
+
+    def grads():
+        reg = GPARRegressor(scale=0.5, per=True, rq=True, input_linear=True, linear=True, nonlinear=True, noise=0.1, normalise_y=False, impute=False)
+        with torch.no_grad():
+            reg.logpdf(x, y)
+        reg.vs.requires_grad(True)
+        reg.logpdf(torch.tensor(x), torch.tensor(y)).backward()
+        return np.concatenate([v.grad.numpy().reshape(-1) for v in reg.vs.get_vars()])
+
+    ref, got = _on("oracle", grads), _on("hip", grads)
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(ref)))
+
+
+# ---- properties at benchmark sizes (no oracle: too large for the CPU) -----------------------------------------
+
+@pytest.mark.parametrize("n,m,p_cols", [(4096, 2, [2, 3]), (16384, 4, [9, 10])])
+def test_full_size_cholesky_properties(hip, n, m, p_cols):
+    """K v = L (L^T v) and the augmented row equals L^-1 y, on the layer kernel at BASELINE sizes."""
+    from gpar_amd import hip as H
+    from gpar_amd.kernels import EQ, Linear, compile_kernel
+
+    dev = hip.device
+    width = max(p_cols) + 1
+    g = torch.Generator().manual_seed(n)
+    x = torch.rand(n, width, generator=g, dtype=torch.float64).to(dev)
+    k = (1.0 * EQ().stretch(np.full(m, 0.5))).select(list(range(m))) + (
+        Linear().stretch(np.full(len(p_cols), 100.0)) + 1.0 * EQ().stretch(np.ones(len(p_cols)))
+    ).select(p_cols)
+    ck = compile_kernel(k, width)
+    z = H.featurize(ck, x)
+    A = H.alloc_matrix(n + 1, n + 1, dev)
+    H.gram(ck, z, None, out=A[:n, :n], lower=True, diag_const=0.1 + 1e-12)
+    yv = torch.randn(n, generator=g, dtype=torch.float64).to(dev)
+    A[n, :n] = yv
+    A[n, n] = 0.0
+    v = torch.randn(n, 3, generator=g, dtype=torch.float64).to(dev)
+    Kl = torch.tril(A[:n, :n])
+    Kv = Kl @ v + torch.tril(Kl, -1).T @ v
+    del Kl
+    logdet, info = H.potrf_(A, nf=n)
+    assert int(info.item()) == 0
+    L = torch.tril(A[:n, :n])
+    LLv = L @ (L.T @ v)
+    rel = (LLv - Kv).norm() / Kv.norm()
+    assert rel < 1e-12, rel
+    # augmented row: z = L^-1 y  <=>  L z = y ; corner = -|z|^2
+    zrow = A[n, :n]
+    assert ((L @ zrow) - yv).norm() / yv.norm() < 1e-10
+    assert abs(float(-A[n, n]) - float(zrow @ zrow)) <= 1e-10 * float(zrow @ zrow)
+    assert abs(float(logdet) - 2 * float(torch.log(torch.diagonal(L)).sum())) <= 1e-10 * abs(float(logdet))
+
+
+def test_c2_logpdf_chain_rule_and_vfe_tightness(hip):
+    """n = 4096, m = 2, p = 4 (BASELINE C2): the joint log-likelihood equals the sum of the per-layer conditionals
+    computed one at a time, and with inducing points at a subset == all inputs of a small problem the bound is tight."""
+    from gpar_amd.gp import GP, PseudoObs
+    from gpar_amd.kernels import EQ
+    from gpar_amd.regression import GPARRegressor, _construct_gpar
+
+    x, y = _problem(4096, 2, 4, seed=2)
+    reg = GPARRegressor(scale=0.5, linear=True, nonlinear=False, noise=0.1, normalise_y=False)
+    total = float(reg.logpdf(x, y))
+    gpar = _construct_gpar(reg, reg.vs, 2, 4)
+    parts = 0.0
+    for i in range(4):
+        f, noise = gpar.layers[i]()
+        xi = np.concatenate([x, y[:, :i]], axis=1)
+        parts += float(f(xi, float(noise)).logpdf(y[:, i]))
+    assert abs(total - parts) <= 1e-12 * abs(total)
+    xs, ys = x[:700], y[:700, 0]
+    f = GP(1.0 * EQ().stretch(np.full(2, 0.5)))
+    exact = float(f(xs, 0.1).logpdf(ys))
+    tight = float(PseudoObs(f(xs), f(xs, 0.1), ys).logpdf())
+    assert abs(exact - tight) <= 1e-6 * abs(exact)
