@@ -16,49 +16,89 @@ namespace gpar {
 constexpr int POTRF_NBI = 64;   // inner block (diag / strip width)
 
 // ---------------------------------------------------------------------------------------------------
-// 64 x 64 (or smaller, cb <= 64) diagonal block, one wave.  A points at the block's (0,0).
-// Lane i owns row i in registers; step j: the pivot is broadcast with a wave shuffle (v_readlane), the
-// column is scaled by the reciprocal pivot (as LAPACK's dpotf2 does: DSCAL by 1/ajj), published through LDS
-// and applied as a rank-1 update.  Only the lower triangle is read or written.
+// Panel kernels.  Both are written as SHORT LOOPS over 8-wide sub-blocks with the matrix resident in LDS and
+// only an 8-element register window per lane: a fully unrolled 64-step formulation is ~30 KB of straight-line
+// code and ran at instruction-fetch speed (37 us per launch, profiles/r01_potrf_v1_kernels.txt); the looped form
+// re-executes ~1.5 KB bodies from the instruction cache.
+constexpr int PAN_LD = 66;   // LDS row pitch (doubles): even -> 16-byte aligned rows for ds_read_b128
+
+typedef double pan_d2 __attribute__((ext_vector_type(2)));
+
+// 64 x 64 (or smaller, cb <= 64) diagonal block, one wave; lane i owns row i.  Blocked left-looking Cholesky:
+// for each 8-column block, (1) subtract the contribution of all previous columns (own row entries: lane-private
+// LDS reads; the other row: wave-uniform broadcast reads), (2) factor the 8 columns with pivots and column
+// entries broadcast by v_readlane, scaling by the reciprocal pivot as LAPACK's dpotf2 does.
 __global__ __launch_bounds__(64) void potrf_diag64_kernel(double* __restrict__ A, int lda, int cb, int col0,
                                                           double* __restrict__ logdet, int* __restrict__ info) {
-    __shared__ double T[64 * 65];
-    __shared__ double colbuf[2][64];
+    __shared__ __attribute__((aligned(16))) double T[64 * PAN_LD];
     const int i = threadIdx.x;
     {
         double v[64];
 #pragma unroll
-        for (int r = 0; r < 64; ++r) v[r] = (r < cb && i < cb && i <= r) ? A[(size_t)r * lda + i] : ((r == i) ? 1.0 : 0.0);
+        // unconditional loads from clamped (always valid) addresses, selected afterwards: a guarded load would put
+        // every one of the 64 loads behind its own branch + vmcnt(0) wait (64 serial memory round trips)
+        for (int r = 0; r < 64; ++r) {
+            const int rc = r < cb ? r : cb - 1;
+            v[r] = A[(size_t)rc * lda + (i < rc ? i : rc)];
+        }
 #pragma unroll
-        for (int r = 0; r < 64; ++r) T[r * 65 + i] = v[r];
+        for (int r = 0; r < 64; ++r) T[r * PAN_LD + i] = (r < cb && i <= r) ? v[r] : ((r == i) ? 1.0 : 0.0);
     }
     __syncthreads();
-    double a[64];
-#pragma unroll
-    for (int j = 0; j < 64; ++j) a[j] = T[i * 65 + j];
-
     double mydiag = 1.0;
     int bad = 0;
+    for (int jb = 0; jb < 8; ++jb) {
+        double acc[8];
+        {
+            const pan_d2* src = reinterpret_cast<const pan_d2*>(&T[i * PAN_LD + 8 * jb]);
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const double d = gpar_readlane_f64(a[j], j);
-        if (!(d > 0.0) && bad == 0 && j < cb) bad = col0 + j + 1;
-        const double s = sqrt(d);
-        const double rinv = 1.0 / s;
-        const double lij = (i == j) ? s : a[j] * rinv;
-        if (i == j) mydiag = s;
-        a[j] = lij;
-        colbuf[j & 1][i] = lij;
+            for (int q = 0; q < 4; ++q) { const pan_d2 t = src[q]; acc[2 * q] = t[0]; acc[2 * q + 1] = t[1]; }
+        }
+        for (int kb = 0; kb < jb; ++kb) {
+            double mine[8];
+            const pan_d2* ms = reinterpret_cast<const pan_d2*>(&T[i * PAN_LD + 8 * kb]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const pan_d2 t = ms[q]; mine[2 * q] = t[0]; mine[2 * q + 1] = t[1]; }
+            // all 32 broadcast reads are issued before the first FMA, and the FMAs run k-outer so the 8
+            // accumulators form independent chains (a j-outer order serialises read -> wait -> 8 dependent FMAs)
+            pan_d2 c[8][4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const pan_d2* cs = reinterpret_cast<const pan_d2*>(&T[(8 * jb + j) * PAN_LD + 8 * kb]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c[j][q] = cs[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fma(-mine[2 * q], c[j][q][0], acc[j]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fma(-mine[2 * q + 1], c[j][q][1], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = 8 * jb + j;
+            const double d = gpar_readlane_f64(acc[j], col);
+            if (!(d > 0.0) && bad == 0 && col < cb) bad = col0 + col + 1;
+            const double sd = sqrt(d);
+            const double rinv = 1.0 / sd;
+            const double lij = (i == col) ? sd : acc[j] * rinv;
+            if (i == col) mydiag = sd;
+            acc[j] = lij;
+#pragma unroll
+            for (int j2 = j + 1; j2 < 8; ++j2) acc[j2] = fma(-lij, gpar_readlane_f64(lij, 8 * jb + j2), acc[j2]);
+        }
+        {
+            pan_d2* dst = reinterpret_cast<pan_d2*>(&T[i * PAN_LD + 8 * jb]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
+        }
         __syncthreads();
-#pragma unroll
-        for (int k = j + 1; k < 64; ++k) a[k] = fma(-lij, colbuf[j & 1][k], a[k]);
     }
 #pragma unroll
-    for (int j = 0; j < 64; ++j) T[i * 65 + j] = a[j];
-    __syncthreads();
-#pragma unroll
     for (int r = 0; r < 64; ++r)
-        if (r < cb && i <= r) A[(size_t)r * lda + i] = T[r * 65 + i];
+        if (r < cb && i <= r) A[(size_t)r * lda + i] = T[r * PAN_LD + i];
     double ld = (i < cb) ? 2.0 * log(mydiag) : 0.0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ld += __shfl_xor(ld, off, 64);
@@ -69,128 +109,104 @@ __global__ __launch_bounds__(64) void potrf_diag64_kernel(double* __restrict__ A
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Strip solve against a full 64 x 64 lower-triangular block Ld, 64 rows of B per wave, one row per lane
-// held in registers.  Only rows of the lower triangle of Ld are read.
-//   FWD:  X Ld^T = B   left-looking:  x_j = (b_j - sum_{k<j} x_k L[j][k]) / L_jj   (4 partial sums)
-//   !FWD: X Ld   = B   right-looking, j descending: x_j = b_j / L_jj, then b_q -= x_j L[j][q] for q < j
-// Ld is staged once into LDS (one coalesced round trip); every coefficient is then a wave-uniform
-// (broadcast) LDS read, two per ds_read_b128.  Reciprocal pivots are computed one per lane and broadcast with
-// v_readlane, so there is no division on the dependency chain.  B goes through a padded LDS tile so global
-// traffic stays coalesced; all global loads of a phase are issued before the first is consumed.
-template <bool FWD>
-__global__ __launch_bounds__(64) void trsm_strip64_kernel(const double* __restrict__ Ld, int ldl,
-                                                          double* __restrict__ B, int ldb, int nrows) {
-    __shared__ __attribute__((aligned(16))) double Ls[64 * 64];
-    __shared__ double Bt[64 * 65];
-    const int lane = threadIdx.x;
-    const int row0 = blockIdx.x * 64;
-    {
-        double v[64];
-#pragma unroll
-        for (int r = 0; r < 64; ++r) v[r] = (lane <= r) ? Ld[(size_t)r * ldl + lane] : 0.0;
-#pragma unroll
-        for (int r = 0; r < 64; ++r) Ls[r * 64 + lane] = v[r];
-#pragma unroll
-        for (int r = 0; r < 64; ++r) v[r] = (row0 + r < nrows) ? B[(size_t)(row0 + r) * ldb + lane] : 0.0;
-#pragma unroll
-        for (int r = 0; r < 64; ++r) Bt[r * 65 + lane] = v[r];
-    }
-    __syncthreads();
-    const double my_rinv = 1.0 / Ls[lane * 64 + lane];
-    double a[64];
-#pragma unroll
-    for (int j = 0; j < 64; ++j) a[j] = Bt[lane * 65 + j];
-    if (FWD) {
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            double s0 = a[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-            for (int k = 0; k < j; ++k) {
-                const double c = Ls[j * 64 + k];
-                if ((k & 3) == 0) s0 = fma(-a[k], c, s0);
-                else if ((k & 3) == 1) s1 = fma(-a[k], c, s1);
-                else if ((k & 3) == 2) s2 = fma(-a[k], c, s2);
-                else s3 = fma(-a[k], c, s3);
-            }
-            a[j] = ((s0 + s1) + (s2 + s3)) * gpar_readlane_f64(my_rinv, j);
-        }
-    } else {
-#pragma unroll
-        for (int j = 63; j >= 0; --j) {
-            const double x = a[j] * gpar_readlane_f64(my_rinv, j);
-            a[j] = x;
-#pragma unroll
-            for (int q = 0; q < j; ++q) a[q] = fma(-x, Ls[j * 64 + q], a[q]);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 64; ++j) Bt[lane * 65 + j] = a[j];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 64; ++r)
-        if (row0 + r < nrows) B[(size_t)(row0 + r) * ldb + lane] = Bt[r * 65 + lane];
-}
-
-// Generic (cb < 64) strip solve: coefficients staged in LDS with identity padding.  Only the ragged last
-// block of a matrix takes this path.
+// Strip solve against a (cb <= 64) lower-triangular block Ld, 64 rows of B per wave, one row per lane.
+//   FWD:  X Ld^T = B :  x_j = (b_j - sum_{k<j} x_k L[j][k]) / L_jj
+//   !FWD: X Ld   = B :  x_j = (b_j - sum_{i>j} x_i L[i][j]) / L_jj   (j descending)
+// The backward case is run as a forward solve on the index-reversed system (a -> 63 - a), i.e. its coefficient
+// image in LDS is the reversed transpose of Ld, so one loop nest serves both.  Only the lower triangle of Ld is
+// read.  Blocked left-looking substitution, 8 columns at a time: previously solved entries of the lane's row come
+// back from LDS (lane-private), coefficients are wave-uniform broadcast reads (ds_read_b128), reciprocal pivots
+// are precomputed (no division on the dependency chain).  B is staged through LDS so global traffic is coalesced,
+// and all global loads of a phase are issued before the first is consumed.
 template <bool FWD>
 __global__ __launch_bounds__(64) void trsm_strip_kernel(const double* __restrict__ Ld, int ldl, int cb,
                                                         double* __restrict__ B, int ldb, int nrows) {
-    __shared__ double Ls[64 * 65];
-    __shared__ double Bt[64 * 65];
+    __shared__ __attribute__((aligned(16))) double Cs[64 * PAN_LD];   // Cs[j][k]: coefficient of x_k in equation j
+    __shared__ __attribute__((aligned(16))) double Xs[64 * PAN_LD];   // Xs[lane][a]: row `lane` of B / X (reversed if !FWD)
+    __shared__ double rinvs[64];
     const int lane = threadIdx.x;
     const int row0 = blockIdx.x * 64;
-    // coefficient matrix: Ls[j][q] = FWD ? L[q][j] : L[j][q], identity outside cb
     {
-        double v[64];
+        // both 64 x 64 tiles are requested before either is consumed (one memory round trip instead of two);
+        // loads are unconditional from clamped, always valid addresses (see potrf_diag64_kernel)
+        double v[64], u[64];
 #pragma unroll
         for (int r = 0; r < 64; ++r) {
-            v[r] = (r == lane) ? 1.0 : 0.0;
-            if (r < cb && lane < cb && lane <= r) v[r] = Ld[(size_t)r * ldl + lane];   // L[r][lane], coalesced
+            const int rc = r < cb ? r : cb - 1;
+            v[r] = Ld[(size_t)rc * ldl + (lane < rc ? lane : rc)];
         }
 #pragma unroll
         for (int r = 0; r < 64; ++r) {
-            if (FWD) Ls[lane * 65 + r] = v[r]; else Ls[r * 65 + lane] = v[r];
+            const int rr = (row0 + r < nrows) ? row0 + r : nrows - 1;
+            u[r] = B[(size_t)rr * ldb + (lane < cb ? lane : cb - 1)];
         }
 #pragma unroll
-        for (int r = 0; r < 64; ++r) v[r] = (row0 + r < nrows && lane < cb) ? B[(size_t)(row0 + r) * ldb + lane] : 0.0;
+        for (int r = 0; r < 64; ++r) v[r] = (r < cb && lane <= r) ? v[r] : ((r == lane) ? 1.0 : 0.0);
+        if (FWD) {
 #pragma unroll
-        for (int r = 0; r < 64; ++r) Bt[r * 65 + lane] = v[r];
+            for (int r = 0; r < 64; ++r) Cs[r * PAN_LD + lane] = v[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 64; ++r) Cs[(63 - lane) * PAN_LD + (63 - r)] = v[r];   // Cs[a][b] = L[63-b][63-a]
+        }
+#pragma unroll
+        for (int r = 0; r < 64; ++r) Xs[r * PAN_LD + (FWD ? lane : 63 - lane)] = (row0 + r < nrows && lane < cb) ? u[r] : 0.0;
     }
     __syncthreads();
-    double a[64];
+    rinvs[lane] = 1.0 / Cs[lane * PAN_LD + lane];
+    __syncthreads();
+
+    for (int jb = 0; jb < 8; ++jb) {
+        double acc[8];
+        {
+            const pan_d2* src = reinterpret_cast<const pan_d2*>(&Xs[lane * PAN_LD + 8 * jb]);
 #pragma unroll
-    for (int j = 0; j < 64; ++j) a[j] = Bt[lane * 65 + j];
-    if (FWD) {
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            const double x = a[j] / Ls[j * 65 + j];
-            a[j] = x;
-#pragma unroll
-            for (int q = j + 1; q < 64; ++q) a[q] = fma(-x, Ls[j * 65 + q], a[q]);
+            for (int q = 0; q < 4; ++q) { const pan_d2 t = src[q]; acc[2 * q] = t[0]; acc[2 * q + 1] = t[1]; }
         }
-    } else {
+        for (int kb = 0; kb < jb; ++kb) {
+            double xk[8];
+            const pan_d2* xs = reinterpret_cast<const pan_d2*>(&Xs[lane * PAN_LD + 8 * kb]);
 #pragma unroll
-        for (int j = 63; j >= 0; --j) {
-            const double x = a[j] / Ls[j * 65 + j];
-            a[j] = x;
+            for (int q = 0; q < 4; ++q) { const pan_d2 t = xs[q]; xk[2 * q] = t[0]; xk[2 * q + 1] = t[1]; }
+            pan_d2 c[8][4];   // issue all 32 broadcast reads, then k-outer FMAs (see potrf_diag64_kernel)
 #pragma unroll
-            for (int q = 0; q < j; ++q) a[q] = fma(-x, Ls[j * 65 + q], a[q]);
+            for (int j = 0; j < 8; ++j) {
+                const pan_d2* cs = reinterpret_cast<const pan_d2*>(&Cs[(8 * jb + j) * PAN_LD + 8 * kb]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c[j][q] = cs[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fma(-xk[2 * q], c[j][q][0], acc[j]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fma(-xk[2 * q + 1], c[j][q][1], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double* crow = &Cs[(8 * jb + j) * PAN_LD + 8 * jb];
+            double sacc = acc[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sacc = fma(-acc[k], crow[k], sacc);
+            acc[j] = sacc * rinvs[8 * jb + j];
+        }
+        {
+            pan_d2* dst = reinterpret_cast<pan_d2*>(&Xs[lane * PAN_LD + 8 * jb]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
         }
     }
-#pragma unroll
-    for (int j = 0; j < 64; ++j) Bt[lane * 65 + j] = a[j];
     __syncthreads();
+#pragma unroll
     for (int r = 0; r < 64; ++r)
-        if (row0 + r < nrows && lane < cb) B[(size_t)(row0 + r) * ldb + lane] = Bt[r * 65 + lane];
+        if (row0 + r < nrows && lane < cb) B[(size_t)(row0 + r) * ldb + lane] = Xs[r * PAN_LD + (FWD ? lane : 63 - lane)];
 }
 
 template <bool FWD>
 static void launch_strip(const double* Ld, int ldl, int cb, double* B, int ldb, int nrows, hipStream_t stream) {
     if (nrows <= 0) return;
-    const dim3 grid(gpar_ceil_div(nrows, 64)), block(64);
-    if (cb == 64) hipLaunchKernelGGL((trsm_strip64_kernel<FWD>), grid, block, 0, stream, Ld, ldl, B, ldb, nrows);
-    else hipLaunchKernelGGL((trsm_strip_kernel<FWD>), grid, block, 0, stream, Ld, ldl, cb, B, ldb, nrows);
+    hipLaunchKernelGGL((trsm_strip_kernel<FWD>), dim3(gpar_ceil_div(nrows, 64)), dim3(64), 0, stream, Ld, ldl, cb, B, ldb, nrows);
 }
 
 // ---------------------------------------------------------------------------------------------------
