@@ -23,6 +23,7 @@
 //   MC  [16][144]  for operands stored with m/n contiguous (read: 144*k + r)
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 namespace gpar {
 
@@ -44,6 +45,7 @@ struct GemmArgs {
     int flags;
     int tiles_m, tiles_n;
     int fastA, fastB;
+    int stagger;
 };
 
 typedef double gpar_d2 __attribute__((ext_vector_type(2)));
@@ -52,11 +54,12 @@ typedef double gpar_d2 __attribute__((ext_vector_type(2)));
 //   KC: tile element (r, kk) lives at g[(r0 + r) * ld + k0 + kk]     (r < 128, kk < 16)
 //   MC: tile element (r, kk) lives at g[(k0 + kk) * ld + r0 + r]
 // `lower`: entries with global k > global r are treated as zero (triangular op(A)).
-template <bool KC>
+template <bool KC, bool FAST>
 __device__ __forceinline__ void gemm_gload(const double* __restrict__ g, int ld, int r0, int rmax, int k0,
-                                           int kmax, bool vec, bool lower, int t, gpar_d2 (&reg)[4]) {
-    const bool full = vec && (r0 + GEMM_BM <= rmax) && (k0 + GEMM_BK <= kmax) && (!lower || k0 + GEMM_BK - 1 <= r0);
-    if (full) {
+                                           int kmax, bool lower, int t, gpar_d2 (&reg)[4]) {
+    if (FAST) {
+        // interior tile, aligned operand: branch-free 16-byte loads (any branch around a load makes hipcc fence it
+        // with vmcnt(0), serialising the A and B requests and exposing a memory round trip per stage)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = t + 256 * q;
@@ -69,24 +72,19 @@ __device__ __forceinline__ void gemm_gload(const double* __restrict__ g, int ld,
             }
         }
     } else {
+        // edge tile / unaligned operand / triangular operand: clamped (always valid) scalar loads, masked afterwards
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = t + 256 * q;
-            double v0 = 0.0, v1 = 0.0;
-            if (KC) {
-                const int r = r0 + (c >> 3), kk = k0 + (c & 7) * 2;
-                if (r < rmax) {
-                    if (kk < kmax && (!lower || kk <= r)) v0 = g[(size_t)r * ld + kk];
-                    if (kk + 1 < kmax && (!lower || kk + 1 <= r)) v1 = g[(size_t)r * ld + kk + 1];
-                }
-            } else {
-                const int kk = k0 + (c >> 6), r = r0 + (c & 63) * 2;
-                if (kk < kmax) {
-                    if (r < rmax && (!lower || kk <= r)) v0 = g[(size_t)kk * ld + r];
-                    if (r + 1 < rmax && (!lower || kk <= r + 1)) v1 = g[(size_t)kk * ld + r + 1];
-                }
-            }
-            reg[q] = gpar_d2{v0, v1};
+            int r, kk, r1, kk1;
+            if (KC) { r = r0 + (c >> 3); kk = k0 + (c & 7) * 2; r1 = r; kk1 = kk + 1; }
+            else { kk = k0 + (c >> 6); r = r0 + (c & 63) * 2; r1 = r + 1; kk1 = kk; }
+            const bool ok0 = r < rmax && kk < kmax && (!lower || kk <= r);
+            const bool ok1 = r1 < rmax && kk1 < kmax && (!lower || kk1 <= r1);
+            const int rc = min(r, rmax - 1), kc = min(kk, kmax - 1), rc1 = min(r1, rmax - 1), kc1 = min(kk1, kmax - 1);
+            const double v0 = KC ? g[(size_t)rc * ld + kc] : g[(size_t)kc * ld + rc];
+            const double v1 = KC ? g[(size_t)rc1 * ld + kc1] : g[(size_t)kc1 * ld + rc1];
+            reg[q] = gpar_d2{ok0 ? v0 : 0.0, ok1 ? v1 : 0.0};
         }
     }
 }
@@ -103,6 +101,58 @@ __device__ __forceinline__ void gemm_sstore(double* __restrict__ s, int t, const
             const int kk = c >> 6, r = (c & 63) * 2;
             *reinterpret_cast<gpar_d2*>(s + kk * GEMM_LDMC + r) = reg[q];
         }
+    }
+}
+
+// K loop of one 128 x 128 tile.  FAST (interior tile, aligned operands, k % 16 == 0) is branch-free so the loads
+// of stage s+1 stay in flight under the MFMAs of stage s; the other instantiation handles every edge case.
+template <bool A_KC, bool B_KC, bool FAST>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, double (&acc)[16][4], int m0, int n0,
+                                              int kend, int nk, bool a_lower, int t, int lane, int wm, int wn) {
+    gpar_d2 ra[4], rb[4];
+    if (nk > 0) {
+        gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, 0, kend, a_lower, t, ra);
+        gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, 0, kend, false, t, rb);
+        gemm_sstore<A_KC>(smem, t, ra);
+        gemm_sstore<B_KC>(smem + GEMM_TILE, t, rb);
+    }
+    __syncthreads();
+
+    const int l3 = lane & 3, l15 = lane & 15, lk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const double* As = smem + (kt & 1) * 2 * GEMM_TILE;
+        const double* Bs = As + GEMM_TILE;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, (kt + 1) * GEMM_BK, kend, a_lower, t, ra);
+            gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, (kt + 1) * GEMM_BK, kend, false, t, rb);
+        }
+#pragma unroll 1
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int kk = k4 * 4 + lk;
+            double pf[16], qf[4];
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) {
+                const int c = wn * 64 + 16 * nj + l15;
+                qf[nj] = B_KC ? Bs[c * GEMM_LDKC + kk] : Bs[kk * GEMM_LDMC + c];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 16; ++mi) {
+                const int r = wm * 64 + 4 * mi + l3;
+                pf[mi] = A_KC ? As[r * GEMM_LDKC + kk] : As[kk * GEMM_LDMC + r];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 16; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj)
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f64_4x4x4f64(qf[nj], pf[mi], acc[mi][nj], 0, 0, 0);
+        }
+        if (more) {
+            double* An = smem + ((kt + 1) & 1) * 2 * GEMM_TILE;
+            gemm_sstore<A_KC>(An, t, ra);
+            gemm_sstore<B_KC>(An + GEMM_TILE, t, rb);
+        }
+        __syncthreads();
     }
 }
 
@@ -154,81 +204,83 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
 
-    gpar_d2 ra[4], rb[4];
-    if (nk > 0) {
-        gemm_gload<A_KC>(p.A, p.lda, m0, p.m, 0, kend, p.fastA, a_lower, t, ra);
-        gemm_gload<B_KC>(p.B, p.ldb, n0, p.n, 0, kend, p.fastB, false, t, rb);
-        gemm_sstore<A_KC>(smem, t, ra);
-        gemm_sstore<B_KC>(smem + GEMM_TILE, t, rb);
+    // Phase staggering.  All workgroups of the first generation start together and every tile costs the same, so
+    // left alone the whole chip stays in phase: everyone in the MFMA loop (no C traffic), then everyone in the
+    // read-modify-write epilogue (matrix pipes idle behind one HBM burst) - measured as a fixed cost per launch equal
+    // to the streaming time of C, added to the compute time instead of hidden under it.  Spreading the start of the
+    // first generation uniformly over one tile period smooths the HBM demand; later workgroups inherit the spread
+    // because each starts when a predecessor retires.
+    if (p.stagger && blockIdx.x < 512) {
+        const int slot = (blockIdx.x * 7 + (blockIdx.x >> 8) * 8) & 15;
+        const int naps = (nk * 9 * slot) >> 7;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    __syncthreads();
 
-    const int l3 = lane & 3, l15 = lane & 15, lk = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const double* As = smem + (kt & 1) * 2 * GEMM_TILE;
-        const double* Bs = As + GEMM_TILE;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            gemm_gload<A_KC>(p.A, p.lda, m0, p.m, (kt + 1) * GEMM_BK, kend, p.fastA, a_lower, t, ra);
-            gemm_gload<B_KC>(p.B, p.ldb, n0, p.n, (kt + 1) * GEMM_BK, kend, p.fastB, false, t, rb);
+    // beta != 0: touch the 1024 cache lines of this tile of C now, so that the read-modify-write epilogue finds
+    // them in L2.  Without it every workgroup reaches its epilogue at about the same time and the whole chip waits
+    // on one HBM burst per tile generation (measured: a fixed 0.7 ms per n = 16384 launch, independent of k).
+    double touch[4] = {0.0, 0.0, 0.0, 0.0};
+    if (p.beta != 0.0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int li = t + 256 * q;
+            const int row = min(m0 + (li >> 3), p.m - 1), col = min(n0 + (li & 7) * 16, p.n - 1);
+            touch[q] = p.C[(size_t)row * p.ldc + col];
         }
-#pragma unroll 1
-        for (int k4 = 0; k4 < 4; ++k4) {
-            const int kk = k4 * 4 + lk;
-            double pf[16], qf[4];
-#pragma unroll
-            for (int mi = 0; mi < 16; ++mi) {
-                const int r = wm * 64 + 4 * mi + l3;
-                pf[mi] = A_KC ? As[r * GEMM_LDKC + kk] : As[kk * GEMM_LDMC + r];
-            }
-#pragma unroll
-            for (int nj = 0; nj < 4; ++nj) {
-                const int c = wn * 64 + 16 * nj + l15;
-                qf[nj] = B_KC ? Bs[c * GEMM_LDKC + kk] : Bs[kk * GEMM_LDMC + c];
-            }
-#pragma unroll
-            for (int mi = 0; mi < 16; ++mi)
-#pragma unroll
-                for (int nj = 0; nj < 4; ++nj)
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f64_4x4x4f64(qf[nj], pf[mi], acc[mi][nj], 0, 0, 0);
-        }
-        if (more) {
-            double* An = smem + ((kt + 1) & 1) * 2 * GEMM_TILE;
-            gemm_sstore<A_KC>(An, t, ra);
-            gemm_sstore<B_KC>(An + GEMM_TILE, t, rb);
-        }
-        __syncthreads();
     }
+
+    const bool fast = p.fastA && p.fastB && !a_lower && (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n) && (kend % GEMM_BK == 0);
+    if (fast) gemm_mainloop<A_KC, B_KC, true>(p, smem, acc, m0, n0, kend, nk, a_lower, t, lane, wm, wn);
+    else gemm_mainloop<A_KC, B_KC, false>(p, smem, acc, m0, n0, kend, nk, a_lower, t, lane, wm, wn);
+    asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));   // keep the touches alive
+    const int l3 = lane & 3, lk = lane >> 4;
 
     // epilogue: lane l of acc[mi][nj] holds C[4*mi + (l&3)][16*nj + 4*((l>>2)&3) + (l>>4)] of the wave tile
     const bool c_lower = (p.flags & GPAR_GEMM_C_LOWER) != 0;
     const int colw = n0 + wn * 64 + 4 * ((lane >> 2) & 3) + lk;
     const int roww = m0 + wm * 64 + l3;
     const double alpha = p.alpha, beta = p.beta;
+    // Loads of C are never placed behind a per-element condition (hipcc would fence each with vmcnt(0): 64 serial
+    // memory round trips per tile, measured as a fixed ~20 us per tile): interior tiles use plain loads/stores, edge
+    // tiles load from clamped (always valid) addresses and only the stores are predicated.
+    const bool interior = (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n) && (!c_lower || n0 + GEMM_BN - 1 <= m0);
+    if (interior) {
 #pragma unroll
-    for (int mi = 0; mi < 16; ++mi) {
-        const int row = roww + 4 * mi;
-        double* crow = p.C + (size_t)row * p.ldc;
-        if (beta != 0.0) {
-            double cv[4];
+        for (int half = 0; half < 2; ++half) {
+            double cv[8][4];
+            if (beta != 0.0) {
 #pragma unroll
-            for (int nj = 0; nj < 4; ++nj) {
-                const int col = colw + 16 * nj;
-                const bool ok = row < p.m && col < p.n && (!c_lower || col <= row);
-                cv[nj] = ok ? crow[col] : 0.0;
+                for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < 4; ++nj)
+                        cv[mi][nj] = p.C[(size_t)(roww + 4 * (8 * half + mi)) * p.ldc + colw + 16 * nj];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    double v = alpha * acc[8 * half + mi][nj];
+                    if (beta != 0.0) v = fma(beta, cv[mi][nj], v);
+                    p.C[(size_t)(roww + 4 * (8 * half + mi)) * p.ldc + colw + 16 * nj] = v;
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 16; ++mi) {
+            const int row = roww + 4 * mi;
+            const int rowc = min(row, p.m - 1);
+            double cv[4] = {0.0, 0.0, 0.0, 0.0};
+            if (beta != 0.0) {
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) cv[nj] = p.C[(size_t)rowc * p.ldc + min(colw + 16 * nj, p.n - 1)];
             }
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) {
                 const int col = colw + 16 * nj;
                 const bool ok = row < p.m && col < p.n && (!c_lower || col <= row);
-                if (ok) crow[col] = alpha * acc[mi][nj] + beta * cv[nj];
-            }
-        } else {
-#pragma unroll
-            for (int nj = 0; nj < 4; ++nj) {
-                const int col = colw + 16 * nj;
-                const bool ok = row < p.m && col < p.n && (!c_lower || col <= row);
-                if (ok) crow[col] = alpha * acc[mi][nj];
+                double v = alpha * acc[mi][nj];
+                if (beta != 0.0) v = fma(beta, cv[nj], v);
+                if (ok) p.C[(size_t)row * p.ldc + col] = v;
             }
         }
     }
@@ -259,6 +311,11 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     }
     p.fastA = gpar_aligned16(A) && (lda % 2 == 0);
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
+    {
+        static int stagger_env = -1;
+        if (stagger_env < 0) { const char* e = getenv("GPAR_GEMM_STAGGER"); stagger_env = e ? atoi(e) : 1; }
+        p.stagger = stagger_env;
+    }
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
     static bool attr_done = false;
     if (!attr_done) {

@@ -10,6 +10,7 @@
 #pragma once
 #include "common.h"
 #include "gemm_f64.h"
+#include <stdlib.h>
 
 namespace gpar {
 
@@ -232,59 +233,188 @@ static void profile_collect() {
     g_prof.nev = 0;
 }
 
-static int potrf_outer_block(int N) {
-    // measured trade-off: wider panels raise SYRK intensity, narrower panels shorten the serial panel chain
-    if (N >= 6144) return 256;
-    if (N >= 1536) return 128;
-    return 64;
+// ---- blocking policy (overridable for experiments: GPAR_POTRF_NBO / GPAR_POTRF_NBM / GPAR_POTRF_LOOKAHEAD) ----------
+struct PotrfPolicy {
+    int nbo;        // top-level panel width: K of the trailing SYRK
+    int nbm;        // mid-level width inside a panel
+    int lookahead;  // overlap panel k+1 with the trailing update of panel k on a second stream
+    int split;      // factor the diagonal block first, then solve the rows below (see potrf_panel_split)
+};
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
+static PotrfPolicy potrf_policy(int N) {
+    PotrfPolicy p;
+    // wider top-level panels amortise the read-modify-write of the trailing matrix over more flops (measured SYRK
+    // rate at n = 16384: K = 128 31, K = 256 42, K = 512 53 TFLOP/s); the panel itself is factored recursively
+    if (N >= 12288) p.nbo = 512;
+    else if (N >= 6144) p.nbo = 256;
+    else if (N >= 1536) p.nbo = 128;
+    else p.nbo = 64;
+    p.nbm = p.nbo >= 512 ? 128 : 64;
+    // Look-ahead on a second stream is implemented but OFF by default: with the present panel kernels the serial
+    // diag/strip chain, not the trailing update, is the critical path (profiles/r01_potrf_trace_*.txt), and the
+    // chain's small kernels queue for CU slots behind the big SYRK, so overlapping buys nothing yet.
+    p.lookahead = 0;
+    p.nbo = env_int("GPAR_POTRF_NBO", p.nbo);
+    p.nbm = env_int("GPAR_POTRF_NBM", p.nbm);
+    p.lookahead = env_int("GPAR_POTRF_LOOKAHEAD", p.lookahead);
+    p.split = env_int("GPAR_POTRF_SPLIT", p.lookahead);
+    if (p.nbo < 64) p.nbo = 64;
+    if (p.nbm < 64) p.nbm = 64;
+    return p;
+}
+
+struct PotrfCtx {
+    double* A;
+    int N, lda;
+    double* logdet;
+    int* info;
+    int nbm;
+};
+
+static int potrf_gemm_update(const PotrfCtx& c, int k0, int kend, int col_end, hipStream_t stream) {
+    // A[kend:N, kend:col_end] -= A[kend:N, k0:kend] A[kend:col_end, k0:kend]^T   (lower part only)
+    const int rows = c.N - kend, cols = col_end - kend;
+    if (rows <= 0 || cols <= 0) return 0;
+    const double* P = c.A + (size_t)kend * c.lda + k0;
+    return gemm_launch(0, 1, rows, cols, kend - k0, -1.0, P, c.lda, P, c.lda, 1.0, c.A + (size_t)kend * c.lda + kend, c.lda,
+                       GPAR_GEMM_C_LOWER, stream);
+}
+
+// Factor columns [c0, c1) (already up to date with respect to all columns < c0): on exit rows c0..N of those
+// columns hold L.  Recursive right-looking restricted to the panel: widths nb(level) -> ... -> 64.
+static int potrf_panel(const PotrfCtx& c, int c0, int c1, int nb, hipStream_t stream) {
+    const int w = c1 - c0;
+    if (w <= POTRF_NBI) {
+        double* Acc = c.A + (size_t)c0 * c.lda + c0;
+        hipLaunchKernelGGL(potrf_diag64_kernel, dim3(1), dim3(64), 0, stream, Acc, c.lda, w, c0, c.logdet, c.info);
+        launch_strip<true>(Acc, c.lda, w, c.A + (size_t)c1 * c.lda + c0, c.lda, c.N - c1, stream);
+        return 0;
+    }
+    if (nb >= w) nb = (w > c.nbm && c.nbm >= POTRF_NBI) ? c.nbm : POTRF_NBI;
+    const int next_nb = nb > c.nbm ? c.nbm : POTRF_NBI;
+    for (int k0 = c0; k0 < c1; k0 += nb) {
+        const int kend = (k0 + nb < c1) ? k0 + nb : c1;
+        int rc = potrf_panel(c, k0, kend, next_nb, stream);
+        if (rc) return rc;
+        rc = potrf_gemm_update(c, k0, kend, c1, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static int trsm_rlt_run(const double* L, int n, int ldl, double* B, int nrows, int ldb, hipStream_t stream);
+
+// Panel = (a) the w x w diagonal block, factored recursively with kernels that only span the block's own rows
+// (1-4 workgroups each: they slip in beside a running trailing update instead of queueing for 256 CU slots), then
+// (b) the rows below, X = A21 L11^-T, as a blocked forward substitution over all rows (bulk work).
+static int potrf_panel_split(const PotrfCtx& c, int k0, int kend, int nb, hipStream_t stream) {
+    PotrfCtx blk = c;
+    blk.N = kend;
+    int rc = potrf_panel(blk, k0, kend, nb, stream);
+    if (rc) return rc;
+    if (c.N > kend)
+        rc = trsm_rlt_run(c.A + (size_t)k0 * c.lda + k0, kend - k0, c.lda, c.A + (size_t)kend * c.lda + k0, c.N - kend, c.lda, stream);
+    return rc;
+}
+
+struct LookaheadState {
+    hipStream_t side = nullptr;
+    static constexpr int MAXE = 1024;
+    hipEvent_t ev[MAXE];
+    int nev = 0;
+    bool ok = false;
+};
+static LookaheadState g_la;
+
+static hipEvent_t la_event() {
+    if (g_la.nev >= LookaheadState::MAXE) g_la.nev = 0;   // ring: far more than one factorisation's worth in flight
+    return g_la.ev[g_la.nev++];
+}
+
+static bool la_init() {
+    if (g_la.ok) return true;
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least urgent
+    if (hipStreamCreateWithPriority(&g_la.side, hipStreamNonBlocking, lo) != hipSuccess) return false;
+    for (int i = 0; i < LookaheadState::MAXE; ++i)
+        if (hipEventCreateWithFlags(&g_la.ev[i], hipEventDisableTiming) != hipSuccess) return false;
+    g_la.ok = true;
+    return true;
+}
+
+static void prof_begin(hipStream_t s, bool& active) {
+    active = g_prof.on && g_prof.nev < ProfileState::MAXEV;
+    if (!active) return;
+    if (!g_prof.created) {
+        for (int i = 0; i < ProfileState::MAXEV; ++i) { hipEventCreate(&g_prof.ev[i][0]); hipEventCreate(&g_prof.ev[i][1]); }
+        g_prof.created = true;
+    }
+    hipEventRecord(g_prof.ev[g_prof.nev][0], s);
+}
+
+static void prof_end(hipStream_t s, bool active, int rows, int cols, int kb) {
+    if (!active) return;
+    hipEventRecord(g_prof.ev[g_prof.nev][1], s);
+    g_prof.nev++;
+    g_prof.launches++;
+    // algorithmic flops of the lower-trapezoid rank-kb update: 2 * kb per stored element
+    g_prof.flops += 2.0 * (double)kb * ((double)cols * ((double)cols + 1.0) * 0.5 + (double)(rows - cols) * (double)cols);
+}
+
+// Top level: panels of `nbo` columns; the trailing update of panel k is split into the next panel's columns
+// (look-ahead part, stays on the caller's stream ahead of the next panel factorisation) and the rest (on a
+// low-priority side stream), so the serial diag/strip chain of panel k+1 runs under the big SYRK of panel k.
 static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* info, hipStream_t stream) {
     if (nf > N) return GPAR_ARG_ERROR(1);
-    const int NBO = potrf_outer_block(N);
-    for (int k0 = 0; k0 < nf; k0 += NBO) {
-        const int kb = (nf - k0 < NBO) ? nf - k0 : NBO;
-        const int kend = k0 + kb;
-        for (int c = k0; c < kend; c += POTRF_NBI) {
-            const int cb = (kend - c < POTRF_NBI) ? kend - c : POTRF_NBI;
-            double* Acc = A + (size_t)c * lda + c;
-            hipLaunchKernelGGL(potrf_diag64_kernel, dim3(1), dim3(64), 0, stream, Acc, lda, cb, c, logdet, info);
-            const int r0 = c + cb;
-            const int below = N - r0;
-            if (below > 0) {
-                launch_strip<true>(Acc, lda, cb, A + (size_t)r0 * lda + c, lda, below, stream);
-                const int ncols = kend - r0;   // remaining columns of this panel
-                if (ncols > 0) {
-                    const double* P = A + (size_t)r0 * lda + c;
-                    int rc = gemm_launch(0, 1, below, ncols, cb, -1.0, P, lda, P, lda, 1.0,
-                                         A + (size_t)r0 * lda + r0, lda, GPAR_GEMM_C_LOWER, stream);
-                    if (rc) return rc;
-                }
-            }
-        }
-        const int rem = N - kend;
-        if (rem > 0) {
-            const double* P = A + (size_t)kend * lda + k0;
-            const bool prof = g_prof.on && g_prof.nev < ProfileState::MAXEV;
-            if (prof) {
-                if (!g_prof.created) {
-                    for (int i = 0; i < ProfileState::MAXEV; ++i) { hipEventCreate(&g_prof.ev[i][0]); hipEventCreate(&g_prof.ev[i][1]); }
-                    g_prof.created = true;
-                }
-                hipEventRecord(g_prof.ev[g_prof.nev][0], stream);
-            }
-            int rc = gemm_launch(0, 1, rem, rem, kb, -1.0, P, lda, P, lda, 1.0, A + (size_t)kend * lda + kend, lda,
-                                 GPAR_GEMM_C_LOWER, stream);
+    const PotrfPolicy pol = potrf_policy(N);
+    PotrfCtx c{A, N, lda, logdet, info, pol.nbm};
+    const int nbo = pol.nbo;
+    const bool la = pol.lookahead && nf > nbo && la_init();
+    hipEvent_t trail_done = nullptr;   // completion of the side-stream update issued in the previous step
+    for (int k0 = 0; k0 < nf; k0 += nbo) {
+        const int kend = (k0 + nbo < nf) ? k0 + nbo : nf;
+        int rc = pol.split ? potrf_panel_split(c, k0, kend, nbo, stream) : potrf_panel(c, k0, kend, nbo, stream);
+        if (rc) return rc;
+        if (kend >= N) break;
+        const int next_end = (kend + nbo < nf) ? kend + nbo : nf;   // columns of the next panel: [kend, next_end)
+        bool pa;
+        if (!la || kend >= nf) {
+            // no further panel to overlap with (or look-ahead off): one update of everything that is left
+            if (la && trail_done) { hipStreamWaitEvent(stream, trail_done, 0); trail_done = nullptr; }
+            prof_begin(stream, pa);
+            rc = potrf_gemm_update(c, k0, kend, N, stream);
+            prof_end(stream, pa, N - kend, N - kend, kend - k0);
             if (rc) return rc;
-            if (prof) {
-                hipEventRecord(g_prof.ev[g_prof.nev][1], stream);
-                g_prof.nev++;
-                g_prof.launches++;
-                // algorithmic flops of the lower-triangular rank-kb update
-                g_prof.flops += (double)rem * ((double)rem + 1.0) * (double)kb;
+            continue;
+        }
+        // (1) next panel's columns, on the caller's stream; they were last written by the previous side update
+        if (trail_done) hipStreamWaitEvent(stream, trail_done, 0);
+        hipEvent_t panel_done = la_event();
+        hipEventRecord(panel_done, stream);
+        rc = potrf_gemm_update(c, k0, kend, next_end, stream);
+        if (rc) return rc;
+        // (2) everything to the right of the next panel, on the side stream
+        hipStreamWaitEvent(g_la.side, panel_done, 0);
+        {
+            const int rows = N - next_end, cols = N - next_end;
+            if (rows > 0) {
+                const double* P = A + (size_t)next_end * lda + k0;
+                prof_begin(g_la.side, pa);
+                rc = gemm_launch(0, 1, rows, cols, kend - k0, -1.0, P, lda, P, lda, 1.0, A + (size_t)next_end * lda + next_end,
+                                 lda, GPAR_GEMM_C_LOWER, g_la.side);
+                prof_end(g_la.side, pa, rows, cols, kend - k0);
+                if (rc) return rc;
             }
         }
+        trail_done = la_event();
+        hipEventRecord(trail_done, g_la.side);
     }
+    if (trail_done) hipStreamWaitEvent(stream, trail_done, 0);   // join
     GPAR_LAUNCH_CHECK();
     return 0;
 }
