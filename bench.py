@@ -150,13 +150,14 @@ def main():
     if launches.value > 0 and ms.value > 0:
         achieved = flops.value / (ms.value * 1e-3) * 1e-12
         out["roofline"] = {
-            "kernel": "gemm_f64_kernel<false,true> (trailing SYRK update of gpar_potrf, v_mfma_f64_4x4x4_4b)",
+            "kernel": "gpar::gemm_f64_kernel<false, true, 1> (trailing SYRK update of gpar_potrf, v_mfma_f64_4x4x4_4b)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MATRIX_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": pmc_traffic(n, m, p),
+            "traffic_source": "profiles/r01_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)",
             "launches": launches.value,
             "avg_launch_ms": ms.value / launches.value,
             "rank": 0,
@@ -171,6 +172,16 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def pmc_traffic(n, m, p):
+    """HBM bytes per trailing-SYRK launch from the committed PMC passes of this very workload (null for any other
+    workload: counters cannot be collected from inside the timed process)."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")
+    if (n, m, p) != (16384, 4, 8) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("traffic_bytes_per_launch")
 
 
 def fit_predict_leg(eng, x_np, y_np, n, m, p, fit_iters=2, num_samples=4, n_star=1024):

@@ -157,7 +157,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, d
 }
 
 // TA: A stored k x m (op(A) = A^T);  TB: B stored n x k (op(B) = B^T).
-template <bool TA, bool TB>
+// ROLE only gives the trailing SYRK of gpar_potrf (ROLE = 1) its own kernel symbol, so that profilers report the
+// dominant kernel separately from the small panel-internal updates that share the code.
+template <bool TA, bool TB, int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr bool A_KC = !TA;
@@ -295,7 +297,8 @@ inline int gemm_num_tiles(int tiles_m, int tiles_n, int flags) {
 }
 
 static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
-                       const double* B, int ldb, double beta, double* C, int ldc, int flags, hipStream_t stream) {
+                       const double* B, int ldb, double beta, double* C, int ldc, int flags, hipStream_t stream,
+                       int role = 0) {
     if (m <= 0 || n <= 0) return 0;
     GemmArgs p;
     p.A = A; p.B = B; p.C = C;
@@ -319,17 +322,19 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
         attr_done = true;
     }
     dim3 grid(ntiles), block(256);
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, GEMM_LDS_BYTES, stream, p);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, GEMM_LDS_BYTES, stream, p);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, GEMM_LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, GEMM_LDS_BYTES, stream, p);
+    if (role == 1 && !ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, GEMM_LDS_BYTES, stream, p);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((gemm_f64_kernel<true, true, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

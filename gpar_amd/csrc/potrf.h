@@ -276,13 +276,13 @@ struct PotrfCtx {
     int nbm;
 };
 
-static int potrf_gemm_update(const PotrfCtx& c, int k0, int kend, int col_end, hipStream_t stream) {
+static int potrf_gemm_update(const PotrfCtx& c, int k0, int kend, int col_end, hipStream_t stream, int role = 0) {
     // A[kend:N, kend:col_end] -= A[kend:N, k0:kend] A[kend:col_end, k0:kend]^T   (lower part only)
     const int rows = c.N - kend, cols = col_end - kend;
     if (rows <= 0 || cols <= 0) return 0;
     const double* P = c.A + (size_t)kend * c.lda + k0;
     return gemm_launch(0, 1, rows, cols, kend - k0, -1.0, P, c.lda, P, c.lda, 1.0, c.A + (size_t)kend * c.lda + kend, c.lda,
-                       GPAR_GEMM_C_LOWER, stream);
+                       GPAR_GEMM_C_LOWER, stream, role);
 }
 
 // Factor columns [c0, c1) (already up to date with respect to all columns < c0): on exit rows c0..N of those
@@ -387,7 +387,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             // no further panel to overlap with (or look-ahead off): one update of everything that is left
             if (la && trail_done) { hipStreamWaitEvent(stream, trail_done, 0); trail_done = nullptr; }
             prof_begin(stream, pa);
-            rc = potrf_gemm_update(c, k0, kend, N, stream);
+            rc = potrf_gemm_update(c, k0, kend, N, stream, 1);
             prof_end(stream, pa, N - kend, N - kend, kend - k0);
             if (rc) return rc;
             continue;
@@ -406,7 +406,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
                 const double* P = A + (size_t)next_end * lda + k0;
                 prof_begin(g_la.side, pa);
                 rc = gemm_launch(0, 1, rows, cols, kend - k0, -1.0, P, lda, P, lda, 1.0, A + (size_t)next_end * lda + next_end,
-                                 lda, GPAR_GEMM_C_LOWER, g_la.side);
+                                 lda, GPAR_GEMM_C_LOWER, g_la.side, 1);
                 prof_end(g_la.side, pa, rows, cols, kend - k0);
                 if (rc) return rc;
             }
