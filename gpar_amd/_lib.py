@@ -80,6 +80,7 @@ SIGNATURES = {
     "gpar_potrf": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "gpar_trsm_rlt": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),
     "gpar_trsm_rln": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),
+    "gpar_chol_inverse": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr]),
     "gpar_gemm": (
         _c_int,
         [_c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _ptr, _c_int, _ptr, _c_int, _c_dbl, _ptr, _c_int, _c_int, _ptr],

@@ -46,6 +46,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int fastA, fastB;
     int stagger;
+    long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memtime stamps, normally null
 };
 
 typedef double gpar_d2 __attribute__((ext_vector_type(2)));
@@ -108,11 +109,11 @@ __device__ __forceinline__ void gemm_sstore(double* __restrict__ s, int t, const
 // of stage s+1 stay in flight under the MFMAs of stage s; the other instantiation handles every edge case.
 template <bool A_KC, bool B_KC, bool FAST>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, double (&acc)[16][4], int m0, int n0,
-                                              int kend, int nk, bool a_lower, int t, int lane, int wm, int wn) {
+                                              int kbeg, int kend, int nk, bool a_lower, int t, int lane, int wm, int wn) {
     gpar_d2 ra[4], rb[4];
     if (nk > 0) {
-        gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, 0, kend, a_lower, t, ra);
-        gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, 0, kend, false, t, rb);
+        gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, kbeg, kend, a_lower, t, ra);
+        gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, kbeg, kend, false, t, rb);
         gemm_sstore<A_KC>(smem, t, ra);
         gemm_sstore<B_KC>(smem + GEMM_TILE, t, rb);
     }
@@ -124,8 +125,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, d
         const double* Bs = As + GEMM_TILE;
         const bool more = kt + 1 < nk;
         if (more) {
-            gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, (kt + 1) * GEMM_BK, kend, a_lower, t, ra);
-            gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, (kt + 1) * GEMM_BK, kend, false, t, rb);
+            gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, kbeg + (kt + 1) * GEMM_BK, kend, a_lower, t, ra);
+            gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, kbeg + (kt + 1) * GEMM_BK, kend, false, t, rb);
         }
 #pragma unroll 1
         for (int k4 = 0; k4 < 4; ++k4) {
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
 
     // XCD-aware, bijective remap of the block index: the dispatcher places block b on XCD b % 8; give each
     // XCD a contiguous run of tiles so neighbouring tiles (shared operand panels) hit the same L2.
+    const long long t_start = p.stamps ? (long long)__builtin_readcyclecounter() : 0;
     int idx;
     {
         const int nb = gridDim.x, b = blockIdx.x;
@@ -198,7 +200,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     const bool a_lower = (p.flags & GPAR_GEMM_A_LOWER) != 0;
     // with a triangular op(A) nothing beyond k = m0 + 127 contributes to this tile
     const int kend = a_lower ? min(p.k, m0 + GEMM_BM) : p.k;
-    const int nk = (kend + GEMM_BK - 1) / GEMM_BK;
+    // K_FROM_ROW: both operands vanish for k < their row (upper-triangular factors): with col <= row nothing
+    // before k = m0 contributes to this tile
+    const int kbeg = (p.flags & GPAR_GEMM_K_FROM_ROW) ? min(m0, kend) : 0;
+    const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
 
     double acc[16][4];
 #pragma unroll
@@ -218,23 +223,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
     }
 
-    // beta != 0: touch the 1024 cache lines of this tile of C now, so that the read-modify-write epilogue finds
-    // them in L2.  Without it every workgroup reaches its epilogue at about the same time and the whole chip waits
-    // on one HBM burst per tile generation (measured: a fixed 0.7 ms per n = 16384 launch, independent of k).
-    double touch[4] = {0.0, 0.0, 0.0, 0.0};
-    if (p.beta != 0.0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int li = t + 256 * q;
-            const int row = min(m0 + (li >> 3), p.m - 1), col = min(n0 + (li & 7) * 16, p.n - 1);
-            touch[q] = p.C[(size_t)row * p.ldc + col];
-        }
-    }
-
-    const bool fast = p.fastA && p.fastB && !a_lower && (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n) && (kend % GEMM_BK == 0);
-    if (fast) gemm_mainloop<A_KC, B_KC, true>(p, smem, acc, m0, n0, kend, nk, a_lower, t, lane, wm, wn);
-    else gemm_mainloop<A_KC, B_KC, false>(p, smem, acc, m0, n0, kend, nk, a_lower, t, lane, wm, wn);
-    asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));   // keep the touches alive
+    const bool fast = p.fastA && p.fastB && !a_lower && (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n) && ((kend - kbeg) % GEMM_BK == 0);
+    if (fast) gemm_mainloop<A_KC, B_KC, true>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
+    else gemm_mainloop<A_KC, B_KC, false>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
+    const long long t_main = p.stamps ? (long long)__builtin_readcyclecounter() : 0;
     const int l3 = lane & 3, lk = lane >> 4;
 
     // epilogue: lane l of acc[mi][nj] holds C[4*mi + (l&3)][16*nj + 4*((l>>2)&3) + (l>>4)] of the wave tile
@@ -286,6 +278,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
             }
         }
     }
+    if (p.stamps && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.stamps[blockIdx.x * 4 + 0] = t_start;
+        p.stamps[blockIdx.x * 4 + 1] = t_main;
+        p.stamps[blockIdx.x * 4 + 2] = (long long)__builtin_readcyclecounter();
+    }
 }
 
 inline int gemm_num_tiles(int tiles_m, int tiles_n, int flags) {
@@ -314,6 +312,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     }
     p.fastA = gpar_aligned16(A) && (lda % 2 == 0);
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
+    p.stamps = nullptr;
     {
         static int stagger_env = -1;
         if (stagger_env < 0) { const char* e = getenv("GPAR_GEMM_STAGGER"); stagger_env = e ? atoi(e) : 1; }
@@ -322,19 +321,22 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+    static int lds_extra = -1;
+    if (lds_extra < 0) { const char* e = getenv("GPAR_GEMM_LDS_EXTRA"); lds_extra = e ? atoi(e) : 0; }
+    const int GEMM_LDS_REQ = GEMM_LDS_BYTES + lds_extra;   // experiment knob: > 6.2 KB extra forces one workgroup per CU
     dim3 grid(ntiles), block(256);
-    if (role == 1 && !ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, GEMM_LDS_BYTES, stream, p);
-    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL((gemm_f64_kernel<true, true, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
+    if (role == 1 && !ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, GEMM_LDS_REQ, stream, p);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, GEMM_LDS_REQ, stream, p);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, GEMM_LDS_REQ, stream, p);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, GEMM_LDS_REQ, stream, p);
+    else hipLaunchKernelGGL((gemm_f64_kernel<true, true, 0>), grid, block, GEMM_LDS_REQ, stream, p);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

@@ -180,6 +180,10 @@ int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb
     return trsm_rln_run(L, n, ldl, B, nrows, ldb, (hipStream_t)stream);
 }
 
+int gpar_chol_inverse(const double* L, int n, int ldl, double* X, int ldx, double* Kinv, int ldk, void* stream) {
+    return chol_inverse_run(L, n, ldl, X, ldx, Kinv, ldk, (hipStream_t)stream);
+}
+
 int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B, int ldb,
               double beta, double* C, int ldc, int flags, void* stream) {
     return gemm_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, (hipStream_t)stream);

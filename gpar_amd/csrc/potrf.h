@@ -308,6 +308,7 @@ static int potrf_panel(const PotrfCtx& c, int c0, int c1, int nb, hipStream_t st
 }
 
 static int trsm_rlt_run(const double* L, int n, int ldl, double* B, int nrows, int ldb, hipStream_t stream);
+static int trsm_rlt_run2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int upper_tri, hipStream_t stream);
 
 // Panel = (a) the w x w diagonal block, factored recursively with kernels that only span the block's own rows
 // (1-4 workgroups each: they slip in beside a running trailing update instead of queueing for 256 CU slots), then
@@ -422,19 +423,55 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
 // B <- B L^-T : forward over column blocks.  B[:, c:c+cb] solved against L_cc, then
 // B[:, c+cb:] -= X_c L[c+cb:, c:c+cb]^T  (NT GEMM, K = cb)
 static int trsm_rlt_run(const double* L, int n, int ldl, double* B, int nrows, int ldb, hipStream_t stream) {
+    return trsm_rlt_run2(L, n, ldl, B, nrows, ldb, 0, stream);
+}
+
+// Two-level blocked forward substitution.  Columns are processed in blocks of NB: inside a block, 64-wide strip
+// solves with rank-64 updates confined to the block; the rest of the row block is then updated with ONE GEMM of
+// K = NB (the K = 64 updates over all remaining columns that a one-level scheme issues run at a third of the rate).
+// `upper_tri`: B is upper triangular on entry (e.g. the identity when forming L^-T): row r has nothing left of
+// column r, so block [c0, c1) only involves rows < c1 - the n^3 of a full solve becomes n^3 / 3.
+static int trsm_rlt_run2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int upper_tri, hipStream_t stream) {
     if (nrows <= 0) return 0;
-    for (int c = 0; c < n; c += POTRF_NBI) {
-        const int cb = (n - c < POTRF_NBI) ? n - c : POTRF_NBI;
-        launch_strip<true>(L + (size_t)c * ldl + c, ldl, cb, B + c, ldb, nrows, stream);
-        const int rest = n - (c + cb);
-        if (rest > 0) {
-            int rc = gemm_launch(0, 1, nrows, rest, cb, -1.0, B + c, ldb, L + (size_t)(c + cb) * ldl + c, ldl, 1.0,
-                                 B + c + cb, ldb, 0, stream);
+    const int NB = n >= 4096 ? 512 : (n >= 1024 ? 256 : 64);
+    for (int c0 = 0; c0 < n; c0 += NB) {
+        const int c1 = (c0 + NB < n) ? c0 + NB : n;
+        const int rows = upper_tri ? (nrows < c1 ? nrows : c1) : nrows;
+        for (int c = c0; c < c1; c += POTRF_NBI) {
+            const int cb = (c1 - c < POTRF_NBI) ? c1 - c : POTRF_NBI;
+            launch_strip<true>(L + (size_t)c * ldl + c, ldl, cb, B + c, ldb, rows, stream);
+            const int rest = c1 - (c + cb);
+            if (rest > 0) {
+                int rc = gemm_launch(0, 1, rows, rest, cb, -1.0, B + c, ldb, L + (size_t)(c + cb) * ldl + c, ldl, 1.0,
+                                     B + c + cb, ldb, 0, stream);
+                if (rc) return rc;
+            }
+        }
+        if (c1 < n) {
+            int rc = gemm_launch(0, 1, rows, n - c1, c1 - c0, -1.0, B + c0, ldb, L + (size_t)c1 * ldl + c0, ldl, 1.0, B + c1, ldb,
+                                 0, stream);
             if (rc) return rc;
         }
     }
     GPAR_LAUNCH_CHECK();
     return 0;
+}
+
+// Lower triangle of (L L^T)^-1 into Kinv, with X (n x n) as workspace:  X = L^-T (upper triangular, by the
+// triangular-aware solve of the identity), Kinv = X X^T where only k >= row contributes.  2 n^3 / 3 flops.
+// [torch autograd through cholesky/solve_triangular forms the same quantity implicitly, gpar/regression.py:459]
+__global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ X, int n, int ldx) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c < n) X[(size_t)r * ldx + c] = (r == c) ? 1.0 : 0.0;
+}
+
+static int chol_inverse_run(const double* L, int n, int ldl, double* X, int ldx, double* Kinv, int ldk, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(set_identity_kernel, dim3(gpar_ceil_div(n, 256), n), dim3(256), 0, stream, X, n, ldx);
+    int rc = trsm_rlt_run2(L, n, ldl, X, n, ldx, 1, stream);
+    if (rc) return rc;
+    return gemm_launch(0, 1, n, n, n, 1.0, X, ldx, X, ldx, 0.0, Kinv, ldk, GPAR_GEMM_C_LOWER | GPAR_GEMM_K_FROM_ROW, stream);
 }
 
 // B <- B L^-1 : backward over column blocks.  B[:, c:c+cb] solved against L_cc, then

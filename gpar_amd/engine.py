@@ -90,6 +90,9 @@ class HipEngine:
     def gemm(self, A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False, a_lower=False):
         return hip.gemm(self._mat(A), self._mat(B), ta=ta, tb=tb, alpha=alpha, beta=beta, out=out, c_lower=c_lower, a_lower=a_lower)
 
+    def chol_inverse(self, L):
+        return hip.chol_inverse(L)
+
     def kernel_grads(self, ck, x, W):
         """1/2 sum_ab W_ab dK_ab/dtheta for every parameter of the compiled kernel (W: lower triangle of a symmetric
         matrix).  One fused device pass produces per-term / per-factor / per-feature moment sums (csrc/gram.h); the

@@ -319,10 +319,7 @@ class Obs:
     def gradients(self):
         """(1/2 diag(W) as a device vector, kernel-parameter gradients) with W = alpha alpha^T - (K + D)^-1."""
         eng, fac, n = self.eng, self.factor(), self.fdd.n
-        X = eng.new_matrix(n, n, zero=True)
-        X.diagonal().fill_(1.0)
-        eng.trsm_rlt_(fac.L, X)  # X = L^-T
-        W = eng.gemm(X, X, tb=True, c_lower=True)  # (K + D)^-1, lower triangle
+        W = eng.chol_inverse(fac.L)  # (K + D)^-1, lower triangle
         a = fac.alpha()
         eng.gemm(a, a, ta=True, alpha=1.0, beta=-1.0, out=W, c_lower=True)
         ck, _ = self.fdd.features()

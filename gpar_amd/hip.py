@@ -270,3 +270,17 @@ def gram_grad(ck, z, zd, W, nblocks=None):
         "gpar_gram_grad",
     )
     return out
+
+
+def chol_inverse(L):
+    """Lower triangle of (L L^T)^-1 (new matrix) from the Cholesky factor L; triangular-aware (2 n^3 / 3 flops)."""
+    lib = _lib.load()
+    _check_mat(L, "L")
+    n = L.shape[0]
+    X = alloc_matrix(n, n, L.device)
+    Kinv = alloc_matrix(n, n, L.device)
+    _lib.check(
+        lib.gpar_chol_inverse(L.data_ptr(), n, _ld(L), X.data_ptr(), _ld(X), Kinv.data_ptr(), _ld(Kinv), stream_ptr(L.device)),
+        "gpar_chol_inverse",
+    )
+    return Kinv

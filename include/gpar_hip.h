@@ -90,6 +90,7 @@ typedef struct {
 #define GPAR_GRAM_LOWER 1  /* symmetric Gram (z1 == z2): write only tiles that touch the lower triangle */
 #define GPAR_GEMM_C_LOWER 1 /* C is square-aligned: compute/store only elements with col <= row */
 #define GPAR_GEMM_A_LOWER 2 /* treat op(A) as lower triangular (entries with k > m are zero) */
+#define GPAR_GEMM_K_FROM_ROW 4 /* with C_LOWER: op(A)[m][k] = op(B)^T[n][k] = 0 for k < row, so k starts at the tile's first row */
 
 int gpar_abi_version(void);
 size_t gpar_sizeof_fspec(void);
@@ -137,6 +138,11 @@ int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, voi
 int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);
 /* B <- B L^-1  (right side, lower, not transposed: backward substitution on the rows of B). */
 int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);
+
+/* Kinv (lower triangle) <- (L L^T)^-1 given the Cholesky factor L; X is an n x n workspace (holds L^-T on exit).
+ * Triangular-aware: 2 n^3 / 3 flops.  [the K^-1 that the analytic gradient 1/2 tr((aa^T - K^-1) dK) needs;
+ * replaces autograd through cholesky / solve_triangular, gpar/regression.py:459] */
+int gpar_chol_inverse(const double* L, int n, int ldl, double* X, int ldx, double* Kinv, int ldk, void* stream);
 
 /* C <- alpha * op(A) op(B) + beta * C with op(A) m x k, op(B) k x n.  ta: A is stored k x m (transposed);
  * tb: B is stored n x k (transposed).  fp64 on the matrix cores (v_mfma_f64_4x4x4_4b).

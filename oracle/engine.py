@@ -132,6 +132,15 @@ class OracleEngine:
             b[...] = scipy.linalg.solve_triangular(np.tril(L.numpy()), b.T, lower=True, trans="T").T
         return B
 
+    def chol_inverse(self, L):
+        """Lower triangle of (L L^T)^-1 (dense inverse of the explicit product: an independent route)."""
+        l = np.tril(_np(L))
+        inv = np.linalg.inv(l @ l.T)
+        out = torch.full(inv.shape, float("nan"), dtype=torch.float64)
+        il = np.tril_indices(inv.shape[0])
+        out.numpy()[il] = inv[il]
+        return out
+
     def gemm(self, A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False, a_lower=False):
         a, b = _np(A), _np(B)
         opa = a.T if ta else a

@@ -265,3 +265,16 @@ def test_kernel_gradients_match_oracle(env, m, p_cols, n):
                     if rf[key] is None:
                         continue
                     assert np.allclose(gf[key], rf[key], rtol=1e-10, atol=1e-12 * scale), (name, key, t, fi)
+
+
+@pytest.mark.parametrize("n", [1, 50, 64, 129, 700, 1500, 4200])
+def test_chol_inverse(env, n):
+    """Triangular-aware (L L^T)^-1: two-level TRSM of the identity + SYRK that starts k at the tile's first row."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    A = _spd(rng, n, cond=50.0)
+    L = np.linalg.cholesky(A)
+    got = hip.chol_inverse(to_dev(L + np.triu(np.full((n, n), np.nan), 1))).cpu().numpy()
+    ref = np.linalg.inv(A)
+    il = np.tril_indices(n)
+    assert np.allclose(got[il], ref[il], rtol=1e-9, atol=1e-11 * np.abs(ref).max())
