@@ -45,7 +45,6 @@ struct GemmArgs {
     int flags;
     int tiles_m, tiles_n;
     int fastA, fastB;
-    int stagger;
     long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memtime stamps, normally null
 };
 
@@ -211,18 +210,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
 
-    // Phase staggering.  All workgroups of the first generation start together and every tile costs the same, so
-    // left alone the whole chip stays in phase: everyone in the MFMA loop (no C traffic), then everyone in the
-    // read-modify-write epilogue (matrix pipes idle behind one HBM burst) - measured as a fixed cost per launch equal
-    // to the streaming time of C, added to the compute time instead of hidden under it.  Spreading the start of the
-    // first generation uniformly over one tile period smooths the HBM demand; later workgroups inherit the spread
-    // because each starts when a predecessor retires.
-    if (p.stagger && blockIdx.x < 512) {
-        const int slot = (blockIdx.x * 7 + (blockIdx.x >> 8) * 8) & 15;
-        const int naps = (nk * 9 * slot) >> 7;
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-
     const bool fast = p.fastA && p.fastB && !a_lower && (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n) && ((kend - kbeg) % GEMM_BK == 0);
     if (fast) gemm_mainloop<A_KC, B_KC, true>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
     else gemm_mainloop<A_KC, B_KC, false>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
@@ -313,11 +300,6 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     p.fastA = gpar_aligned16(A) && (lda % 2 == 0);
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
     p.stamps = nullptr;
-    {
-        static int stagger_env = -1;
-        if (stagger_env < 0) { const char* e = getenv("GPAR_GEMM_STAGGER"); stagger_env = e ? atoi(e) : 1; }
-        p.stagger = stagger_env;
-    }
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
     static bool attr_done = false;
     if (!attr_done) {
