@@ -203,6 +203,19 @@ class GP:
             return torch.zeros(x.shape[0], 1, dtype=torch.float64, device=x.device)
         return self._obs.posterior_mean(x)
 
+    def sample_batch(self, xs, noise=None):
+        """One draw of f (+ noise) at each input set in `xs` (a list of n* x D matrices, e.g. the per-sample design
+        matrices of ancestral sampling): returns an n* x len(xs) matrix.  For a dense posterior the expensive step -
+        V_s = K(x_s, X) L^-T for every s - is ONE stacked triangular solve instead of len(xs) separate ones."""
+        if self.is_posterior and isinstance(self._obs, Obs):
+            return self._obs.posterior_sample_batch(self, xs, noise)
+        return torch.cat([self(x_s, noise).sample() for x_s in xs], dim=1)
+
+    def mean_batch(self, xs):
+        if self.is_posterior and isinstance(self._obs, Obs) and len(xs) > 1:
+            return self._obs.posterior_mean_batch(xs)
+        return [self.mean(x_s) for x_s in xs]
+
     # convenience used by tests / examples
     def marginals(self, x):
         return self(x).marginals()
@@ -364,6 +377,55 @@ class Obs:
             return torch.zeros(x.shape[0], 1, dtype=torch.float64, device=x.device)
         _, _, Ks = self._cross(x)
         return self.eng.gemm(Ks, fac.alpha(), tb=True)
+
+    def posterior_mean_batch(self, xs):
+        """Posterior means at several input sets with one stacked cross-Gram product."""
+        eng, fac = self.eng, self.factor()
+        ck, z = self.fdd.features()
+        sizes = [int(x_s.shape[0]) for x_s in xs]
+        if self.fdd.n == 0:
+            return [torch.zeros(k, 1, dtype=torch.float64, device=z.device) for k in sizes]
+        B = eng.new_matrix(sum(sizes), self.fdd.n)
+        r = 0
+        for x_s, k in zip(xs, sizes):
+            eng.gram(ck, eng.features(ck, _as_matrix(eng, x_s)), z, out=B[r : r + k])
+            r += k
+        means = eng.gemm(B, fac.alpha(), tb=True)
+        return list(torch.split(means, sizes, dim=0))
+
+    def posterior_sample_batch(self, gp, xs, noise):
+        eng, fac = self.eng, self.factor()
+        ck, z = self.fdd.features()
+        n, S = self.fdd.n, len(xs)
+        ns = int(xs[0].shape[0])
+        out = torch.empty(ns, S, dtype=torch.float64, device=z.device)
+        if ns == 0:
+            return out
+        noise_vec = _noise_vector(eng, noise, ns)
+        zr = eng.randn(ns, S)
+        # bound the stacked right-hand side (S n* x n doubles) to ~16 GB of the 288 GB HBM
+        chunk = max(1, int(16e9 // max(1, ns * max(n, 1) * 8)))
+        for s0 in range(0, S, chunk):
+            s1 = min(S, s0 + chunk)
+            zss = [eng.features(ck, _as_matrix(eng, xs[s])) for s in range(s0, s1)]
+            B = eng.new_matrix((s1 - s0) * ns, max(n, 1))
+            if n > 0:
+                for k, zs in enumerate(zss):
+                    eng.gram(ck, zs, z, out=B[k * ns : (k + 1) * ns])
+                eng.trsm_rlt_(fac.L, B)  # every V_s = K(x_s, X) L^-T in one solve
+                means = eng.gemm(B, fac.zrow, tb=True)
+            for k, zs in enumerate(zss):
+                cov = eng.new_matrix(ns, ns)
+                eng.gram(ck, zs, lower=True, diag_add=noise_vec, diag_const=eng.epsilon, out=cov)
+                mean = 0.0
+                if n > 0:
+                    V = B[k * ns : (k + 1) * ns]
+                    eng.gemm(V, V, tb=True, alpha=-1.0, beta=1.0, out=cov, c_lower=True)
+                    mean = means[k * ns : (k + 1) * ns]
+                _, info = eng.potrf_(cov)
+                eng.check_info(info)
+                out[:, s0 + k : s0 + k + 1] = eng.gemm(cov, zr[:, s0 + k : s0 + k + 1], a_lower=True) + mean
+        return out
 
     def posterior_moments(self, fdd, block, jitter):
         """Lower triangle of K_** - V V^T + diag(noise*) + jitter I into `block`; returns the mean."""

@@ -199,8 +199,46 @@ class GPAR:
         return torch.cat(columns, dim=1)
 
     def sample_many(self, x, w, num_samples, latent=False):
-        """`num_samples` independent ancestral samples (the loop of reference regression.py:559-563)."""
-        return [self.sample(x, w, latent=latent) for _ in range(num_samples)]
+        """`num_samples` independent ancestral samples (the loop of reference regression.py:559-563), computed layer by
+        layer for all samples at once.  While every sample still sees the same design matrix (always at layer 0;
+        at every layer when `replace` feeds posterior means forward) one factorisation serves all draws; once the
+        inputs differ per sample, the per-sample cross-covariances are stacked into one triangular solve."""
+        if num_samples == 1:
+            return [self.sample(x, w, latent=latent)]
+        eng = get_engine()
+        x = eng.tensor(x)
+        if x.dim() == 1:
+            x = x[:, None]
+        w = eng.tensor(w)
+        S, ns = num_samples, x.shape[0]
+        x_ind = self._prep_ind(self.x_ind)
+        shared, xs = True, None
+        columns = []  # per layer: n* x S
+        for i, (is_last, model) in enumerate(last(self.layers)):
+            f, noise = model()
+            obs_noise = None if latent else self._noise_over(noise, w[:, i])
+            draws = f(x, obs_noise).sample(num=S) if shared else f.sample_batch(xs, obs_noise)
+            columns.append(draws)
+            if is_last:
+                break
+            if latent:
+                fed = draws + torch.sqrt(self._noise_over(noise, w[:, i : i + 1])) * eng.randn(ns, S)
+            else:
+                fed = draws
+            if self.sparse:
+                x_ind = torch.cat([x_ind, f.mean(x_ind)], dim=1)
+            if self.replace:
+                # the sampled values are replaced by the (posterior) mean at the current inputs
+                if shared:
+                    x = torch.cat([x, f.mean(x)], dim=1)
+                else:
+                    xs = [torch.cat([x_s, m_s], dim=1) for x_s, m_s in zip(xs, f.mean_batch(xs))]
+            elif shared:
+                xs = [torch.cat([x, fed[:, s : s + 1]], dim=1) for s in range(S)]
+                shared = False
+            else:
+                xs = [torch.cat([x_s, fed[:, s : s + 1]], dim=1) for s, x_s in enumerate(xs)]
+        return [torch.stack([c[:, s] for c in columns], dim=1) for s in range(S)]
 
     # ---- helpers -----------------------------------------------------------------------------------
     @staticmethod

@@ -285,3 +285,26 @@ def test_sparse_regressor_runs_end_to_end(engine):
     reg.condition(x, y)
     mean = reg.predict(x, num_samples=30)
     assert mean.shape == (40, 2) and np.sqrt(np.mean((mean - y) ** 2)) < 0.3
+
+
+@pytest.mark.parametrize("kw", [dict(replace=False), dict(replace=True), dict(replace=False, x_ind=np.linspace(0, 1, 9))])
+def test_batched_sampling_agrees_with_sequential_sampling(engine, kw):
+    """`sample(num_samples=S)` draws all samples layer by layer (shared factorisations, stacked triangular solves);
+    its first two moments must agree with S independent calls of the one-sample ancestral loop."""
+    from gpar_amd.regression import _construct_gpar
+
+    rng = np.random.default_rng(17)
+    x = np.sort(rng.random(14))
+    y = np.stack([np.sin(5 * x), np.sin(5 * x) ** 2, x + np.cos(5 * x)], axis=1) + 0.05 * rng.standard_normal((14, 3))
+    xs = np.linspace(0.05, 0.95, 6)
+    reg = GPARRegressor(scale=0.3, linear=True, nonlinear=True, noise=0.05, normalise_y=False, **kw)
+    reg.condition(x, y)
+    S = 300
+    batched = np.stack(reg.sample(xs, posterior=True, num_samples=S, latent=True))
+    gpar = _construct_gpar(reg, reg.vs, 1, 3) | (reg.x, reg.y, reg.w)
+    w = np.ones((6, 3))
+    sequential = np.stack([to_np(gpar.sample(xs, w, latent=True)) for _ in range(S)])
+    assert batched.shape == sequential.shape == (S, 6, 3)
+    scale = sequential.std(axis=0) + 0.02
+    assert np.all(np.abs(batched.mean(axis=0) - sequential.mean(axis=0)) < 4 * scale / np.sqrt(S) * 2)
+    assert np.all(np.abs(batched.std(axis=0) - sequential.std(axis=0)) < 0.35 * scale)
