@@ -3,6 +3,7 @@
 #include "common.h"
 #include "gemm_f64.h"
 #include "potrf.h"
+#include "panel.h"
 #include "gram.h"
 
 namespace gpar {

@@ -1,0 +1,343 @@
+// Fused panel factorisation: ONE persistent launch factors a whole W-column panel (W = 64 * S, S <= 8) for all
+// rows below it, instead of S x {diag kernel, strip kernel, rank-64 GEMM} = 3 S dependent launches.
+//
+// Why: the blocked Cholesky's critical path is the chain  diag(s) -> strip(s) -> update(s) -> diag(s+1) ...; as
+// separate kernels each link costs a launch boundary plus two or three cold memory round trips (26 + 21 + ~40 us
+// per 64 columns, profiles/r01_bench_kernel_stats.txt), 21 of the 48 ms of an n = 16384 factorisation.  Here the
+// links are in-launch hand-offs between workgroups.
+//
+// Decomposition: 64-row blocks; workgroup g owns row blocks g, g + G, ... (G = grid size <= resident capacity, so
+// every workgroup is resident and spinning is safe; every spin is bounded and reports through `info`).
+// For step s (column block s):
+//   * the owner of row block s factors the 64 x 64 diagonal block (blocked left-looking Cholesky, one wave) and
+//     publishes it (flag1[s]);
+//   * every workgroup, for each of its row blocks rb > s: waits for flag1[s], solves its 64 rows against L_ss
+//     (blocked substitution, one wave), writes X = L[rb][s], publishes it if rb < S (flag2[s][rb]: those rows are
+//     the B operands of everybody's updates), then applies  A[rb][c] -= X L[c][s]^T  for c = s+1 .. min(rb, S-1)
+//     on the matrix cores (v_mfma_f64_4x4x4_4b; X and L[c][s] in LDS, C read-modify-written in global memory).
+// Hand-offs follow the agent-scope release / acquire recipe (cdna_hip_programming.md Guideline 16): plain stores ->
+// every wave drains vmcnt -> barrier -> one lane: release fence + asm vmcnt(0) + relaxed agent-scope flag store;
+// consumer: one lane polls relaxed, one acquire fence, barrier, plain loads.  The flag words live in the strict
+// upper triangle of the panel's diagonal block (scratch by the ABI's convention) and are zeroed by a memset node
+// on the stream before every launch.
+#pragma once
+#include "common.h"
+#include "potrf.h"
+
+namespace gpar {
+
+constexpr int PNL_LD = 66;
+constexpr int PNL_TILE = 64 * PNL_LD;                  // doubles
+constexpr int PNL_LDS_BYTES = 3 * PNL_TILE * 8 + 512;  // Cs/T, Xs, Bs + reciprocal pivots
+constexpr int PNL_FLAG_SLOTS = 56;                     // usable scratch words per row of the diagonal block
+constexpr unsigned PNL_SPIN_LIMIT = 1u << 22;
+
+struct PanelArgs {
+    double* A;
+    int N, lda, k0, S;   // panel columns [k0, k0 + 64 S)
+    double* logdet;
+    int* info;
+};
+
+__device__ __forceinline__ unsigned long long* pnl_flag(const PanelArgs& p, int f) {
+    // flag f lives at A[k0 + f / 56][k0 + 8 + f % 56]: strictly above the diagonal
+    return reinterpret_cast<unsigned long long*>(p.A + (size_t)(p.k0 + f / PNL_FLAG_SLOTS) * p.lda + p.k0 + 8 + f % PNL_FLAG_SLOTS);
+}
+
+// All threads of the workgroup have issued plain stores; make them visible, then raise the flag.
+__device__ __forceinline__ void pnl_publish(const PanelArgs& p, int f) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(pnl_flag(p, f), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Returns after flag f is set and this CU's stale lines are dropped.  Bounded: on timeout the error is recorded and
+// the kernel carries on (results are garbage, info says so) - it never hangs.
+__device__ __forceinline__ void pnl_wait(const PanelArgs& p, int f) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(pnl_flag(p, f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > PNL_SPIN_LIMIT) {
+                if (p.info) atomicCAS(p.info, 0, -77);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// 64 x 64 tile: global (rows r0.., cols c0.., clamped to valid rows) -> LDS [64][PNL_LD]; 256 threads, 16-byte loads.
+__device__ __forceinline__ void pnl_load_tile(const PanelArgs& p, int r0, int c0, double* __restrict__ dst, int t) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = t + 256 * q;          // 2048 chunks of 2 doubles
+        const int r = c >> 5, cc = (c & 31) * 2;
+        const int rr = min(r0 + r, p.N - 1);
+        v[q] = *reinterpret_cast<const d2*>(p.A + (size_t)rr * p.lda + c0 + cc);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = t + 256 * q;
+        const int r = c >> 5, cc = (c & 31) * 2;
+        *reinterpret_cast<d2*>(dst + r * PNL_LD + cc) = v[q];
+    }
+}
+
+// LDS tile -> global; `lower_only`: store only entries with col <= row (diagonal block); rows beyond N are skipped.
+__device__ __forceinline__ void pnl_store_tile(const PanelArgs& p, int r0, int c0, const double* __restrict__ src, int t,
+                                               bool lower_only) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = t + 256 * q;          // 4096 elements
+        const int r = e >> 6, c = e & 63;
+        if (r0 + r < p.N && (!lower_only || c <= r)) p.A[(size_t)(r0 + r) * p.lda + c0 + c] = src[r * PNL_LD + c];
+    }
+}
+
+// Blocked left-looking Cholesky of the 64 x 64 tile T (lower), executed by wave 0; all waves take the barriers.
+__device__ __forceinline__ void pnl_diag(double* __restrict__ T, int col0, const PanelArgs& p, int t) {
+    const int i = t;   // lane = row (wave 0 only)
+    double mydiag = 1.0;
+    int bad = 0;
+    for (int jb = 0; jb < 8; ++jb) {
+        if (t < 64) {
+            double acc[8];
+            const pan_d2* src = reinterpret_cast<const pan_d2*>(&T[i * PNL_LD + 8 * jb]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
+            for (int kb = 0; kb < jb; ++kb) {
+                double mine[8];
+                const pan_d2* ms = reinterpret_cast<const pan_d2*>(&T[i * PNL_LD + 8 * kb]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const pan_d2 v = ms[q]; mine[2 * q] = v[0]; mine[2 * q + 1] = v[1]; }
+                pan_d2 c[8][4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const pan_d2* cs = reinterpret_cast<const pan_d2*>(&T[(8 * jb + j) * PNL_LD + 8 * kb]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) c[j][q] = cs[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fma(-mine[2 * q], c[j][q][0], acc[j]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fma(-mine[2 * q + 1], c[j][q][1], acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = 8 * jb + j;
+                const double d = gpar_readlane_f64(acc[j], col);
+                if (!(d > 0.0) && bad == 0) bad = col0 + col + 1;
+                const double sd = sqrt(d);
+                const double rinv = 1.0 / sd;
+                const double lij = (i == col) ? sd : acc[j] * rinv;
+                if (i == col) mydiag = sd;
+                acc[j] = lij;
+#pragma unroll
+                for (int j2 = j + 1; j2 < 8; ++j2) acc[j2] = fma(-lij, gpar_readlane_f64(lij, 8 * jb + j2), acc[j2]);
+            }
+            pan_d2* dst = reinterpret_cast<pan_d2*>(&T[i * PNL_LD + 8 * jb]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
+        }
+        __syncthreads();
+    }
+    if (t < 64) {
+        double ld = 2.0 * log(mydiag);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ld += __shfl_xor(ld, off, 64);
+        if (t == 0) {
+            if (p.logdet) atomicAdd(p.logdet, ld);
+            if (bad && p.info) atomicCAS(p.info, 0, bad);
+        }
+    }
+}
+
+// X L^T = B for the 64 rows in Xs against the lower-triangular tile Cs (blocked substitution, wave 0).
+__device__ __forceinline__ void pnl_strip(const double* __restrict__ Cs, double* __restrict__ Xs, const double* __restrict__ rinvs, int t) {
+    if (t >= 64) return;
+    const int lane = t;
+    for (int jb = 0; jb < 8; ++jb) {
+        double acc[8];
+        const pan_d2* src = reinterpret_cast<const pan_d2*>(&Xs[lane * PNL_LD + 8 * jb]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
+        for (int kb = 0; kb < jb; ++kb) {
+            double xk[8];
+            const pan_d2* xs = reinterpret_cast<const pan_d2*>(&Xs[lane * PNL_LD + 8 * kb]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const pan_d2 v = xs[q]; xk[2 * q] = v[0]; xk[2 * q + 1] = v[1]; }
+            pan_d2 c[8][4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const pan_d2* cs = reinterpret_cast<const pan_d2*>(&Cs[(8 * jb + j) * PNL_LD + 8 * kb]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c[j][q] = cs[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fma(-xk[2 * q], c[j][q][0], acc[j]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fma(-xk[2 * q + 1], c[j][q][1], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double* crow = &Cs[(8 * jb + j) * PNL_LD + 8 * jb];
+            double sacc = acc[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sacc = fma(-acc[k], crow[k], sacc);
+            acc[j] = sacc * rinvs[8 * jb + j];
+        }
+        pan_d2* dst = reinterpret_cast<pan_d2*>(&Xs[lane * PNL_LD + 8 * jb]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
+    }
+}
+
+// C (64 x 64 block at rows r0, cols c0 of A) -= Xs Bs^T, both LDS tiles [64][PNL_LD] with k contiguous.
+// Wave w owns rows 16 w .. 16 w + 15 (4 row patches) x all 64 columns (4 column patches): 16 accumulators.
+__device__ __forceinline__ void pnl_update(const PanelArgs& p, int r0, int c0, const double* __restrict__ Xs,
+                                           const double* __restrict__ Bs, int t, bool lower_only) {
+    const int lane = t & 63, w = t >> 6;
+    const int l3 = lane & 3, l15 = lane & 15, lk = lane >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll 4
+    for (int k4 = 0; k4 < 16; ++k4) {
+        const int kk = 4 * k4 + lk;
+        double pf[4], qf[4];
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) qf[nj] = Bs[(16 * nj + l15) * PNL_LD + kk];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) pf[mi] = Xs[(16 * w + 4 * mi + l3) * PNL_LD + kk];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_4x4x4f64(qf[nj], pf[mi], acc[mi][nj], 0, 0, 0);
+    }
+    const int colb = c0 + 4 * ((lane >> 2) & 3) + lk;
+    double cv[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int row = min(r0 + 16 * w + 4 * mi + l3, p.N - 1);
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) cv[mi][nj] = p.A[(size_t)row * p.lda + colb + 16 * nj];
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int rloc = 16 * w + 4 * mi + l3;
+        const int row = r0 + rloc;
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const int cloc = 16 * nj + 4 * ((lane >> 2) & 3) + lk;
+            if (row < p.N && (!lower_only || cloc <= rloc)) p.A[(size_t)row * p.lda + colb + 16 * nj] = cv[mi][nj] - acc[mi][nj];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    double* Cs = psm;                    // L_ss (strip coefficients) / diagonal work tile
+    double* Xs = psm + PNL_TILE;         // this row block's X
+    double* Bs = psm + 2 * PNL_TILE;     // L[c][s] operand of the update
+    double* rinvs = psm + 3 * PNL_TILE;  // reciprocal pivots of L_ss
+    const int t = threadIdx.x;
+    const int G = gridDim.x, g = blockIdx.x;
+    const int R = (p.N - p.k0 + 63) / 64;   // row blocks below (and including) the panel's first row
+    const int S = p.S;
+
+    for (int s = 0; s < S; ++s) {
+        const int cs = p.k0 + 64 * s;       // first column of column block s; row block s starts at the same index
+        if (s % G == g) {
+            // ---- owner of the diagonal block
+            pnl_load_tile(p, cs, cs, Cs, t);
+            __syncthreads();
+            pnl_diag(Cs, cs, p, t);
+            pnl_store_tile(p, cs, cs, Cs, t, true);
+            pnl_publish(p, s);
+        }
+        bool have_lss = false;
+        int first = s + 1;                  // first owned row block above s
+        first += ((g - first) % G + G) % G;
+        for (int rb = first; rb < R; rb += G) {
+            const int r0 = p.k0 + 64 * rb;
+            if (!have_lss) {
+                pnl_wait(p, s);
+                pnl_load_tile(p, cs, cs, Cs, t);
+                have_lss = true;
+            }
+            __syncthreads();                // previous iteration done with Xs / Bs
+            pnl_load_tile(p, r0, cs, Xs, t);
+            __syncthreads();
+            if (t < 64) rinvs[t] = 1.0 / Cs[t * PNL_LD + t];
+            __syncthreads();
+            pnl_strip(Cs, Xs, rinvs, t);
+            __syncthreads();
+            pnl_store_tile(p, r0, cs, Xs, t, false);
+            if (rb < S) pnl_publish(p, 8 + s * 8 + rb);
+            const int cmax = rb < S - 1 ? rb : S - 1;
+            for (int c = s + 1; c <= cmax; ++c) {
+                const double* Bt = Xs;
+                if (c != rb) {
+                    __syncthreads();        // earlier update done with Bs
+                    pnl_wait(p, 8 + s * 8 + c);
+                    pnl_load_tile(p, p.k0 + 64 * c, cs, Bs, t);
+                    __syncthreads();
+                    Bt = Bs;
+                }
+                pnl_update(p, r0, p.k0 + 64 * c, Xs, Bt, t, c == rb);
+            }
+        }
+        // a workgroup that owns the next diagonal block must see its own updates of that block: same CU, plain
+        // stores then plain loads through the same L1/L2 -> ordered by the vmcnt drain + barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// Number of workgroups that can be co-resident (1 per CU at this LDS size): queried once.
+static int panel_grid_cap() {
+    static int cap = -1;
+    if (cap < 0) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceProp_t prop;
+        cap = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 64;
+        if (cap < 1) cap = 1;
+    }
+    return cap;
+}
+
+static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream) {
+    PanelArgs p{A, N, lda, k0, W / 64, logdet, info};
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS_BYTES);
+        attr_done = true;
+    }
+    // zero the flag words (two scratch rows in the strict upper triangle of the first diagonal block)
+    hipMemsetAsync(A + (size_t)k0 * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream);
+    hipMemsetAsync(A + (size_t)(k0 + 1) * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream);
+    const int R = (N - k0 + 63) / 64;
+    int G = R < panel_grid_cap() ? R : panel_grid_cap();
+    hipLaunchKernelGGL(potrf_panel_kernel, dim3(G), dim3(256), PNL_LDS_BYTES, stream, p);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace gpar

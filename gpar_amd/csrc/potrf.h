@@ -239,6 +239,7 @@ struct PotrfPolicy {
     int nbm;        // mid-level width inside a panel
     int lookahead;  // overlap panel k+1 with the trailing update of panel k on a second stream
     int split;      // factor the diagonal block first, then solve the rows below (see potrf_panel_split)
+    int fused;      // factor each top-level panel with the persistent fused kernel (panel.h)
 };
 
 static int env_int(const char* name, int dflt) {
@@ -250,7 +251,11 @@ static PotrfPolicy potrf_policy(int N) {
     PotrfPolicy p;
     // wider top-level panels amortise the read-modify-write of the trailing matrix over more flops (measured SYRK
     // rate at n = 16384: K = 128 31, K = 256 42, K = 512 53 TFLOP/s); the panel itself is factored recursively
-    if (N >= 12288) p.nbo = 512;
+    // with the fused panel kernel (panel.h) the panel is cheap, so the widest panel it supports wins at every size
+    // (measured n = 1024 .. 16384, profiles/r01_potrf_nbo_sweep.txt); the unfused fallback prefers narrower ones
+    p.fused = env_int("GPAR_POTRF_FUSED", 1);
+    if (p.fused) p.nbo = 512;
+    else if (N >= 12288) p.nbo = 512;
     else if (N >= 6144) p.nbo = 256;
     else if (N >= 1536) p.nbo = 128;
     else p.nbo = 64;
@@ -323,6 +328,9 @@ static int potrf_panel_split(const PotrfCtx& c, int k0, int kend, int nb, hipStr
     return rc;
 }
 
+// defined in panel.h (one persistent launch per panel)
+static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream);
+
 struct LookaheadState {
     hipStream_t side = nullptr;
     static constexpr int MAXE = 1024;
@@ -377,9 +385,15 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     const int nbo = pol.nbo;
     const bool la = pol.lookahead && nf > nbo && la_init();
     hipEvent_t trail_done = nullptr;   // completion of the side-stream update issued in the previous step
-    for (int k0 = 0; k0 < nf; k0 += nbo) {
-        const int kend = (k0 + nbo < nf) ? k0 + nbo : nf;
-        int rc = pol.split ? potrf_panel_split(c, k0, kend, nbo, stream) : potrf_panel(c, k0, kend, nbo, stream);
+    for (int k0 = 0, knext = 0; k0 < nf; k0 = knext) {
+        int kend = (k0 + nbo < nf) ? k0 + nbo : nf;
+        // a ragged tail (nf not a multiple of 64) becomes its own narrow panel so the wide part stays fusable
+        if (pol.fused && (kend - k0) > 64 && (kend - k0) % 64 != 0) kend = k0 + (kend - k0) / 64 * 64;
+        knext = kend;
+        const int w = kend - k0;
+        const bool fused_ok = pol.fused && w % 64 == 0 && w <= 512 && N - k0 >= 64 && (k0 % 2 == 0) && (lda % 2 == 0) && gpar_aligned16(A);
+        int rc = fused_ok ? potrf_panel_fused(A, N, lda, k0, w, logdet, info, stream)
+                          : (pol.split ? potrf_panel_split(c, k0, kend, nbo, stream) : potrf_panel(c, k0, kend, nbo, stream));
         if (rc) return rc;
         if (kend >= N) break;
         const int next_end = (kend + nbo < nf) ? kend + nbo : nf;   // columns of the next panel: [kend, next_end)

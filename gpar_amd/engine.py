@@ -136,6 +136,8 @@ class HipEngine:
     def check_info(info):
         """Synchronise on the device-side LAPACK-style info word and raise if a pivot failed."""
         code = int(info.item())
+        if code < 0:
+            raise RuntimeError(f"gpar_potrf: device-side hand-off timed out (code {code}); is another kernel holding the CUs?")
         if code != 0:
             raise NotPositiveDefiniteError(code)
 
