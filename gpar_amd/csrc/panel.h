@@ -37,6 +37,7 @@ struct PanelArgs {
     int N, lda, k0, S;   // panel columns [k0, k0 + 64 S)
     double* logdet;
     int* info;
+    long long* stamps;   // dev aid (tools/time_panel.hip): cycle stamps of the critical chain, normally null
 };
 
 __device__ __forceinline__ unsigned long long* pnl_flag(const PanelArgs& p, int f) {
@@ -44,15 +45,14 @@ __device__ __forceinline__ unsigned long long* pnl_flag(const PanelArgs& p, int 
     return reinterpret_cast<unsigned long long*>(p.A + (size_t)(p.k0 + f / PNL_FLAG_SLOTS) * p.lda + p.k0 + 8 + f % PNL_FLAG_SLOTS);
 }
 
-// All threads of the workgroup have issued plain stores; make them visible, then raise the flag.
+// All threads of the workgroup have issued WRITE-THROUGH (sc1) stores of the payload (pnl_store_tile with
+// `publish`): every wave drains them, then one lane raises the flag.  No release fence is needed (recipe R1): a
+// 32 KB tile published with plain stores + buffer_wbl2 costs ~6 us per hand-off, two of which sit on the
+// critical path of every 64-column step.
 __device__ __forceinline__ void pnl_publish(const PanelArgs& p, int f) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(pnl_flag(p, f), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(pnl_flag(p, f), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Returns after flag f is set and this CU's stale lines are dropped.  Bounded: on timeout the error is recorded and
@@ -92,17 +92,51 @@ __device__ __forceinline__ void pnl_load_tile(const PanelArgs& p, int r0, int c0
 }
 
 // LDS tile -> global; `lower_only`: store only entries with col <= row (diagonal block); rows beyond N are skipped.
+// `publish`: the tile will be handed to other workgroups -> relaxed agent-scope atomic stores (global_store ... sc1,
+// write-through to memory) instead of plain stores.
 __device__ __forceinline__ void pnl_store_tile(const PanelArgs& p, int r0, int c0, const double* __restrict__ src, int t,
-                                               bool lower_only) {
+                                               bool lower_only, bool publish) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int e = t + 256 * q;          // 4096 elements
         const int r = e >> 6, c = e & 63;
-        if (r0 + r < p.N && (!lower_only || c <= r)) p.A[(size_t)(r0 + r) * p.lda + c0 + c] = src[r * PNL_LD + c];
+        if (r0 + r < p.N && (!lower_only || c <= r)) {
+            double* dst = p.A + (size_t)(r0 + r) * p.lda + c0 + c;
+            if (publish)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(src[r * PNL_LD + c]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                *dst = src[r * PNL_LD + c];
+        }
     }
 }
 
-// Blocked left-looking Cholesky of the 64 x 64 tile T (lower), executed by wave 0; all waves take the barriers.
+// Rank-8 right-looking update shared by the diagonal factorisation and the strip solve, all four waves:
+//   D[i][k] -= sum_{j<8} D[i][8 jb + j] * Cf[k][8 jb + j]      for k = 8 jb + 8 .. 63 (wave w takes k = w mod 4),
+// lane i = row.  The row's own 8 values are one lane-private read; the 8 coefficients of column k are a
+// wave-uniform broadcast read.
+__device__ __forceinline__ void pnl_rank8(double* __restrict__ D, const double* __restrict__ Cf, int jb, int t) {
+    const int i = t & 63, w = t >> 6;
+    double mine[8];
+    const pan_d2* ms = reinterpret_cast<const pan_d2*>(&D[i * PNL_LD + 8 * jb]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const pan_d2 v = ms[q]; mine[2 * q] = v[0]; mine[2 * q + 1] = v[1]; }
+#pragma unroll 2
+    for (int k = 8 * jb + 8 + w; k < 64; k += 4) {
+        const pan_d2* cs = reinterpret_cast<const pan_d2*>(&Cf[k * PNL_LD + 8 * jb]);
+        const pan_d2 c0 = cs[0], c1 = cs[1], c2 = cs[2], c3 = cs[3];
+        double v0 = D[i * PNL_LD + k], v1 = 0.0;
+        v0 = fma(-mine[0], c0[0], v0); v1 = fma(-mine[1], c0[1], v1);
+        v0 = fma(-mine[2], c1[0], v0); v1 = fma(-mine[3], c1[1], v1);
+        v0 = fma(-mine[4], c2[0], v0); v1 = fma(-mine[5], c2[1], v1);
+        v0 = fma(-mine[6], c3[0], v0); v1 = fma(-mine[7], c3[1], v1);
+        D[i * PNL_LD + k] = v0 + v1;
+    }
+}
+
+// Right-looking Cholesky of the 64 x 64 tile T (lower) in 8-column blocks: wave 0 (lane = row) factors the block
+// (pivots broadcast by v_readlane, reciprocal pivots by v_rsq_f64 + Newton), then all four waves apply the
+// rank-8 update to the columns to the right.  All waves take every barrier.
 __device__ __forceinline__ void pnl_diag(double* __restrict__ T, int col0, const PanelArgs& p, int t) {
     const int i = t;   // lane = row (wave 0 only)
     double mydiag = 1.0;
@@ -113,33 +147,18 @@ __device__ __forceinline__ void pnl_diag(double* __restrict__ T, int col0, const
             const pan_d2* src = reinterpret_cast<const pan_d2*>(&T[i * PNL_LD + 8 * jb]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
-            for (int kb = 0; kb < jb; ++kb) {
-                double mine[8];
-                const pan_d2* ms = reinterpret_cast<const pan_d2*>(&T[i * PNL_LD + 8 * kb]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { const pan_d2 v = ms[q]; mine[2 * q] = v[0]; mine[2 * q + 1] = v[1]; }
-                pan_d2 c[8][4];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const pan_d2* cs = reinterpret_cast<const pan_d2*>(&T[(8 * jb + j) * PNL_LD + 8 * kb]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) c[j][q] = cs[q];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fma(-mine[2 * q], c[j][q][0], acc[j]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fma(-mine[2 * q + 1], c[j][q][1], acc[j]);
-                }
-            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int col = 8 * jb + j;
                 const double d = gpar_readlane_f64(acc[j], col);
                 if (!(d > 0.0) && bad == 0) bad = col0 + col + 1;
-                const double sd = sqrt(d);
-                const double rinv = 1.0 / sd;
+                // pivot: rinv = d^-1/2 by v_rsq_f64 + two Newton steps, sd = d * rinv with one correction (the
+                // library sqrt + divide are ~50 dependent fp64 instructions on this serial chain); 1 ulp agreement
+                double rinv = __builtin_amdgcn_rsq(d);
+                rinv = rinv * fma(-0.5 * d * rinv, rinv, 1.5);
+                rinv = rinv * fma(-0.5 * d * rinv, rinv, 1.5);
+                double sd = d * rinv;
+                sd = fma(fma(-sd, sd, d), 0.5 * rinv, sd);
                 const double lij = (i == col) ? sd : acc[j] * rinv;
                 if (i == col) mydiag = sd;
                 acc[j] = lij;
@@ -151,6 +170,10 @@ __device__ __forceinline__ void pnl_diag(double* __restrict__ T, int col0, const
             for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
         }
         __syncthreads();
+        if (jb < 7) {
+            pnl_rank8(T, T, jb, t);
+            __syncthreads();
+        }
     }
     if (t < 64) {
         double ld = 2.0 * log(mydiag);
@@ -163,46 +186,34 @@ __device__ __forceinline__ void pnl_diag(double* __restrict__ T, int col0, const
     }
 }
 
-// X L^T = B for the 64 rows in Xs against the lower-triangular tile Cs (blocked substitution, wave 0).
+// X L^T = B for the 64 rows in Xs against the lower-triangular tile Cs, right-looking in 8-column blocks: wave 0
+// solves the 8 x 8 diagonal part for every row (lane = row), then all four waves eliminate the solved columns
+// from the remaining ones.  All waves take every barrier.
 __device__ __forceinline__ void pnl_strip(const double* __restrict__ Cs, double* __restrict__ Xs, const double* __restrict__ rinvs, int t) {
-    if (t >= 64) return;
-    const int lane = t;
     for (int jb = 0; jb < 8; ++jb) {
-        double acc[8];
-        const pan_d2* src = reinterpret_cast<const pan_d2*>(&Xs[lane * PNL_LD + 8 * jb]);
+        if (t < 64) {
+            const int lane = t;
+            double acc[8];
+            const pan_d2* src = reinterpret_cast<const pan_d2*>(&Xs[lane * PNL_LD + 8 * jb]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
-        for (int kb = 0; kb < jb; ++kb) {
-            double xk[8];
-            const pan_d2* xs = reinterpret_cast<const pan_d2*>(&Xs[lane * PNL_LD + 8 * kb]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const pan_d2 v = xs[q]; xk[2 * q] = v[0]; xk[2 * q + 1] = v[1]; }
-            pan_d2 c[8][4];
+            for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const pan_d2* cs = reinterpret_cast<const pan_d2*>(&Cs[(8 * jb + j) * PNL_LD + 8 * kb]);
+                const double* crow = &Cs[(8 * jb + j) * PNL_LD + 8 * jb];
+                double sacc = acc[j];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) c[j][q] = cs[q];
+                for (int k = 0; k < j; ++k) sacc = fma(-acc[k], crow[k], sacc);
+                acc[j] = sacc * rinvs[8 * jb + j];
             }
+            pan_d2* dst = reinterpret_cast<pan_d2*>(&Xs[lane * PNL_LD + 8 * jb]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fma(-xk[2 * q], c[j][q][0], acc[j]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fma(-xk[2 * q + 1], c[j][q][1], acc[j]);
-            }
+            for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double* crow = &Cs[(8 * jb + j) * PNL_LD + 8 * jb];
-            double sacc = acc[j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) sacc = fma(-acc[k], crow[k], sacc);
-            acc[j] = sacc * rinvs[8 * jb + j];
+        __syncthreads();
+        if (jb < 7) {
+            pnl_rank8(Xs, Cs, jb, t);
+            __syncthreads();
         }
-        pan_d2* dst = reinterpret_cast<pan_d2*>(&Xs[lane * PNL_LD + 8 * jb]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
     }
 }
 
@@ -212,6 +223,15 @@ __device__ __forceinline__ void pnl_update(const PanelArgs& p, int r0, int c0, c
                                            const double* __restrict__ Bs, int t, bool lower_only) {
     const int lane = t & 63, w = t >> 6;
     const int l3 = lane & 3, l15 = lane & 15, lk = lane >> 4;
+    // the 16 C values of this lane are requested first so their memory latency runs under the MFMA loop
+    const int colb = c0 + 4 * ((lane >> 2) & 3) + lk;
+    double cv[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int row = min(r0 + 16 * w + 4 * mi + l3, p.N - 1);
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) cv[mi][nj] = p.A[(size_t)row * p.lda + colb + 16 * nj];
+    }
     double acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -229,14 +249,6 @@ __device__ __forceinline__ void pnl_update(const PanelArgs& p, int r0, int c0, c
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_4x4x4f64(qf[nj], pf[mi], acc[mi][nj], 0, 0, 0);
-    }
-    const int colb = c0 + 4 * ((lane >> 2) & 3) + lk;
-    double cv[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int row = min(r0 + 16 * w + 4 * mi + l3, p.N - 1);
-#pragma unroll
-        for (int nj = 0; nj < 4; ++nj) cv[mi][nj] = p.A[(size_t)row * p.lda + colb + 16 * nj];
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -265,19 +277,26 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
         const int cs = p.k0 + 64 * s;       // first column of column block s; row block s starts at the same index
         if (s % G == g) {
             // ---- owner of the diagonal block
+            if (p.stamps && t == 0) p.stamps[s * 8 + 0] = (long long)__builtin_readcyclecounter();
             pnl_load_tile(p, cs, cs, Cs, t);
             __syncthreads();
+            if (p.stamps && t == 0) p.stamps[s * 8 + 1] = (long long)__builtin_readcyclecounter();
             pnl_diag(Cs, cs, p, t);
-            pnl_store_tile(p, cs, cs, Cs, t, true);
+            if (p.stamps && t == 0) p.stamps[s * 8 + 2] = (long long)__builtin_readcyclecounter();
+            pnl_store_tile(p, cs, cs, Cs, t, true, true);
             pnl_publish(p, s);
+            if (p.stamps && t == 0) p.stamps[s * 8 + 3] = (long long)__builtin_readcyclecounter();
         }
         bool have_lss = false;
         int first = s + 1;                  // first owned row block above s
         first += ((g - first) % G + G) % G;
         for (int rb = first; rb < R; rb += G) {
             const int r0 = p.k0 + 64 * rb;
+            const bool crit = p.stamps && t == 0 && rb == s + 1;
+            if (crit) p.stamps[s * 8 + 4] = (long long)__builtin_readcyclecounter();
             if (!have_lss) {
                 pnl_wait(p, s);
+                if (crit) p.stamps[s * 8 + 5] = (long long)__builtin_readcyclecounter();
                 pnl_load_tile(p, cs, cs, Cs, t);
                 have_lss = true;
             }
@@ -288,7 +307,8 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
             __syncthreads();
             pnl_strip(Cs, Xs, rinvs, t);
             __syncthreads();
-            pnl_store_tile(p, r0, cs, Xs, t, false);
+            if (crit) p.stamps[s * 8 + 6] = (long long)__builtin_readcyclecounter();
+            pnl_store_tile(p, r0, cs, Xs, t, false, rb < S);
             if (rb < S) pnl_publish(p, 8 + s * 8 + rb);
             const int cmax = rb < S - 1 ? rb : S - 1;
             for (int c = s + 1; c <= cmax; ++c) {
@@ -302,6 +322,7 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
                 }
                 pnl_update(p, r0, p.k0 + 64 * c, Xs, Bt, t, c == rb);
             }
+            if (crit) p.stamps[s * 8 + 7] = (long long)__builtin_readcyclecounter();
         }
         // a workgroup that owns the next diagonal block must see its own updates of that block: same CU, plain
         // stores then plain loads through the same L1/L2 -> ordered by the vmcnt drain + barrier
@@ -324,7 +345,7 @@ static int panel_grid_cap() {
 }
 
 static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream) {
-    PanelArgs p{A, N, lda, k0, W / 64, logdet, info};
+    PanelArgs p{A, N, lda, k0, W / 64, logdet, info, nullptr};
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS_BYTES);
