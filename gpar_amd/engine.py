@@ -49,6 +49,7 @@ class HipEngine:
         self.epsilon = float(epsilon)  # lab's B.epsilon: diagonal jitter added before every Cholesky
         self._seed = int(seed)
         self._calls = 0
+        self._deferred = None  # list of pending device-side info words while a defer_checks() block is open
 
     # ---- memory ----------------------------------------------------------------------------------
     def tensor(self, x):
@@ -132,14 +133,51 @@ class HipEngine:
         return out
 
     # ---- status ----------------------------------------------------------------------------------
+    def defer_checks(self):
+        """Context manager: inside it `check_info` only records the device-side info words (no host sync), so a
+        whole multi-layer evaluation is enqueued back to back; leaving the block synchronises once and raises if
+        any factorisation failed."""
+        return _Deferred(self)
+
+    def check_info(self, info):
+        """Synchronise on the device-side LAPACK-style info word and raise if a pivot failed (or record it while a
+        defer_checks() block is open)."""
+        if self._deferred is not None:
+            self._deferred.append(info)
+            return
+        self._raise_for(info)
+
     @staticmethod
-    def check_info(info):
-        """Synchronise on the device-side LAPACK-style info word and raise if a pivot failed."""
+    def _raise_for(info):
         code = int(info.item())
         if code < 0:
             raise RuntimeError(f"gpar_potrf: device-side hand-off timed out (code {code}); is another kernel holding the CUs?")
         if code != 0:
             raise NotPositiveDefiniteError(code)
+
+
+class _Deferred:
+    def __init__(self, eng):
+        self.eng = eng
+        self.outer = None
+
+    def __enter__(self):
+        self.outer = self.eng._deferred
+        if self.outer is None:
+            self.eng._deferred = []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.outer is None:
+            pending, self.eng._deferred = self.eng._deferred, None
+            if exc_type is None:
+                for info in pending:
+                    self.eng._raise_for(info)
+        return False
+
+    @property
+    def active(self):
+        return True
 
 
 _engine = None

@@ -81,9 +81,10 @@ class _Factor:
         self._alpha = None
 
     def logpdf(self):
-        """-1/2 (log|S| + n log 2 pi + rhs^T S^-1 rhs) as a CPU 0-d tensor."""
-        val = -0.5 * (self.logdet[0] + self.n * _LOG_2PI + self.quad)
-        return val.detach().cpu()
+        """-1/2 (log|S| + n log 2 pi + rhs^T S^-1 rhs) as a 0-d tensor: on the CPU (synchronises), or left on the
+        device while the engine is deferring checks (the caller then reads the sum of many layers once)."""
+        val = (-0.5 * (self.logdet[0] + self.n * _LOG_2PI + self.quad)).detach()
+        return val if getattr(self.eng, "_deferred", None) is not None else val.cpu()
 
     def alpha(self):
         """S^-1 rhs as a row (1 x n): alpha^T = z^T L^-1."""

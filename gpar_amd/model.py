@@ -80,6 +80,13 @@ def per_output(y, w=None, keep=False):
         return
     p = y.shape[1]
     available = ~_isnan(y)
+    if _is_torch(y) and y.is_cuda and bool(available.all()):
+        # complete data (one host sync to find out): every mask is "all rows"; a slice instead of a boolean tensor
+        # keeps the per-layer loop free of the sync that boolean indexing forces, so the host can enqueue layer
+        # i + 1 while the GPU factorises layer i
+        for i in range(p):
+            yield y[:, i : i + 1], w[:, i], slice(None)
+        return
     for i in range(p):
         mask = available[:, i]
         if keep and i < p - 1:
@@ -137,12 +144,13 @@ class GPAR:
         x_ind = self._prep_ind(self.x_ind)
         post = self.copy()
         for is_last, ((yi, wi, mask), model) in last(zip(per_output(y, w, keep=self.impute), self.layers)):
+            complete = isinstance(mask, slice)
             x = x[mask]
             f, noise = model()
-            obs = self._obs(x, x_ind, yi, wi, f, noise)
+            obs = self._obs(x, x_ind, yi, wi, f, noise, complete=complete)
             post.layers.append(construct_model(f | obs, noise))
             if not is_last:
-                x, x_ind = self._update_inputs(x, x_ind, yi, f, obs)
+                x, x_ind = self._update_inputs(x, x_ind, yi, f, obs, complete=complete)
         return post
 
     # ---- log marginal likelihood -------------------------------------------------------------------
@@ -156,20 +164,25 @@ class GPAR:
         x_ind = self._prep_ind(self.x_ind if x_ind is None else x_ind)
         total = torch.zeros((), dtype=torch.float64)
         items = per_output(y, w, keep=self.impute or sample_missing)
-        for is_last, ((yi, wi, mask), model) in last(zip(items, self.layers), select=outputs):
-            x = x[mask]
-            f, noise = model()
-            obs = self._obs(x, x_ind, yi, wi, f, noise)
-            if not only_last_layer or is_last:
-                total = total + f.measure.logpdf(obs)
-            if not is_last:
-                missing = torch.isnan(yi[:, 0])
-                if sample_missing and bool(missing.any()):
-                    f_post = f | obs
-                    drawn = f_post(x[missing], self._noise_over(noise, wi[missing])).sample()
-                    yi = merge(yi, drawn, missing)
-                x, x_ind = self._update_inputs(x, x_ind, yi, f, obs)
-        return (x, x_ind) if return_inputs else total
+        with get_engine().defer_checks():
+            for is_last, ((yi, wi, mask), model) in last(zip(items, self.layers), select=outputs):
+                complete = isinstance(mask, slice)
+                x = x[mask]
+                f, noise = model()
+                obs = self._obs(x, x_ind, yi, wi, f, noise, complete=complete)
+                if not only_last_layer or is_last:
+                    total = total + f.measure.logpdf(obs)
+                if not is_last:
+                    if sample_missing and not complete:
+                        missing = torch.isnan(yi[:, 0])
+                        if bool(missing.any()):
+                            f_post = f | obs
+                            drawn = f_post(x[missing], self._noise_over(noise, wi[missing])).sample()
+                            yi = merge(yi, drawn, missing)
+                    x, x_ind = self._update_inputs(x, x_ind, yi, f, obs, complete=complete)
+        if return_inputs:
+            return x, x_ind
+        return total.cpu() if total.is_cuda and not total.requires_grad else total
 
     # ---- sampling ----------------------------------------------------------------------------------
     def sample(self, x, w, latent=False):
@@ -252,11 +265,12 @@ class GPAR:
             noise = torch.tensor(float(noise), dtype=torch.float64, device=w.device)
         return torch.true_divide(noise, w)
 
-    def _obs(self, x, x_ind, y, w, f, noise):
+    def _obs(self, x, x_ind, y, w, f, noise, complete=False):
         eng = get_engine()
         x, y, w = eng.tensor(x), eng.tensor(y), eng.tensor(w)
-        available = ~torch.isnan(y[:, 0])
-        x, y, w = x[available], y[available], w[available]
+        if not complete:  # `complete`: the caller knows no observation is missing (saves a host sync per layer)
+            available = ~torch.isnan(y[:, 0])
+            x, y, w = x[available], y[available], w[available]
         if self.sparse:
             return PseudoObs(f(x_ind), f(x, self._noise_arg(noise, w)), y)
         return Obs(f(x, self._noise_arg(noise, w)), y)
@@ -268,11 +282,13 @@ class GPAR:
             return noise / w if noise.device == w.device or noise.dim() == 0 else noise.to(w.device) / w
         return GPAR._noise_over(noise, w)
 
-    def _update_inputs(self, x, x_ind, y, f, obs):
+    def _update_inputs(self, x, x_ind, y, f, obs, complete=False):
         """Append output column y to the design matrix (and the estimated output to the inducing inputs)."""
         eng = get_engine()
         x, y = eng.tensor(x), eng.tensor(y)
         x_ind = None if x_ind is None else eng.tensor(x_ind)
+        if complete and not self.sparse and not self.replace:
+            return torch.cat([x, y], dim=1), x_ind  # nothing to estimate: observed column, no host sync
         available = ~torch.isnan(y[:, 0])
         post = (f | obs) if obs else None
 

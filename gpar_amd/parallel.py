@@ -30,9 +30,12 @@ def world(group=None):
     return 0, 1
 
 
-def _needs_estimate(gpar, yi):
-    missing = bool(torch.isnan(yi[:, 0]).any())
-    return gpar.sparse or gpar.replace or (gpar.impute and missing)
+def _needs_estimate(gpar, yi, complete):
+    if gpar.sparse or gpar.replace:
+        return True
+    if complete or not gpar.impute:
+        return False
+    return bool(torch.isnan(yi[:, 0]).any())
 
 
 def sharded_logpdf(gpar, x, y, w, group=None):
@@ -42,17 +45,30 @@ def sharded_logpdf(gpar, x, y, w, group=None):
     x, y, w = gpar._prep(x, y, w)
     x_ind = gpar._prep_ind(gpar.x_ind)
     local = torch.zeros((), dtype=torch.float64)
+    with eng.defer_checks():
+        local, x, x_ind = _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local)
+    if local.is_cuda:
+        local = local.cpu()
+    if size > 1:
+        buf = local.detach().to(device=eng.device, dtype=torch.float64).reshape(1).clone()
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        local = buf[0].cpu()
+    return local
+
+
+def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
     for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(per_output(y, w, keep=gpar.impute), gpar.layers))):
+        complete = isinstance(mask, slice)
         x = x[mask]
         mine = (i % size) == rank
         f = obs = None
         if mine:
             f, noise = model()
-            obs = gpar._obs(x, x_ind, yi, wi, f, noise)
+            obs = gpar._obs(x, x_ind, yi, wi, f, noise, complete=complete)
             local = local + f.measure.logpdf(obs)
         if is_last:
             break
-        if not _needs_estimate(gpar, yi):
+        if not _needs_estimate(gpar, yi, complete):
             x = torch.cat([x, yi], dim=1)  # observed data: already on every rank
             continue
         # dependent chain: the owner computes the forwarded column(s), everyone else receives them
@@ -60,7 +76,7 @@ def sharded_logpdf(gpar, x, y, w, group=None):
         col = torch.empty(n_i, 1, dtype=torch.float64, device=x.device)
         ind_col = None if x_ind is None else torch.empty(x_ind.shape[0], 1, dtype=torch.float64, device=x.device)
         if mine:
-            x_new, x_ind_new = gpar._update_inputs(x, x_ind, yi, f, obs)
+            x_new, x_ind_new = gpar._update_inputs(x, x_ind, yi, f, obs, complete=complete)
             col.copy_(x_new[:, -1:])
             if ind_col is not None:
                 ind_col.copy_(x_ind_new[:, -1:])
@@ -71,11 +87,7 @@ def sharded_logpdf(gpar, x, y, w, group=None):
         x = torch.cat([x, col], dim=1)
         if ind_col is not None:
             x_ind = torch.cat([x_ind, ind_col], dim=1)
-    if size > 1:
-        buf = local.detach().to(device=eng.device, dtype=torch.float64).reshape(1).clone()
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        local = buf[0].cpu()
-    return local
+    return local, x, x_ind
 
 
 def _global_rank(group_rank, group):

@@ -229,7 +229,7 @@ class GPARRegressor:
             gpar = gpar | (self.x, self.y, self.w)
         value = gpar.logpdf(x, y, w, only_last_layer=False, sample_missing=sample_missing)
         if not any_torch:
-            value = value.detach().numpy()
+            value = value.detach().cpu().numpy()
         return value
 
     def sample(self, x, w=None, p=None, posterior=False, num_samples=1, latent=False):

@@ -168,6 +168,13 @@ class OracleEngine:
         self._calls += 1
         return out
 
+    _deferred = None
+
+    def defer_checks(self):
+        import contextlib
+
+        return contextlib.nullcontext()
+
     @staticmethod
     def check_info(info):
         code = int(info.item())
