@@ -85,6 +85,10 @@ SIGNATURES = {
         _c_int,
         [_c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _ptr, _c_int, _ptr, _c_int, _c_dbl, _ptr, _c_int, _c_int, _ptr],
     ),
+    "gpar_gemm_splitk": (
+        _c_int,
+        [_c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _ptr, _c_int, _ptr, _c_int, _c_dbl, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr],
+    ),
     "gpar_logpdf_finalize": (_c_int, [_ptr, _ptr, _c_dbl, _c_int, _ptr, _ptr]),
     "gpar_copy_strided": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _ptr]),
     "gpar_fill": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_dbl, _ptr]),

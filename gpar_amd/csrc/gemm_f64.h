@@ -45,6 +45,8 @@ struct GemmArgs {
     int flags;
     int tiles_m, tiles_n;
     int fastA, fastB;
+    int ksplit;          // > 0: blockIdx.y selects the K range [y * ksplit, (y + 1) * ksplit) and the output slab y
+    long long part_stride;   // elements between consecutive partial slabs of C (split-K)
     long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memtime stamps, normally null
 };
 
@@ -198,10 +200,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     const int wm = w >> 1, wn = w & 1;
     const bool a_lower = (p.flags & GPAR_GEMM_A_LOWER) != 0;
     // with a triangular op(A) nothing beyond k = m0 + 127 contributes to this tile
-    const int kend = a_lower ? min(p.k, m0 + GEMM_BM) : p.k;
+    int kend = a_lower ? min(p.k, m0 + GEMM_BM) : p.k;
     // K_FROM_ROW: both operands vanish for k < their row (upper-triangular factors): with col <= row nothing
     // before k = m0 contributes to this tile
-    const int kbeg = (p.flags & GPAR_GEMM_K_FROM_ROW) ? min(m0, kend) : 0;
+    int kbeg = (p.flags & GPAR_GEMM_K_FROM_ROW) ? min(m0, kend) : 0;
+    if (p.ksplit > 0) {   // split-K: this block's slice of K, accumulated into its own slab of the workspace
+        kbeg = max(kbeg, (int)blockIdx.y * p.ksplit);
+        kend = min(kend, ((int)blockIdx.y + 1) * p.ksplit);
+        if (kend < kbeg) kend = kbeg;
+        p.C += (size_t)blockIdx.y * p.part_stride;
+    }
     const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
 
     double acc[16][4];
@@ -300,6 +308,8 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     p.fastA = gpar_aligned16(A) && (lda % 2 == 0);
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
     p.stamps = nullptr;
+    p.ksplit = 0;
+    p.part_stride = 0;
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
     static bool attr_done = false;
     if (!attr_done) {
@@ -319,6 +329,62 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     else if (!ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, GEMM_LDS_REQ, stream, p);
     else hipLaunchKernelGGL((gemm_f64_kernel<true, true, 0>), grid, block, GEMM_LDS_REQ, stream, p);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- split-K: for outputs with few tiles and a very long K (e.g. the VFE matrix B D^-1 B^T: 1024 x 1024 from
+// K = 65536) one tile per workgroup leaves most of the chip idle.  The K range is cut into `splits` slices, each
+// producing a partial C in a caller-provided workspace (deterministic: slabs are summed in order by a second kernel).
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const double* __restrict__ ws, long long part_stride, int splits,
+                                                                 int m, int n, double alpha, double beta, double* __restrict__ C,
+                                                                 int ldc, int lower) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (col >= n || row >= m || (lower && col > row)) return;
+    double s = 0.0;
+    for (int q = 0; q < splits; ++q) s += ws[(size_t)q * part_stride + (size_t)row * n + col];
+    double* dst = C + (size_t)row * ldc + col;
+    *dst = (beta != 0.0) ? fma(beta, *dst, alpha * s) : alpha * s;
+}
+
+static int gemm_splitk_launch(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
+                              int ldb, double beta, double* C, int ldc, int flags, int splits, double* workspace,
+                              hipStream_t stream) {
+    if (m <= 0 || n <= 0) return 0;
+    if (splits <= 1 || !workspace) return gemm_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, stream);
+    GemmArgs p;
+    p.A = A; p.B = B; p.C = workspace;
+    p.m = m; p.n = n; p.k = k;
+    p.lda = lda; p.ldb = ldb; p.ldc = n;
+    p.alpha = 1.0; p.beta = 0.0;
+    p.flags = flags;
+    p.tiles_m = gpar_ceil_div(m, GEMM_BM);
+    p.tiles_n = gpar_ceil_div(n, GEMM_BN);
+    if ((flags & GPAR_GEMM_C_LOWER) && p.tiles_n > p.tiles_m) p.tiles_n = p.tiles_m;
+    p.fastA = gpar_aligned16(A) && (lda % 2 == 0);
+    p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
+    p.stamps = nullptr;
+    const int len = gpar_ceil_div(gpar_ceil_div(k, splits), GEMM_BK) * GEMM_BK;
+    p.ksplit = len;
+    p.part_stride = (long long)m * n;
+    const int nsl = gpar_ceil_div(k, len);
+    const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    dim3 grid(ntiles, nsl), block(256);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((gemm_f64_kernel<true, true, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gpar_ceil_div(n, 256), m), dim3(256), 0, stream, (const double*)workspace,
+                       p.part_stride, nsl, m, n, alpha, beta, C, ldc, (flags & GPAR_GEMM_C_LOWER) ? 1 : 0);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

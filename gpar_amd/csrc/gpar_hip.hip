@@ -190,6 +190,11 @@ int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A
     return gemm_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, (hipStream_t)stream);
 }
 
+int gpar_gemm_splitk(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B, int ldb,
+                     double beta, double* C, int ldc, int flags, int splits, double* workspace, void* stream) {
+    return gemm_splitk_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, splits, workspace, (hipStream_t)stream);
+}
+
 int gpar_logpdf_finalize(const double* logdet, const double* quad, double quad_sign, int n, double* out, void* stream) {
     hipLaunchKernelGGL(logpdf_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logdet, quad, quad_sign, n, out);
     GPAR_LAUNCH_CHECK();

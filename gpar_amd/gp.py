@@ -483,18 +483,19 @@ class PseudoObs:
         kdiag = eng.gram_diag(ck, zx)
         trace_term = torch.sum((kdiag - torch.sum(Bt * Bt, dim=1)) / d)
         rs = torch.rsqrt(d)
-        Bs = eng.new_matrix(n, M)
-        torch.mul(Bt, rs[:, None], out=Bs)
-        ys = self.y.reshape(-1) * rs
-        # A = I + B D^-1 B^T, c = B D^-1 y; factor A with c as the augmented row
-        c = eng.gemm(ys[None, :], Bs)  # 1 x M
+        # [B D^-1/2 | D^-1/2 y]: ONE product over the n data points gives A - I, c = B D^-1 y and y^T D^-1 y together
+        Bs = eng.new_matrix(n, M + 1)
+        torch.mul(Bt, rs[:, None], out=Bs[:, :M])
+        Bs[:, M] = self.y.reshape(-1) * rs
+        G = eng.gemm(Bs, Bs, ta=True, c_lower=True)  # (M + 1) x (M + 1), lower triangle
+        c = G[M : M + 1, :M].clone()
+        yDy = G[M, M].clone()
 
         def fill(block):
-            eng.gemm(Bs, Bs, ta=True, out=block, c_lower=True)
+            block.copy_(G[:M, :M])
             block.diagonal().add_(1.0)
 
         facA = _Factor(eng, M, fill, c)
-        yDy = torch.sum(ys * ys)
         elbo = -0.5 * (trace_term + torch.sum(torch.log(d)) + n * _LOG_2PI + facA.logdet[0] + yDy - facA.quad)
         # v = L_z^-T A^-1 c, so that mean(x*) = K_*z v
         v = facA.alpha().clone()  # (A^-1 c)^T, 1 x M

@@ -172,6 +172,19 @@ def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False,
             raise ValueError("beta != 0 needs an `out`")
     _check_mat(out, "out")
     flags = (_lib.GEMM_C_LOWER if c_lower else 0) | (_lib.GEMM_A_LOWER if a_lower else 0)
+    # few output tiles but a very long K: cut K into slices so the whole chip works (deterministic two-pass sum)
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    if not a_lower and k >= 8192 and tiles <= 128:
+        splits = max(2, min(64, 512 // max(tiles, 1), k // 1024))
+        work = torch.empty(splits * m * n, dtype=torch.float64, device=A.device)
+        _lib.check(
+            lib.gpar_gemm_splitk(
+                int(ta), int(tb), m, n, k, float(alpha), A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), float(beta),
+                out.data_ptr(), _ld(out), flags, splits, work.data_ptr(), stream_ptr(A.device),
+            ),
+            "gpar_gemm_splitk",
+        )
+        return out
     _lib.check(
         lib.gpar_gemm(
             int(ta), int(tb), m, n, k, float(alpha), A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), float(beta),

@@ -150,6 +150,13 @@ int gpar_chol_inverse(const double* L, int n, int ldl, double* X, int ldx, doubl
 int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
               int ldb, double beta, double* C, int ldc, int flags, void* stream);
 
+/* As gpar_gemm, with the K range cut into `splits` slices whose partial products go to `workspace`
+ * (splits * m * n doubles) and are summed in slice order by a second kernel: for outputs with few 128 x 128 tiles and
+ * a very long K (the inducing-point matrix B D^-1 B^T: M x M from K = n).  Deterministic.  A_LOWER / K_FROM_ROW are
+ * not meaningful here. */
+int gpar_gemm_splitk(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
+                     int ldb, double beta, double* C, int ldc, int flags, int splits, double* workspace, void* stream);
+
 /* Small device-side utilities used by the fused paths (all asynchronous). */
 /* out[0] = -0.5 * (logdet[0] + n*log(2*pi) + quad_sign * quad[0])   [Normal.logpdf] */
 int gpar_logpdf_finalize(const double* logdet, const double* quad, double quad_sign, int n, double* out, void* stream);

@@ -278,3 +278,30 @@ def test_chol_inverse(env, n):
     ref = np.linalg.inv(A)
     il = np.tril_indices(n)
     assert np.allclose(got[il], ref[il], rtol=1e-9, atol=1e-11 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("ta,tb", [(True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("mnk", [(1, 300, 9000), (257, 130, 20000), (1025, 1025, 16411)])
+def test_gemm_split_k_path(env, ta, tb, mnk):
+    """Few output tiles + very long K takes the split-K path (partial slabs + ordered reduce): same answer, and
+    bit-for-bit repeatable."""
+    torch, hip, dev, to_dev = env
+    m, n, k = mnk
+    rng = np.random.default_rng(m + n + k)
+    A = rng.standard_normal((k, m) if ta else (m, k))
+    B = rng.standard_normal((n, k) if tb else (k, n))
+    opA, opB = (A.T if ta else A), (B.T if tb else B)
+    dA, dB = to_dev(A), to_dev(B)
+    got = hip.gemm(dA, dB, ta=ta, tb=tb).cpu().numpy()
+    again = hip.gemm(dA, dB, ta=ta, tb=tb).cpu().numpy()
+    assert np.array_equal(got, again)
+    scale = np.abs(opA) @ np.abs(opB)
+    assert np.all(np.abs(got - opA @ opB) <= 2e-13 * scale)
+    if m == n:
+        C = rng.standard_normal((m, n))
+        dC = to_dev(C)
+        hip.gemm(dA, dB, ta=ta, tb=tb, alpha=0.5, beta=2.0, out=dC, c_lower=True)
+        il, iu = np.tril_indices(m), np.triu_indices(m, 1)
+        gotc = dC.cpu().numpy()
+        assert np.all(np.abs(gotc - (0.5 * opA @ opB + 2 * C))[il] <= 2e-13 * (scale + np.abs(C))[il])
+        assert np.array_equal(gotc[iu], C[iu])
