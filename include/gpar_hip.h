@@ -17,7 +17,8 @@
  * Conventions
  *   - All matrices are ROW-MAJOR IEEE fp64 in device (HBM) memory with an explicit leading dimension
  *     (elements between consecutive rows).  For symmetric matrices the LOWER triangle is authoritative;
- *     the strict upper triangle is never read and may hold anything.
+ *     the strict upper triangle is never read; it may hold anything on entry and is SCRATCH: gpar_potrf keeps the
+ *     hand-off flags of its persistent panel kernel there (two rows of 56 words per 512-column panel).
  *   - Plain pointers and sizes only.  The caller owns every buffer, including workspace; the library
  *     never allocates or frees device memory and never synchronises the device, so every call is
  *     asynchronous on `stream` (a hipStream_t passed as void*) and hipGraph-capturable.
@@ -130,6 +131,8 @@ int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, in
  * Appending rows below K turns this one routine into the whole exact-GP computation:
  *   row  [y^T, 0]      -> z^T = (L^-1 y)^T and -|z|^2          (log marginal likelihood, gpar/model.py:226)
  *   rows [K_*x, K_**]  -> V^T = K_*x L^-T and K_** - V^T V      (posterior covariance, gpar/model.py:264,270)
+ * Requires the whole GPU to itself while it runs (its panel kernel spins on in-launch hand-offs between co-resident
+ * workgroups; every spin is bounded and a timeout is reported as info = -77).
  * [matrix.cholesky -> torch.linalg.cholesky (LAPACK dpotrf)] */
 int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, void* stream);
 
