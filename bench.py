@@ -163,6 +163,29 @@ def main():
             "rank": 0,
         }
 
+    # The timed region overlaps the trailing SYRK of panel k with the fused factorisation of panel k+1 (look-ahead on a
+    # second stream), so the live number above is the kernel's rate WHILE SHARING the chip.  One extra, untimed
+    # evaluation with look-ahead switched off gives the same kernel's rate when it has the GPU to itself.
+    if "roofline" in out:
+        os.environ["GPAR_POTRF_LOOKAHEAD"] = "0"
+        try:
+            lib.gpar_profile_read(None, None, None, 1)
+            lib.gpar_profile_enable(1)
+            step()
+            barrier()
+            lib.gpar_profile_enable(0)
+            l2, ms2, fl2 = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+            lib.gpar_profile_read(ctypes.byref(l2), ctypes.byref(ms2), ctypes.byref(fl2), 1)
+            if l2.value > 0 and ms2.value > 0:
+                iso = fl2.value / (ms2.value * 1e-3) * 1e-12
+                out["roofline"]["isolated"] = {"achieved": iso, "frac": iso / FP64_MATRIX_PEAK_TFLOPS, "launches": l2.value,
+                                               "avg_launch_ms": ms2.value / l2.value,
+                                               "note": "same kernel, one untimed evaluation with GPAR_POTRF_LOOKAHEAD=0 (no co-running panel kernel)"}
+        finally:
+            del os.environ["GPAR_POTRF_LOOKAHEAD"]
+        out["roofline"]["note"] = ("live value: measured inside the timed region, where the kernel co-runs with the fused panel "
+                                   "kernel of the next panel (look-ahead); see `isolated` for the kernel alone")
+
     if rank == 0 and not args.no_extras:
         out["fit_predict"] = fit_predict_leg(eng, x_np, y_np, n, m, p)
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -28,7 +28,8 @@ namespace gpar {
 
 constexpr int PNL_LD = 66;
 constexpr int PNL_TILE = 64 * PNL_LD;                  // doubles
-constexpr int PNL_LDS_BYTES = 3 * PNL_TILE * 8 + 512;  // Cs/T, Xs, Bs + reciprocal pivots
+constexpr int PNL_LDS_BYTES = 2 * PNL_TILE * 8 + 512;  // Cs/T (aliased by the update operand), Xs + reciprocal pivots: 68 KB, so a
+                                                       // panel workgroup fits on a CU beside one 73.7 KB SYRK workgroup
 constexpr int PNL_FLAG_SLOTS = 56;                     // usable scratch words per row of the diagonal block
 constexpr unsigned PNL_SPIN_LIMIT = 1u << 22;
 
@@ -266,8 +267,8 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
     double* Cs = psm;                    // L_ss (strip coefficients) / diagonal work tile
     double* Xs = psm + PNL_TILE;         // this row block's X
-    double* Bs = psm + 2 * PNL_TILE;     // L[c][s] operand of the update
-    double* rinvs = psm + 3 * PNL_TILE;  // reciprocal pivots of L_ss
+    double* Bs = psm;                    // L[c][s] operand of the update: ALIASES Cs (dead after the strip)
+    double* rinvs = psm + 2 * PNL_TILE;  // reciprocal pivots of L_ss
     const int t = threadIdx.x;
     const int G = gridDim.x, g = blockIdx.x;
     const int R = (p.N - p.k0 + 63) / 64;   // row blocks below (and including) the panel's first row
@@ -297,10 +298,10 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
             if (!have_lss) {
                 pnl_wait(p, s);
                 if (crit) p.stamps[s * 8 + 5] = (long long)__builtin_readcyclecounter();
-                pnl_load_tile(p, cs, cs, Cs, t);
                 have_lss = true;
             }
             __syncthreads();                // previous iteration done with Xs / Bs
+            pnl_load_tile(p, cs, cs, Cs, t); // (re)load L_ss: the update operand of the previous row block overwrote it
             pnl_load_tile(p, r0, cs, Xs, t);
             __syncthreads();
             if (t < 64) rinvs[t] = 1.0 / Cs[t * PNL_LD + t];
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
             for (int c = s + 1; c <= cmax; ++c) {
                 const double* Bt = Xs;
                 if (c != rb) {
-                    __syncthreads();        // earlier update done with Bs
+                    __syncthreads();        // strip / earlier update done with the Cs = Bs tile
                     pnl_wait(p, 8 + s * 8 + c);
                     pnl_load_tile(p, p.k0 + 64 * c, cs, Bs, t);
                     __syncthreads();

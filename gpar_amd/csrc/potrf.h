@@ -260,14 +260,15 @@ static PotrfPolicy potrf_policy(int N) {
     else if (N >= 1536) p.nbo = 128;
     else p.nbo = 64;
     p.nbm = p.nbo >= 512 ? 128 : 64;
-    // Look-ahead on a second stream is implemented but OFF by default: with the present panel kernels the serial
-    // diag/strip chain, not the trailing update, is the critical path (profiles/r01_potrf_trace_*.txt), and the
-    // chain's small kernels queue for CU slots behind the big SYRK, so overlapping buys nothing yet.
-    p.lookahead = 0;
+    // Look-ahead: the fused panel kernel of panel k+1 (68 KB LDS: fits on a CU beside one SYRK workgroup) runs on
+    // the caller's stream under the trailing update of panel k on a low-priority side stream.  Pays once the
+    // trailing updates are long enough to hide it (measured: n = 8192 8.4 -> 7.8 ms, 16384 37.2 -> 33.7 ms; a wash
+    // at 6144, a loss at 4096).  The unfused fallback keeps it off (its small kernels starve behind the SYRK).
+    p.lookahead = (p.fused && N >= 7168) ? 1 : 0;
     p.nbo = env_int("GPAR_POTRF_NBO", p.nbo);
     p.nbm = env_int("GPAR_POTRF_NBM", p.nbm);
     p.lookahead = env_int("GPAR_POTRF_LOOKAHEAD", p.lookahead);
-    p.split = env_int("GPAR_POTRF_SPLIT", p.lookahead);
+    p.split = env_int("GPAR_POTRF_SPLIT", 0);
     if (p.nbo < 64) p.nbo = 64;
     if (p.nbm < 64) p.nbm = 64;
     return p;
