@@ -34,6 +34,7 @@ constexpr int GEMM_LDKC = 18;
 constexpr int GEMM_LDMC = 144;
 constexpr int GEMM_TILE = 2304;  // doubles per operand stage (128*18 == 16*144)
 constexpr int GEMM_LDS_BYTES = 4 * GEMM_TILE * 8;
+constexpr int GEMM_LDT = 66;     // row pitch of the epilogue's transposition buffer: 16 x 66 doubles per wave
 
 struct GemmArgs {
     const double* A;
@@ -44,7 +45,7 @@ struct GemmArgs {
     double alpha, beta;
     int flags;
     int tiles_m, tiles_n;
-    int fastA, fastB;
+    int fastA, fastB, fastC;
     int ksplit;          // > 0: blockIdx.y selects the K range [y * ksplit, (y + 1) * ksplit) and the output slab y
     long long part_stride;   // elements between consecutive partial slabs of C (split-K)
     long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memtime stamps, normally null
@@ -233,7 +234,50 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     // memory round trips per tile, measured as a fixed ~20 us per tile): interior tiles use plain loads/stores, edge
     // tiles load from clamped (always valid) addresses and only the stores are predicated.
     const bool interior = (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n) && (!c_lower || n0 + GEMM_BN - 1 <= m0);
-    if (interior) {
+    if (interior && p.fastC) {
+        // Interior tile, 16-byte aligned C: transpose the accumulators through LDS (the operand stages are dead
+        // after the K loop; every wave owns a private 18 KB slice, so no workgroup barrier is needed) so that each
+        // lane ends up with two ADJACENT columns of one row.  In the MFMA D layout neighbouring lanes hold different
+        // rows: a wave-level 8-byte access is 64 separate requests to four 128-byte lines, and the 64 loads + 64
+        // stores per lane of the straightforward epilogue cost ~30 k cycles per tile (tools/time_gemm_phases.hip).
+        // Transposed, a wave-level 16-byte access covers two full 512-byte row segments.
+        double* S = smem + w * GEMM_TILE;                     // [16][GEMM_LDT] doubles, private to this wave
+        const int rrow = lane >> 5, rcol = (lane & 31) * 2;   // read-back: row 2 q + rrow, columns rcol, rcol + 1
+        double* cbase = p.C + (size_t)(m0 + wm * 64 + rrow) * p.ldc + n0 + wn * 64 + rcol;
+        // four quarters of 16 rows; the C values of quarter h + 1 are requested before quarter h is processed
+        gpar_d2 cv[2][8];
+        if (beta != 0.0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cv[0][q] = *reinterpret_cast<const gpar_d2*>(cbase + (size_t)(2 * q) * p.ldc);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj)
+                    S[(4 * mi + l3) * GEMM_LDT + 16 * nj + 4 * ((lane >> 2) & 3) + lk] = acc[4 * h + mi][nj];
+            if (h < 3 && beta != 0.0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    cv[(h + 1) & 1][q] = *reinterpret_cast<const gpar_d2*>(cbase + (size_t)(16 * (h + 1) + 2 * q) * p.ldc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            gpar_d2 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const gpar_d2*>(S + (2 * q + rrow) * GEMM_LDT + rcol);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the next quarter overwrites S
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                gpar_d2 o = v[q] * alpha;
+                if (beta != 0.0) o = gpar_d2{fma(beta, cv[h & 1][q][0], o[0]), fma(beta, cv[h & 1][q][1], o[1])};
+                *reinterpret_cast<gpar_d2*>(cbase + (size_t)(16 * h + 2 * q) * p.ldc) = o;
+            }
+        }
+    } else if (interior) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             double cv[8][4];
@@ -307,6 +351,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     }
     p.fastA = gpar_aligned16(A) && (lda % 2 == 0);
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
+    p.fastC = gpar_aligned16(C) && (ldc % 2 == 0);
     p.stamps = nullptr;
     p.ksplit = 0;
     p.part_stride = 0;
@@ -364,6 +409,7 @@ static int gemm_splitk_launch(int ta, int tb, int m, int n, int k, double alpha,
     if ((flags & GPAR_GEMM_C_LOWER) && p.tiles_n > p.tiles_m) p.tiles_n = p.tiles_m;
     p.fastA = gpar_aligned16(A) && (lda % 2 == 0);
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
+    p.fastC = gpar_aligned16(workspace) && (n % 2 == 0) && (((long long)m * n) % 2 == 0);
     p.stamps = nullptr;
     const int len = gpar_ceil_div(gpar_ceil_div(k, splits), GEMM_BK) * GEMM_BK;
     p.ksplit = len;

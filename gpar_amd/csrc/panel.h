@@ -1,4 +1,4 @@
-// Fused panel factorisation: ONE persistent launch factors a whole W-column panel (W = 64 * S, S <= 8) for all
+// Fused panel factorisation: ONE persistent launch factors a whole W-column panel (W = 64 * S, S <= 16) for all
 // rows below it, instead of S x {diag kernel, strip kernel, rank-64 GEMM} = 3 S dependent launches.
 //
 // Why: the blocked Cholesky's critical path is the chain  diag(s) -> strip(s) -> update(s) -> diag(s+1) ...; as
@@ -31,6 +31,7 @@ constexpr int PNL_TILE = 64 * PNL_LD;                  // doubles
 constexpr int PNL_LDS_BYTES = 2 * PNL_TILE * 8 + 512;  // Cs/T (aliased by the update operand), Xs + reciprocal pivots: 68 KB, so a
                                                        // panel workgroup fits on a CU beside one 73.7 KB SYRK workgroup
 constexpr int PNL_FLAG_SLOTS = 56;                     // usable scratch words per row of the diagonal block
+constexpr int PNL_MAX_S = 16;                          // S + S^2 <= 8 rows x 56 slots
 constexpr unsigned PNL_SPIN_LIMIT = 1u << 22;
 
 struct PanelArgs {
@@ -310,13 +311,13 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
             __syncthreads();
             if (crit) p.stamps[s * 8 + 6] = (long long)__builtin_readcyclecounter();
             pnl_store_tile(p, r0, cs, Xs, t, false, rb < S);
-            if (rb < S) pnl_publish(p, 8 + s * 8 + rb);
+            if (rb < S) pnl_publish(p, S + s * S + rb);
             const int cmax = rb < S - 1 ? rb : S - 1;
             for (int c = s + 1; c <= cmax; ++c) {
                 const double* Bt = Xs;
                 if (c != rb) {
                     __syncthreads();        // strip / earlier update done with the Cs = Bs tile
-                    pnl_wait(p, 8 + s * 8 + c);
+                    pnl_wait(p, S + s * S + c);
                     pnl_load_tile(p, p.k0 + 64 * c, cs, Bs, t);
                     __syncthreads();
                     Bt = Bs;
@@ -352,9 +353,12 @@ static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* l
         hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS_BYTES);
         attr_done = true;
     }
-    // zero the flag words (two scratch rows in the strict upper triangle of the first diagonal block)
-    hipMemsetAsync(A + (size_t)k0 * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream);
-    hipMemsetAsync(A + (size_t)(k0 + 1) * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream);
+    // zero the flag words (S + S^2 of them, 56 per scratch row in the strict upper triangle of the first diagonal
+    // block: rows 0..7 have columns 8..63 strictly above the diagonal, which bounds S at 16)
+    const int nflags = p.S + p.S * p.S;
+    if (p.S > PNL_MAX_S) return GPAR_ARG_ERROR(5);
+    for (int r = 0; r * PNL_FLAG_SLOTS < nflags; ++r)
+        hipMemsetAsync(A + (size_t)(k0 + r) * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream);
     const int R = (N - k0 + 63) / 64;
     int G = R < panel_grid_cap() ? R : panel_grid_cap();
     hipLaunchKernelGGL(potrf_panel_kernel, dim3(G), dim3(256), PNL_LDS_BYTES, stream, p);

@@ -392,7 +392,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         if (pol.fused && (kend - k0) > 64 && (kend - k0) % 64 != 0) kend = k0 + (kend - k0) / 64 * 64;
         knext = kend;
         const int w = kend - k0;
-        const bool fused_ok = pol.fused && w % 64 == 0 && w <= 512 && N - k0 >= 64 && (k0 % 2 == 0) && (lda % 2 == 0) && gpar_aligned16(A);
+        const bool fused_ok = pol.fused && w % 64 == 0 && w <= 1024 && N - k0 >= 64 && (k0 % 2 == 0) && (lda % 2 == 0) && gpar_aligned16(A);
         int rc = fused_ok ? potrf_panel_fused(A, N, lda, k0, w, logdet, info, stream)
                           : (pol.split ? potrf_panel_split(c, k0, kend, nbo, stream) : potrf_panel(c, k0, kend, nbo, stream));
         if (rc) return rc;

@@ -10,7 +10,7 @@ int main(int argc, char** argv) {
     hipMalloc(&C, sizeof(double) * (size_t)n * n); hipMalloc(&P, sizeof(double) * (size_t)n * 512);
     hipMemset(C, 0, sizeof(double) * (size_t)n * n); hipMemset(P, 0, sizeof(double) * (size_t)n * 512);
     GemmArgs p; p.A = P; p.B = P; p.C = C; p.m = n; p.n = n; p.k = K; p.lda = 512; p.ldb = 512; p.ldc = n;
-    p.alpha = -1; p.beta = 1; p.flags = GPAR_GEMM_C_LOWER; p.tiles_m = n / 128; p.tiles_n = n / 128; p.fastA = p.fastB = 1;
+    p.alpha = -1; p.beta = 1; p.flags = GPAR_GEMM_C_LOWER; p.tiles_m = n / 128; p.tiles_n = n / 128; p.fastA = p.fastB = p.fastC = 1;
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, p.flags);
     hipMalloc(&st, sizeof(long long) * 4 * ntiles); p.stamps = st;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
