@@ -28,8 +28,10 @@ namespace gpar {
 
 constexpr int PNL_LD = 66;
 constexpr int PNL_TILE = 64 * PNL_LD;                  // doubles
-constexpr int PNL_LDS_BYTES = 2 * PNL_TILE * 8 + 512;  // Cs/T (aliased by the update operand), Xs + reciprocal pivots: 68 KB, so a
-                                                       // panel workgroup fits on a CU beside one 73.7 KB SYRK workgroup
+constexpr int PNL_LDT = 34;                            // row pitch of the update's wave-private transposition buffers
+constexpr int PNL_LDS_BYTES = 2 * PNL_TILE * 8 + 512 + 4 * 4 * PNL_LDT * 8;  // Cs/T (aliased by the update operand), Xs, reciprocal
+                                                       // pivots, 4 transposition buffers: 70.8 KB - it must fit the
+                                                       // 73.7 KB hole a retiring SYRK workgroup leaves (see pnl_update)
 constexpr int PNL_FLAG_SLOTS = 56;                     // usable scratch words per row of the diagonal block
 constexpr int PNL_MAX_S = 16;                          // S + S^2 <= 8 rows x 56 slots
 constexpr unsigned PNL_SPIN_LIMIT = 1u << 22;
@@ -221,18 +223,25 @@ __device__ __forceinline__ void pnl_strip(const double* __restrict__ Cs, double*
 
 // C (64 x 64 block at rows r0, cols c0 of A) -= Xs Bs^T, both LDS tiles [64][PNL_LD] with k contiguous.
 // Wave w owns rows 16 w .. 16 w + 15 (4 row patches) x all 64 columns (4 column patches): 16 accumulators.
+// In the MFMA D layout neighbouring lanes hold different rows, so reading / writing C straight from that layout is
+// 64 separate 8-byte requests per wave instruction: C is read and written row-contiguously instead (16 bytes per
+// lane, 256-byte row segments) and the accumulators are transposed into that layout, half a row patch (4 x 32) at a
+// time, through a small wave-private LDS buffer Tw ([4][PNL_LDT]).  The buffer is kept that small on purpose: the
+// whole workgroup must stay below the 73.7 KB of a SYRK workgroup, because LDS is allocated contiguously and the
+// hole a retiring SYRK workgroup leaves is exactly that big (a 76 KB version of this kernel was not dispatched
+// until the co-running trailing update had drained: tools/time_panel.hip).
 __device__ __forceinline__ void pnl_update(const PanelArgs& p, int r0, int c0, const double* __restrict__ Xs,
-                                           const double* __restrict__ Bs, int t, bool lower_only) {
+                                           const double* __restrict__ Bs, double* __restrict__ Tw, int t, bool lower_only) {
     const int lane = t & 63, w = t >> 6;
     const int l3 = lane & 3, l15 = lane & 15, lk = lane >> 4;
-    // the 16 C values of this lane are requested first so their memory latency runs under the MFMA loop
-    const int colb = c0 + 4 * ((lane >> 2) & 3) + lk;
-    double cv[4][4];
+    const int rrow = lane >> 4, rcol = (lane & 15) * 2;
+    // the C values of this lane are requested first so their memory latency runs under the MFMA loop
+    pan_d2 cv[4][2];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        const int row = min(r0 + 16 * w + 4 * mi + l3, p.N - 1);
+        const int row = min(r0 + 16 * w + 4 * mi + rrow, p.N - 1);
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) cv[mi][nj] = p.A[(size_t)row * p.lda + colb + 16 * nj];
+        for (int hf = 0; hf < 2; ++hf) cv[mi][hf] = *reinterpret_cast<const pan_d2*>(p.A + (size_t)row * p.lda + c0 + 32 * hf + rcol);
     }
     double acc[4][4];
 #pragma unroll
@@ -254,12 +263,25 @@ __device__ __forceinline__ void pnl_update(const PanelArgs& p, int r0, int c0, c
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        const int rloc = 16 * w + 4 * mi + l3;
+        const int rloc = 16 * w + 4 * mi + rrow;
         const int row = r0 + rloc;
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) {
-            const int cloc = 16 * nj + 4 * ((lane >> 2) & 3) + lk;
-            if (row < p.N && (!lower_only || cloc <= rloc)) p.A[(size_t)row * p.lda + colb + 16 * nj] = cv[mi][nj] - acc[mi][nj];
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) Tw[l3 * PNL_LDT + 16 * nj + 4 * ((lane >> 2) & 3) + lk] = acc[mi][2 * hf + nj];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const pan_d2 v = *reinterpret_cast<const pan_d2*>(Tw + rrow * PNL_LDT + rcol);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the next half patch overwrites Tw
+            const int cloc = 32 * hf + rcol;
+            double* dst = p.A + (size_t)row * p.lda + c0 + cloc;
+            const pan_d2 o = cv[mi][hf] - v;
+            if (row < p.N) {
+                if (!lower_only || cloc + 1 <= rloc) *reinterpret_cast<pan_d2*>(dst) = o;
+                else if (cloc == rloc) dst[0] = o[0];
+            }
         }
     }
 }
@@ -270,10 +292,16 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
     double* Xs = psm + PNL_TILE;         // this row block's X
     double* Bs = psm;                    // L[c][s] operand of the update: ALIASES Cs (dead after the strip)
     double* rinvs = psm + 2 * PNL_TILE;  // reciprocal pivots of L_ss
+    double* Tw = psm + 2 * PNL_TILE + 64 + (threadIdx.x >> 6) * 4 * PNL_LDT;   // this wave's transposition buffer
     const int t = threadIdx.x;
     const int G = gridDim.x, g = blockIdx.x;
     const int R = (p.N - p.k0 + 63) / 64;   // row blocks below (and including) the panel's first row
     const int S = p.S;
+    // Under look-ahead this latency-bound kernel shares every CU with a trailing-update workgroup whose waves issue
+    // fp64 MFMAs back to back on the same double-precision pipes: at equal priority the serial pivot chain ran 3-4x
+    // slower than alone (tools/time_panel.hip).  Its waves are few and mostly waiting, so they take issue priority.
+    __builtin_amdgcn_s_setprio(3);
+    if (p.stamps && t == 0) p.stamps[64 + g] = (long long)__builtin_amdgcn_s_memrealtime();   // dev aid: arrival (100 MHz wall clock)
 
     for (int s = 0; s < S; ++s) {
         const int cs = p.k0 + 64 * s;       // first column of column block s; row block s starts at the same index
@@ -322,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
                     __syncthreads();
                     Bt = Bs;
                 }
-                pnl_update(p, r0, p.k0 + 64 * c, Xs, Bt, t, c == rb);
+                pnl_update(p, r0, p.k0 + 64 * c, Xs, Bt, Tw, t, c == rb);
             }
             if (crit) p.stamps[s * 8 + 7] = (long long)__builtin_readcyclecounter();
         }
@@ -330,6 +358,7 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
         // stores then plain loads through the same L1/L2 -> ordered by the vmcnt drain + barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (p.stamps && t == 0) p.stamps[64 + 256 * (1 + s) + g] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -342,6 +371,8 @@ static int panel_grid_cap() {
         hipDeviceProp_t prop;
         cap = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 64;
         if (cap < 1) cap = 1;
+        const char* e = getenv("GPAR_PANEL_GRID");   // experiment knob: fewer, busier panel workgroups
+        if (e && atoi(e) > 0 && atoi(e) < cap) cap = atoi(e);
     }
     return cap;
 }

@@ -260,7 +260,7 @@ static PotrfPolicy potrf_policy(int N) {
     else if (N >= 1536) p.nbo = 128;
     else p.nbo = 64;
     p.nbm = p.nbo >= 512 ? 128 : 64;
-    // Look-ahead: the fused panel kernel of panel k+1 (68 KB LDS: fits on a CU beside one SYRK workgroup) runs on
+    // Look-ahead: the fused panel kernel of panel k+1 (70.8 KB LDS: fits on a CU beside one SYRK workgroup) runs on
     // the caller's stream under the trailing update of panel k on a low-priority side stream.  Pays once the
     // trailing updates are long enough to hide it (measured: n = 8192 8.4 -> 7.8 ms, 16384 37.2 -> 33.7 ms; a wash
     // at 6144, a loss at 4096).  The unfused fallback keeps it off (its small kernels starve behind the SYRK).
