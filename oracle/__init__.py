@@ -17,5 +17,9 @@ exact GP regression; Titsias 2009 for the VFE inducing-point bound; mlkernels' E
 Linear / stretch / periodic / select definitions) and is pinned by
   (i)   every literal / closed-form identity the reference tests do hold (tests/test_oracle*.py),
   (ii)  an O(n^3)-free-of-Cholesky second formula (slogdet + solve) at small n,
-  (iii) central finite differences for every analytic gradient.
+  (iii) central finite differences for every analytic gradient,
+  (iv)  an independent published implementation of the same definitions: scikit-learn's
+        GaussianProcessRegressor with RBF / RationalQuadratic / DotProduct / ExpSineSquared kernels
+        (Gram matrices, log marginal likelihood, posterior mean and covariance agree to 1e-10;
+        tests/test_oracle_sklearn.py).  This is not the reference, so the header above stands.
 """
