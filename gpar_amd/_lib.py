@@ -94,6 +94,10 @@ SIGNATURES = {
     "gpar_fill": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_dbl, _ptr]),
     "gpar_dot": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "gpar_randn": (_c_int, [_u64, _u64, _ptr, _c_int, _c_int, _c_int, _ptr]),
+    "gpar_sample_stats": (
+        _c_int,
+        [_ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_dbl, _c_int, _c_dbl, _ptr, _ptr, _ptr, _ptr],
+    ),
     "gpar_profile_enable": (_c_int, [_c_int]),
     "gpar_profile_read": (_c_int, [ctypes.POINTER(_c_int), ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_dbl), _c_int]),
 }

@@ -88,6 +88,43 @@ __global__ __launch_bounds__(256) void randn_kernel(uint64_t seed, uint64_t offs
 
 using namespace gpar;
 
+// ---- Monte-Carlo reduction over posterior samples (reference regression.py:589-595)
+__device__ __forceinline__ double np_lerp(double a, double b, double t) {
+    // numpy's _lerp: a + (b - a) t, replaced by b - (b - a)(1 - t) when t >= 0.5; numpy rounds the product and the
+    // sum separately, so no fused multiply-add here
+#pragma clang fp contract(off)
+    const double d = b - a;
+    return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
+}
+
+__global__ __launch_bounds__(256) void sample_stats_kernel(const double* __restrict__ x, int S, long long count, long long stride,
+                                                           int k_lo, double g_lo, int k_hi, double g_hi, double* __restrict__ mean,
+                                                           double* __restrict__ lo, double* __restrict__ hi) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    const double* col = x + e;
+    double sum = 0.0;
+    for (int s = 0; s < S; ++s) sum += col[(long long)s * stride];
+    mean[e] = sum / (double)S;
+    if (!lo && !hi) return;
+    const int k_lo1 = min(k_lo + 1, S - 1), k_hi1 = min(k_hi + 1, S - 1);
+    double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const double v = col[(long long)s * stride];
+        int rank = 0;   // position of sample s in the stable ascending order
+        for (int t = 0; t < S; ++t) {
+            const double u = col[(long long)t * stride];
+            rank += (u < v || (u == v && t < s)) ? 1 : 0;
+        }
+        if (rank == k_lo) a0 = v;
+        if (rank == k_lo1) b0 = v;
+        if (rank == k_hi) a1 = v;
+        if (rank == k_hi1) b1 = v;
+    }
+    if (lo) lo[e] = np_lerp(a0, b0, g_lo);
+    if (hi) hi[e] = np_lerp(a1, b1, g_hi);
+}
+
 extern "C" {
 
 int gpar_abi_version(void) { return GPAR_ABI_VERSION; }
@@ -228,6 +265,17 @@ int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, 
     const size_t pairs = ((size_t)rows * cols + 1) / 2;
     hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, offset, out,
                        rows, cols, ldo);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_sample_stats(const double* samples, int S, long long count, long long stride, int k_lo, double g_lo, int k_hi,
+                      double g_hi, double* mean, double* lo, double* hi, void* stream) {
+    if (count <= 0) return 0;
+    if (S <= 0 || S > 65536 || !samples || !mean) return GPAR_ARG_ERROR(2);
+    if ((lo || hi) && (k_lo < 0 || k_lo >= S || k_hi < 0 || k_hi >= S)) return GPAR_ARG_ERROR(5);
+    hipLaunchKernelGGL(sample_stats_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, samples, S,
+                       count, stride, k_lo, g_lo, k_hi, g_hi, mean, lo, hi);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

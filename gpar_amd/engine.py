@@ -19,6 +19,7 @@ Primitive set (all tensors float64, row-major, lower triangles authoritative):
     trsm_rlt_(L, B) / trsm_rln_(L, B) B L^-T / B L^-1
     gemm(A, B, ta, tb, alpha, beta, out, c_lower, a_lower)
     randn(rows, cols)                 counter-based standard normals
+    sample_stats(samples, qlo, qhi)   Monte-Carlo mean / percentiles over the sample axis
 """
 import torch
 
@@ -131,6 +132,10 @@ class HipEngine:
         out = hip.randn(self._seed, self._calls, rows, cols, self.device)
         self._calls += 1
         return out
+
+    def sample_stats(self, samples, q_lo=None, q_hi=None):
+        """(mean, lo-percentile, hi-percentile) over the leading (sample) axis, on the device."""
+        return hip.sample_stats(samples.contiguous(), q_lo, q_hi)
 
     # ---- status ----------------------------------------------------------------------------------
     def defer_checks(self):

@@ -6,6 +6,8 @@ stride (`stride(1) == 1`); the leading dimension is `stride(0)`.
 """
 import ctypes
 
+import math
+
 import torch
 
 from . import _lib
@@ -25,6 +27,7 @@ __all__ = [
     "fill_",
     "dot",
     "randn",
+    "sample_stats",
 ]
 
 
@@ -241,6 +244,41 @@ def randn(seed, offset, rows, cols, device):
         "gpar_randn",
     )
     return out
+
+
+def percentile_index(num, q):
+    """(k, g) such that numpy's default ("linear", Hyndman & Fan 7) percentile q of `num` sorted values v is
+    lerp(v[k], v[k + 1], g), with virtual index h = (num - 1) * (q / 100), k = floor(h), g = h - k - the expression
+    numpy >= 2.0 evaluates, so the device result is bit-identical to np.percentile there."""
+    virtual = (num - 1) * (float(q) / 100.0)
+    k = int(math.floor(virtual))
+    g = virtual - k
+    if k < 0:
+        k, g = 0, 0.0
+    if k >= num - 1:
+        k, g = num - 1, 0.0
+    return k, g
+
+
+def sample_stats(samples, q_lo=None, q_hi=None):
+    """samples: contiguous (S, ...) fp64 device tensor.  Returns (mean, lo, hi) over axis 0 (lo / hi None unless both
+    percentiles are given) - np.mean / np.percentile(method="linear") of the reference's predict, on the device."""
+    if samples.dtype != torch.float64 or not samples.is_contiguous() or samples.dim() < 2:
+        raise ValueError("samples must be a contiguous fp64 tensor of shape (S, ...)")
+    lib = _lib.load()
+    S = samples.shape[0]
+    count = samples[0].numel()
+    mean = torch.empty(samples.shape[1:], dtype=torch.float64, device=samples.device)
+    want = q_lo is not None and q_hi is not None
+    lo = torch.empty_like(mean) if want else None
+    hi = torch.empty_like(mean) if want else None
+    (k0, g0), (k1, g1) = (percentile_index(S, q_lo), percentile_index(S, q_hi)) if want else ((0, 0.0), (0, 0.0))
+    _lib.check(
+        lib.gpar_sample_stats(samples.data_ptr(), int(S), int(count), int(count), k0, g0, k1, g1, mean.data_ptr(),
+                              lo.data_ptr() if want else None, hi.data_ptr() if want else None, stream_ptr(samples.device)),
+        "gpar_sample_stats",
+    )
+    return mean, lo, hi
 
 
 def featurize_dfreq(ck, x):

@@ -232,9 +232,8 @@ class GPARRegressor:
             value = value.detach().cpu().numpy()
         return value
 
-    def sample(self, x, w=None, p=None, posterior=False, num_samples=1, latent=False):
-        """Draw samples from the prior or the posterior at inputs x; a single ndarray for num_samples=1, otherwise
-        a list (reference regression.py:508-564)."""
+    def _sample_device(self, x, w, p, posterior, num_samples, latent):
+        """The samples of `sample` as engine tensors (n* x p each), output transforms undone."""
         x = _uprank(_to_torch(x))
         if posterior and not self.is_conditioned:
             raise RuntimeError("Must condition or fit model before sampling from the posterior.")
@@ -249,18 +248,28 @@ class GPARRegressor:
             gpar = gpar | (self.x, self.y, self.w)
         else:
             gpar = _construct_gpar(self, self.vs, x.shape[1], p)
+        return [self._untransform_y(self._unnormalise_y(s)).detach() for s in gpar.sample_many(x, w, num_samples, latent=latent)]
 
-        def undo_transforms(y_):
-            return self._untransform_y(self._unnormalise_y(y_))
-
-        samples = [undo_transforms(s).detach().cpu().numpy() for s in gpar.sample_many(x, w, num_samples, latent=latent)]
+    def sample(self, x, w=None, p=None, posterior=False, num_samples=1, latent=False):
+        """Draw samples from the prior or the posterior at inputs x; a single ndarray for num_samples=1, otherwise
+        a list (reference regression.py:508-564)."""
+        samples = [s.cpu().numpy() for s in self._sample_device(x, w, p, posterior, num_samples, latent)]
         return samples[0] if num_samples == 1 else samples
 
     def predict(self, x, w=None, num_samples=100, latent=False, credible_bounds=False):
         """Monte-Carlo predictive mean (and central 95% marginal bounds) from posterior samples
-        (reference regression.py:566-597)."""
-        samples = self.sample(x, w, num_samples=num_samples, latent=latent, posterior=True)
-        mean = np.mean(samples, axis=0)
+        (reference regression.py:566-597).  The reduction over the sample axis runs on the device
+        (`gpar_sample_stats`: sequential mean, numpy-"linear" percentiles); only the n* x p results cross PCIe."""
+        samples = self._sample_device(x, w, None, True, num_samples, latent)
+        if num_samples == 1:
+            # the reference hands np.mean a single (n*, p) array here, so axis 0 is the input axis; keep that
+            samples = samples[0].cpu().numpy()
+            mean = np.mean(samples, axis=0)
+            if credible_bounds:
+                return mean, np.percentile(samples, 2.5, axis=0), np.percentile(samples, 100 - 2.5, axis=0)
+            return mean
+        stack = torch.stack(samples)
         if credible_bounds:
-            return mean, np.percentile(samples, 2.5, axis=0), np.percentile(samples, 100 - 2.5, axis=0)
-        return mean
+            mean, lower, upper = get_engine().sample_stats(stack, 2.5, 100 - 2.5)
+            return mean.cpu().numpy(), lower.cpu().numpy(), upper.cpu().numpy()
+        return get_engine().sample_stats(stack)[0].cpu().numpy()

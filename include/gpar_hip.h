@@ -173,6 +173,15 @@ int gpar_dot(const double* x, int incx, const double* y, int incy, int n, double
  * identified by (seed, offset).   [B.randn in Normal.sample] */
 int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, int ldo, void* stream);
 
+/* Monte-Carlo reduction of predict [gpar/regression.py:589-595: np.mean / np.percentile over the sample axis]:
+ * samples[s * stride + e], s < S, e < count.  mean[e] = (sum over s, in order) / S.  If lo / hi are non-null they
+ * receive the order-statistic interpolations  v[k] + g (v[k+1] - v[k])  (numpy's "linear" method, evaluated with
+ * numpy's _lerp so the result is bit-identical to np.percentile for the same (k, g)); the caller derives
+ * (k_lo, g_lo), (k_hi, g_hi) from the percentiles exactly as numpy does.  Selection is by rank counting, O(S^2)
+ * per element, S <= 65536. */
+int gpar_sample_stats(const double* samples, int S, long long count, long long stride, int k_lo, double g_lo, int k_hi,
+                      double g_hi, double* mean, double* lo, double* hi, void* stream);
+
 /* Profiling hook for bench.py: when enabled, every trailing-update SYRK launched by gpar_potrf is
  * bracketed by hipEvents on its own stream; the accumulated (launches, milliseconds, flops) can be read
  * back (this call synchronises the recorded events). */

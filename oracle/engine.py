@@ -168,6 +168,14 @@ class OracleEngine:
         self._calls += 1
         return out
 
+    def sample_stats(self, samples, q_lo=None, q_hi=None):
+        """numpy, exactly as the reference does it (regression.py:589-595)."""
+        arr = _np(samples)
+        mean = torch.from_numpy(np.mean(arr, axis=0))
+        if q_lo is None or q_hi is None:
+            return mean, None, None
+        return mean, torch.from_numpy(np.percentile(arr, q_lo, axis=0)), torch.from_numpy(np.percentile(arr, q_hi, axis=0))
+
     _deferred = None
 
     def defer_checks(self):

@@ -92,3 +92,26 @@ def test_kernel_compile_limits_and_errors():
     big = EQ().stretch(np.ones(97)).select(list(range(97)))
     with pytest.raises(ValueError):
         compile_kernel(big, 97)
+
+
+def test_percentile_index_reproduces_numpy_linear_method():
+    """Host half of gpar_sample_stats: (k, g) reproduces np.percentile's default method for every S and q the
+    regressor uses (and some it does not) - bit for bit on numpy >= 2.0, to 1e-14 in any case."""
+    import numpy as np
+
+    from gpar_amd.hip import percentile_index
+
+    def lerp(a, b, t):  # numpy's _lerp
+        d = b - a
+        return b - d * (1 - t) if t >= 0.5 else a + d * t
+
+    rng = np.random.default_rng(0)
+    for S in [1, 2, 3, 10, 40, 100, 101, 1000]:
+        v = np.sort(rng.standard_normal(S))
+        for q in [0.0, 2.5, 33.3, 50.0, 97.5, 100.0]:
+            k, g = percentile_index(S, q)
+            assert 0 <= k <= S - 1
+            mine = lerp(v[k], v[min(k + 1, S - 1)], g)
+            np.testing.assert_allclose(mine, np.percentile(v, q), rtol=1e-14, atol=1e-300)
+            if int(np.__version__.split(".")[0]) >= 2:
+                assert mine == np.percentile(v, q)

@@ -163,6 +163,27 @@ def test_randn_matches_philox_oracle(env):
     assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
 
 
+@pytest.mark.parametrize("S,shape", [(2, (5, 3)), (7, (1, 1)), (30, (40, 8)), (100, (64, 5)), (257, (300, 2))])
+def test_sample_stats_is_numpy_mean_and_percentile(env, S, shape):
+    """gpar_sample_stats vs np.mean / np.percentile (reference regression.py:589-595): bit-exact, ties included."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(S)
+    x = rng.standard_normal((S,) + shape)
+    x[S // 2] = x[0]  # exact ties between samples
+    x[:, 0, 0] = 1.25  # a constant column
+    d = torch.tensor(x, dtype=torch.float64, device=dev)
+    mean, lo, hi = hip.sample_stats(d, 2.5, 97.5)
+    assert np.array_equal(mean.cpu().numpy(), np.mean(x, axis=0))
+    assert np.array_equal(lo.cpu().numpy(), np.percentile(x, 2.5, axis=0))
+    assert np.array_equal(hi.cpu().numpy(), np.percentile(x, 97.5, axis=0))
+    for q_lo, q_hi in [(0.0, 100.0), (50.0, 50.0), (33.3, 66.6)]:
+        _, lo, hi = hip.sample_stats(d, q_lo, q_hi)
+        assert np.array_equal(lo.cpu().numpy(), np.percentile(x, q_lo, axis=0))
+        assert np.array_equal(hi.cpu().numpy(), np.percentile(x, q_hi, axis=0))
+    only_mean = hip.sample_stats(d)
+    assert only_mean[1] is None and only_mean[2] is None and np.array_equal(only_mean[0].cpu().numpy(), np.mean(x, axis=0))
+
+
 def test_small_utilities(env):
     torch, hip, dev, to_dev = env
     rng = np.random.default_rng(5)

@@ -139,6 +139,36 @@ def test_logpdf_condition_predict_match_oracle(name):
     np.testing.assert_allclose(got[2], ref[2], rtol=1e-6, atol=atol)
 
 
+def test_predict_reduction_on_device_matches_numpy_reduction():
+    """predict = device-side mean / percentiles of the same samples `sample` returns (row a10 of SURVEY section 8):
+    same seed -> the HIP reduction equals numpy's on the HIP samples bit for bit, and the oracle's to sample parity."""
+    from gpar_amd.engine import get_engine
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(150, 2, 3, seed=9)
+    xs = np.random.default_rng(4).uniform(0, 1, (33, 2))
+
+    def run():
+        reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1)
+        reg.condition(x, y)
+        get_engine().seed(123)
+        samples = np.stack(reg.sample(xs, posterior=True, num_samples=40))
+        get_engine().seed(123)
+        mean, lo, hi = reg.predict(xs, num_samples=40, credible_bounds=True)
+        get_engine().seed(123)
+        only_mean = reg.predict(xs, num_samples=40)
+        return samples, mean, lo, hi, only_mean
+
+    got = _on("hip", run)
+    assert np.array_equal(got[1], np.mean(got[0], axis=0))
+    assert np.array_equal(got[2], np.percentile(got[0], 2.5, axis=0))
+    assert np.array_equal(got[3], np.percentile(got[0], 97.5, axis=0))
+    assert np.array_equal(got[4], got[1])
+    ref = _on("oracle", run)
+    for g, r in zip(got[1:], ref[1:]):
+        np.testing.assert_allclose(g, r, rtol=1e-6, atol=1e-7)
+
+
 def test_sparse_path_matches_oracle():
     from gpar_amd.regression import GPARRegressor
 
