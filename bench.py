@@ -109,7 +109,7 @@ def main():
     value = None
     for _ in range(args.warmup):
         value = step()
-    lib.gpar_profile_read(None, None, None, 1)
+    lib.gpar_profile_read(None, None, None, None, 1)
     lib.gpar_profile_enable(1)
     barrier()
     t0 = time.perf_counter()
@@ -120,8 +120,8 @@ def main():
     lib.gpar_profile_enable(0)
     import ctypes
 
-    launches, ms, flops = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
-    lib.gpar_profile_read(ctypes.byref(launches), ctypes.byref(ms), ctypes.byref(flops), 1)
+    launches, ms, busy, flops = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    lib.gpar_profile_read(ctypes.byref(launches), ctypes.byref(ms), ctypes.byref(busy), ctypes.byref(flops), 1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -147,8 +147,11 @@ def main():
             "logpdf": float(value),
         },
     }
-    if launches.value > 0 and ms.value > 0:
-        achieved = flops.value / (ms.value * 1e-3) * 1e-12
+    if launches.value > 0 and busy.value > 0:
+        # Independent layers are pipelined over two streams, so two trailing updates (of different layers) are often in
+        # flight at once and each one's own duration covers work of both.  The kernel's rate is therefore taken over the
+        # UNION of the launch intervals: flops / busy time = per-launch flops / (average launch duration / concurrency).
+        achieved = flops.value / (busy.value * 1e-3) * 1e-12
         out["roofline"] = {
             "kernel": "gpar::gemm_f64_kernel<false, true, 1> (trailing SYRK update of gpar_potrf, v_mfma_f64_4x4x4_4b)",
             "bound": "mfma",
@@ -159,33 +162,43 @@ def main():
             "traffic": pmc_traffic(n, m, p),
             "traffic_source": "profiles/r01_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)",
             "launches": launches.value,
+            "flop_per_launch": flops.value / launches.value,
             "avg_launch_ms": ms.value / launches.value,
+            "concurrency": ms.value / busy.value,
+            "busy_ms": busy.value,
             "rank": 0,
         }
 
     # The timed region overlaps the trailing SYRK of panel k with the fused factorisation of panel k+1 (look-ahead on a
-    # second stream), so the live number above is the kernel's rate WHILE SHARING the chip.  One extra, untimed
-    # evaluation with look-ahead switched off gives the same kernel's rate when it has the GPU to itself.
+    # second stream) and with the other stream's layer, so the live number above is the kernel's rate WHILE SHARING the
+    # chip.  One extra, untimed evaluation with look-ahead and layer pipelining switched off gives the same kernel's
+    # per-launch rate when it has the GPU to itself (concurrency 1: flops per launch / average launch duration).
     if True:  # every rank takes part (the evaluation contains a collective), whether or not it owns a layer
         os.environ["GPAR_POTRF_LOOKAHEAD"] = "0"
+        os.environ["GPAR_LAYER_PIPELINE"] = "0"
         try:
-            lib.gpar_profile_read(None, None, None, 1)
+            lib.gpar_profile_read(None, None, None, None, 1)
             lib.gpar_profile_enable(1)
             step()
             barrier()
             lib.gpar_profile_enable(0)
-            l2, ms2, fl2 = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
-            lib.gpar_profile_read(ctypes.byref(l2), ctypes.byref(ms2), ctypes.byref(fl2), 1)
+            l2, ms2, b2, fl2 = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            lib.gpar_profile_read(ctypes.byref(l2), ctypes.byref(ms2), ctypes.byref(b2), ctypes.byref(fl2), 1)
             if "roofline" in out and l2.value > 0 and ms2.value > 0:
                 iso = fl2.value / (ms2.value * 1e-3) * 1e-12
                 out["roofline"]["isolated"] = {"achieved": iso, "frac": iso / FP64_MATRIX_PEAK_TFLOPS, "launches": l2.value,
                                                "avg_launch_ms": ms2.value / l2.value,
-                                               "note": "same kernel, one untimed evaluation with GPAR_POTRF_LOOKAHEAD=0 (no co-running panel kernel)"}
+                                               "note": "same kernel, one untimed evaluation with GPAR_POTRF_LOOKAHEAD=0 "
+                                                       "GPAR_LAYER_PIPELINE=0 (nothing co-running): flops per launch / average launch duration"}
         finally:
             del os.environ["GPAR_POTRF_LOOKAHEAD"]
+            del os.environ["GPAR_LAYER_PIPELINE"]
         if "roofline" in out:
-            out["roofline"]["note"] = ("live value: measured inside the timed region, where the kernel co-runs with the fused panel "
-                                       "kernel of the next panel (look-ahead); see `isolated` for the kernel alone")
+            out["roofline"]["note"] = ("live value, measured inside the timed region with hipEvents on the launch streams: flops of all "
+                                       "launches / union of their intervals (`concurrency` launches are in flight on average because "
+                                       "independent layers run on two streams, and each co-runs with the next panel's factorisation); "
+                                       "`avg_launch_ms` is the plain per-launch average that `rocprofv3 --stats` reports; see `isolated` "
+                                       "for the kernel alone")
 
     if rank == 0 and not args.no_extras:
         out["fit_predict"] = fit_predict_leg(eng, x_np, y_np, n, m, p)

@@ -99,7 +99,7 @@ SIGNATURES = {
         [_ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_dbl, _c_int, _c_dbl, _ptr, _ptr, _ptr, _ptr],
     ),
     "gpar_profile_enable": (_c_int, [_c_int]),
-    "gpar_profile_read": (_c_int, [ctypes.POINTER(_c_int), ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_dbl), _c_int]),
+    "gpar_profile_read": (_c_int, [ctypes.POINTER(_c_int), ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_dbl), _c_int]),
 }
 
 _lib = None

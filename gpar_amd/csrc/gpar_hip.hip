@@ -285,12 +285,13 @@ int gpar_profile_enable(int on) {
     return 0;
 }
 
-int gpar_profile_read(int* launches, double* ms, double* flops, int reset) {
+int gpar_profile_read(int* launches, double* ms, double* busy_ms, double* flops, int reset) {
     profile_collect();
     if (launches) *launches = g_prof.launches;
     if (ms) *ms = g_prof.ms_done;
+    if (busy_ms) *busy_ms = g_prof.ms_busy;
     if (flops) *flops = g_prof.flops;
-    if (reset) { g_prof.launches = 0; g_prof.ms_done = 0.0; g_prof.flops = 0.0; }
+    if (reset) { g_prof.launches = 0; g_prof.ms_done = 0.0; g_prof.ms_busy = 0.0; g_prof.flops = 0.0; }
     return 0;
 }
 

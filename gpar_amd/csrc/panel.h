@@ -397,4 +397,64 @@ static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* l
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused block of the forward triangular solve  X L^T = B  (gpar_trsm_rlt): ONE launch carries a 64-row block of B
+// through S consecutive 64-column steps of L - strip solve against L_ss, then the rank-64 updates of the block's
+// remaining columns - instead of S strip launches + (S - 1) GEMM launches.  Row blocks are independent, so unlike
+// the panel factorisation there are no hand-offs between workgroups: it is the panel kernel's strip / update code
+// with the diagonal factorisation and the flags removed.
+struct TrsmBlockArgs {
+    const double* L;   // n x n lower-triangular factor (strict upper triangle never read)
+    int n, ldl;
+    double* B;         // nrows x n right-hand sides, overwritten by X
+    int nrows, ldb;
+    int c0, S;         // columns [c0, c0 + 64 S)
+    int upper_tri;     // B is upper triangular on entry: row r has nothing left of column r -> whole steps are skipped
+};
+
+__global__ __launch_bounds__(256) void trsm_block_kernel(TrsmBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    double* Cs = psm;
+    double* Xs = psm + PNL_TILE;
+    double* Bs = psm;
+    double* rinvs = psm + 2 * PNL_TILE;
+    double* Tw = psm + 2 * PNL_TILE + 64 + (threadIdx.x >> 6) * 4 * PNL_LDT;
+    const int t = threadIdx.x;
+    const int r0 = 64 * blockIdx.x;
+    const PanelArgs pL{const_cast<double*>(a.L), a.n, a.ldl, 0, 0, nullptr, nullptr, nullptr};
+    const PanelArgs pB{a.B, a.nrows, a.ldb, 0, 0, nullptr, nullptr, nullptr};
+    for (int s = 0; s < a.S; ++s) {
+        const int cs = a.c0 + 64 * s;
+        if (a.upper_tri && r0 >= cs + 64) continue;   // these rows are still zero in every column <= cs + 63
+        __syncthreads();                              // previous step done with Xs / Bs
+        pnl_load_tile(pL, cs, cs, Cs, t);
+        pnl_load_tile(pB, r0, cs, Xs, t);
+        __syncthreads();
+        if (t < 64) rinvs[t] = 1.0 / Cs[t * PNL_LD + t];
+        __syncthreads();
+        pnl_strip(Cs, Xs, rinvs, t);
+        __syncthreads();
+        pnl_store_tile(pB, r0, cs, Xs, t, false, false);
+        for (int c = s + 1; c < a.S; ++c) {
+            __syncthreads();                          // strip / earlier update done with the Cs = Bs tile
+            pnl_load_tile(pL, a.c0 + 64 * c, cs, Bs, t);
+            __syncthreads();
+            pnl_update(pB, r0, a.c0 + 64 * c, Xs, Bs, Tw, t, false);
+        }
+    }
+}
+
+static int trsm_block_fused(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
+                            hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS_BYTES);
+        attr_done = true;
+    }
+    TrsmBlockArgs a{L, n, ldl, B, nrows, ldb, c0, S, upper_tri};
+    hipLaunchKernelGGL(trsm_block_kernel, dim3(gpar_ceil_div(nrows, 64)), dim3(256), PNL_LDS_BYTES, stream, a);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace gpar

@@ -11,6 +11,9 @@
 #include "common.h"
 #include "gemm_f64.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <utility>
+#include <vector>
 
 namespace gpar {
 
@@ -215,7 +218,8 @@ struct ProfileState {
     bool on = false;
     int launches = 0;
     double flops = 0.0;
-    double ms_done = 0.0;
+    double ms_done = 0.0;    // sum of the launches' own durations
+    double ms_busy = 0.0;    // union of their intervals (launches issued from different streams may overlap)
     static constexpr int MAXEV = 4096;
     hipEvent_t ev[MAXEV][2];
     int nev = 0;
@@ -224,12 +228,24 @@ struct ProfileState {
 static ProfileState g_prof;
 
 static void profile_collect() {
+    if (g_prof.nev == 0) return;
+    std::vector<std::pair<float, float>> iv(g_prof.nev);
+    hipEventSynchronize(g_prof.ev[0][0]);
     for (int i = 0; i < g_prof.nev; ++i) {
-        float ms = 0.f;
+        float t0 = 0.f, t1 = 0.f;
         hipEventSynchronize(g_prof.ev[i][1]);
-        hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]);
-        g_prof.ms_done += ms;
+        hipEventElapsedTime(&t0, g_prof.ev[0][0], g_prof.ev[i][0]);
+        hipEventElapsedTime(&t1, g_prof.ev[0][0], g_prof.ev[i][1]);
+        g_prof.ms_done += t1 - t0;
+        iv[i] = {t0, t1};
     }
+    std::sort(iv.begin(), iv.end());
+    float cs = iv[0].first, ce = iv[0].second;
+    for (size_t i = 1; i < iv.size(); ++i) {
+        if (iv[i].first > ce) { g_prof.ms_busy += ce - cs; cs = iv[i].first; ce = iv[i].second; }
+        else if (iv[i].second > ce) ce = iv[i].second;
+    }
+    g_prof.ms_busy += ce - cs;
     g_prof.nev = 0;
 }
 
@@ -329,12 +345,20 @@ static int potrf_panel_split(const PotrfCtx& c, int k0, int kend, int nb, hipStr
     return rc;
 }
 
+// defined in panel.h (one launch per 64-row block of B for up to 8 column steps)
+static int trsm_block_fused(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
+                            hipStream_t stream);
 // defined in panel.h (one persistent launch per panel)
 static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream);
 
 struct LookaheadState {
-    hipStream_t side = nullptr;
-    static constexpr int MAXE = 1024;
+    // one low-priority side stream per caller stream (callers that pipeline independent layers over two or three
+    // streams must not have their trailing updates queued behind one another on a shared side stream)
+    static constexpr int MAXS = 8;
+    hipStream_t caller[MAXS];
+    hipStream_t side[MAXS];
+    int nside = 0;
+    static constexpr int MAXE = 4096;
     hipEvent_t ev[MAXE];
     int nev = 0;
     bool ok = false;
@@ -342,19 +366,32 @@ struct LookaheadState {
 static LookaheadState g_la;
 
 static hipEvent_t la_event() {
-    if (g_la.nev >= LookaheadState::MAXE) g_la.nev = 0;   // ring: far more than one factorisation's worth in flight
+    if (g_la.nev >= LookaheadState::MAXE) g_la.nev = 0;   // ring: far more than a few factorisations' worth in flight
     return g_la.ev[g_la.nev++];
 }
 
 static bool la_init() {
     if (g_la.ok) return true;
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least urgent
-    if (hipStreamCreateWithPriority(&g_la.side, hipStreamNonBlocking, lo) != hipSuccess) return false;
     for (int i = 0; i < LookaheadState::MAXE; ++i)
         if (hipEventCreateWithFlags(&g_la.ev[i], hipEventDisableTiming) != hipSuccess) return false;
     g_la.ok = true;
     return true;
+}
+
+// Side stream paired with `caller`: lowest priority, non-blocking (a blocking stream would serialise with the null
+// stream: tools/probe_queue_concurrency2.hip).  Returns nullptr when the table is full (look-ahead is then skipped).
+static hipStream_t la_side(hipStream_t caller) {
+    for (int i = 0; i < g_la.nside; ++i)
+        if (g_la.caller[i] == caller) return g_la.side[i];
+    if (g_la.nside >= LookaheadState::MAXS) return nullptr;
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least urgent
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+    g_la.caller[g_la.nside] = caller;
+    g_la.side[g_la.nside] = s;
+    ++g_la.nside;
+    return s;
 }
 
 static void prof_begin(hipStream_t s, bool& active) {
@@ -384,7 +421,8 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     const PotrfPolicy pol = potrf_policy(N);
     PotrfCtx c{A, N, lda, logdet, info, pol.nbm};
     const int nbo = pol.nbo;
-    const bool la = pol.lookahead && nf > nbo && la_init();
+    hipStream_t side = (pol.lookahead && nf > nbo && la_init()) ? la_side(stream) : nullptr;
+    const bool la = side != nullptr;
     hipEvent_t trail_done = nullptr;   // completion of the side-stream update issued in the previous step
     for (int k0 = 0, knext = 0; k0 < nf; k0 = knext) {
         int kend = (k0 + nbo < nf) ? k0 + nbo : nf;
@@ -415,20 +453,20 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         rc = potrf_gemm_update(c, k0, kend, next_end, stream);
         if (rc) return rc;
         // (2) everything to the right of the next panel, on the side stream
-        hipStreamWaitEvent(g_la.side, panel_done, 0);
+        hipStreamWaitEvent(side, panel_done, 0);
         {
             const int rows = N - next_end, cols = N - next_end;
             if (rows > 0) {
                 const double* P = A + (size_t)next_end * lda + k0;
-                prof_begin(g_la.side, pa);
+                prof_begin(side, pa);
                 rc = gemm_launch(0, 1, rows, cols, kend - k0, -1.0, P, lda, P, lda, 1.0, A + (size_t)next_end * lda + next_end,
-                                 lda, GPAR_GEMM_C_LOWER, g_la.side, 1);
-                prof_end(g_la.side, pa, rows, cols, kend - k0);
+                                 lda, GPAR_GEMM_C_LOWER, side, 1);
+                prof_end(side, pa, rows, cols, kend - k0);
                 if (rc) return rc;
             }
         }
         trail_done = la_event();
-        hipEventRecord(trail_done, g_la.side);
+        hipEventRecord(trail_done, side);
     }
     if (trail_done) hipStreamWaitEvent(stream, trail_done, 0);   // join
     GPAR_LAUNCH_CHECK();
@@ -449,17 +487,25 @@ static int trsm_rlt_run(const double* L, int n, int ldl, double* B, int nrows, i
 static int trsm_rlt_run2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int upper_tri, hipStream_t stream) {
     if (nrows <= 0) return 0;
     const int NB = n >= 4096 ? 512 : (n >= 1024 ? 256 : 64);
-    for (int c0 = 0; c0 < n; c0 += NB) {
-        const int c1 = (c0 + NB < n) ? c0 + NB : n;
+    const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && NB > 64 && gpar_aligned16(L) && gpar_aligned16(B) && (ldl % 2 == 0) && (ldb % 2 == 0);
+    for (int c0 = 0, c1 = 0; c0 < n; c0 = c1) {
+        c1 = (c0 + NB < n) ? c0 + NB : n;
+        // a ragged tail (n not a multiple of 64) becomes its own narrow block so the wide part stays fusable
+        if (fusable && (c1 - c0) > 64 && (c1 - c0) % 64 != 0) c1 = c0 + (c1 - c0) / 64 * 64;
         const int rows = upper_tri ? (nrows < c1 ? nrows : c1) : nrows;
-        for (int c = c0; c < c1; c += POTRF_NBI) {
-            const int cb = (c1 - c < POTRF_NBI) ? c1 - c : POTRF_NBI;
-            launch_strip<true>(L + (size_t)c * ldl + c, ldl, cb, B + c, ldb, rows, stream);
-            const int rest = c1 - (c + cb);
-            if (rest > 0) {
-                int rc = gemm_launch(0, 1, rows, rest, cb, -1.0, B + c, ldb, L + (size_t)(c + cb) * ldl + c, ldl, 1.0,
-                                     B + c + cb, ldb, 0, stream);
-                if (rc) return rc;
+        if (fusable && (c1 - c0) % 64 == 0 && (c1 - c0) > 64) {
+            int rc = trsm_block_fused(L, n, ldl, B, rows, ldb, c0, (c1 - c0) / 64, upper_tri, stream);
+            if (rc) return rc;
+        } else {
+            for (int c = c0; c < c1; c += POTRF_NBI) {
+                const int cb = (c1 - c < POTRF_NBI) ? c1 - c : POTRF_NBI;
+                launch_strip<true>(L + (size_t)c * ldl + c, ldl, cb, B + c, ldb, rows, stream);
+                const int rest = c1 - (c + cb);
+                if (rest > 0) {
+                    int rc = gemm_launch(0, 1, rows, rest, cb, -1.0, B + c, ldb, L + (size_t)(c + cb) * ldl + c, ldl, 1.0,
+                                         B + c + cb, ldb, 0, stream);
+                    if (rc) return rc;
+                }
             }
         }
         if (c1 < n) {

@@ -21,6 +21,9 @@ Primitive set (all tensors float64, row-major, lower triangles authoritative):
     randn(rows, cols)                 counter-based standard normals
     sample_stats(samples, qlo, qhi)   Monte-Carlo mean / percentiles over the sample axis
 """
+import contextlib
+import os
+
 import torch
 
 from . import _lib, hip
@@ -51,6 +54,7 @@ class HipEngine:
         self._seed = int(seed)
         self._calls = 0
         self._deferred = None  # list of pending device-side info words while a defer_checks() block is open
+        self._pipe_streams = []  # streams of pipeline(), created on first use
 
     # ---- memory ----------------------------------------------------------------------------------
     def tensor(self, x):
@@ -137,6 +141,20 @@ class HipEngine:
         """(mean, lo-percentile, hi-percentile) over the leading (sample) axis, on the device."""
         return hip.sample_stats(samples.contiguous(), q_lo, q_hi)
 
+    # ---- layer pipelining ------------------------------------------------------------------------
+    def pipeline(self, depth=None):
+        """Streams for layers that do not depend on one another (complete data, no `replace`, no inducing points):
+        the tail of a blocked factorisation is a latency-bound chain of small panels that leaves most of the chip
+        idle, the front of the next one is throughput-bound - on alternating streams the two overlap.  Returns None
+        when disabled (GPAR_LAYER_PIPELINE=0)."""
+        if depth is None:
+            depth = int(os.environ.get("GPAR_LAYER_PIPELINE", "2"))  # 0 / 1 disable
+        if depth < 2:
+            return None
+        if len(self._pipe_streams) < depth:
+            self._pipe_streams += [torch.cuda.Stream(device=self.device) for _ in range(depth - len(self._pipe_streams))]
+        return _LayerPipeline(self, self._pipe_streams[:depth])
+
     # ---- status ----------------------------------------------------------------------------------
     def defer_checks(self):
         """Context manager: inside it `check_info` only records the device-side info words (no host sync), so a
@@ -159,6 +177,38 @@ class HipEngine:
             raise RuntimeError(f"gpar_potrf: device-side hand-off timed out (code {code}); is another kernel holding the CUs?")
         if code != 0:
             raise NotPositiveDefiniteError(code)
+
+
+class _LayerPipeline:
+    """`with pipe.stage(i, *inputs): ...` runs the block on stream i mod depth after everything enqueued on the
+    caller's stream so far; `inputs` (tensors allocated on the caller's stream that the block reads) are kept alive
+    until `join()`, which makes the caller's stream wait for every stage.  Tensors created inside a stage belong to
+    that stage's stream (torch's caching allocator is stream-aware) and may be used by the caller after `join()`."""
+
+    def __init__(self, engine, streams):
+        self.main = torch.cuda.current_stream(engine.device)
+        self.streams = streams
+        self.keep = []
+        self.used = []
+
+    @contextlib.contextmanager
+    def stage(self, i, *inputs):
+        s = self.streams[i % len(self.streams)]
+        s.wait_stream(self.main)
+        self.keep.extend(inputs)
+        if s not in self.used:
+            self.used.append(s)
+        with torch.cuda.stream(s):
+            yield
+
+    def keep_alive(self, *tensors):
+        self.keep.extend(tensors)
+
+    def join(self):
+        for s in self.used:
+            self.main.wait_stream(s)
+        self.keep = []
+        self.used = []
 
 
 class _Deferred:

@@ -70,6 +70,13 @@ def last(xs, select=None):
         yield True, current
 
 
+def _differentiable(f, noise):
+    """Does the layer's log-likelihood take part in an autograd graph (the objective of `fit`)?"""
+    from .gp import kernel_parameters
+
+    return (_is_torch(noise) and noise.requires_grad) or bool(kernel_parameters(f.kernel))
+
+
 def per_output(y, w=None, keep=False):
     """Per layer: `(y_i (n_i x 1), w_i (n_i,), mask_i)` where `mask_i` selects, among the rows that survived
     layer i-1, those observed at output i (or, with `keep`, at any later output: rows needed to keep the data
@@ -163,12 +170,27 @@ class GPAR:
         x, y, w = self._prep(x, y, w)
         x_ind = self._prep_ind(self.x_ind if x_ind is None else x_ind)
         total = torch.zeros((), dtype=torch.float64)
-        items = per_output(y, w, keep=self.impute or sample_missing)
-        with get_engine().defer_checks():
+        items = list(per_output(y, w, keep=self.impute or sample_missing))
+        eng = get_engine()
+        # layers that do not feed one another (observed data only) are spread over alternating streams
+        pipe = eng.pipeline() if self._independent(items) and not return_inputs else None
+        values, stage = [], 0
+        with eng.defer_checks():
             for is_last, ((yi, wi, mask), model) in last(zip(items, self.layers), select=outputs):
                 complete = isinstance(mask, slice)
                 x = x[mask]
                 f, noise = model()
+                if pipe is not None and _differentiable(f, noise):
+                    pipe.join()
+                    pipe = None  # an objective under autograd: keep everything on the caller's stream
+                if pipe is not None:
+                    if not only_last_layer or is_last:
+                        with pipe.stage(stage, x, yi, wi):
+                            values.append(f.measure.logpdf(self._obs(x, x_ind, yi, wi, f, noise, complete=True)))
+                        stage += 1
+                    if not is_last:
+                        x = torch.cat([x, yi], dim=1)
+                    continue
                 obs = self._obs(x, x_ind, yi, wi, f, noise, complete=complete)
                 if not only_last_layer or is_last:
                     total = total + f.measure.logpdf(obs)
@@ -180,9 +202,19 @@ class GPAR:
                             drawn = f_post(x[missing], self._noise_over(noise, wi[missing])).sample()
                             yi = merge(yi, drawn, missing)
                     x, x_ind = self._update_inputs(x, x_ind, yi, f, obs, complete=complete)
+            if pipe is not None:
+                pipe.join()
+            for v in values:
+                total = total + v
         if return_inputs:
             return x, x_ind
         return total.cpu() if total.is_cuda and not total.requires_grad else total
+
+    def _independent(self, items):
+        """No layer needs anything a previous layer computes: complete data (slice masks), no `replace`, no
+        inducing points - the design matrix of layer i is just [x, y_<i]."""
+        return (not self.replace and not self.sparse and len(items) > 1
+                and all(isinstance(mask, slice) for _, _, mask in items))
 
     # ---- sampling ----------------------------------------------------------------------------------
     def sample(self, x, w, latent=False):

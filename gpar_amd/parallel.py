@@ -57,15 +57,29 @@ def sharded_logpdf(gpar, x, y, w, group=None):
 
 
 def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
-    for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(per_output(y, w, keep=gpar.impute), gpar.layers))):
+    from .model import _differentiable
+
+    items = list(per_output(y, w, keep=gpar.impute))
+    # this rank's layers alternate over two streams when no layer feeds another (see HipEngine.pipeline)
+    pipe = get_engine().pipeline() if gpar._independent(items) else None
+    values, stage = [], 0
+    for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, gpar.layers))):
         complete = isinstance(mask, slice)
         x = x[mask]
         mine = (i % size) == rank
         f = obs = None
         if mine:
             f, noise = model()
-            obs = gpar._obs(x, x_ind, yi, wi, f, noise, complete=complete)
-            local = local + f.measure.logpdf(obs)
+            if pipe is not None and _differentiable(f, noise):
+                pipe.join()
+                pipe = None
+            if pipe is not None:
+                with pipe.stage(stage, x, yi, wi):
+                    values.append(f.measure.logpdf(gpar._obs(x, x_ind, yi, wi, f, noise, complete=True)))
+                stage += 1
+            else:
+                obs = gpar._obs(x, x_ind, yi, wi, f, noise, complete=complete)
+                local = local + f.measure.logpdf(obs)
         if is_last:
             break
         if not _needs_estimate(gpar, yi, complete):
@@ -87,6 +101,10 @@ def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
         x = torch.cat([x, col], dim=1)
         if ind_col is not None:
             x_ind = torch.cat([x_ind, ind_col], dim=1)
+    if pipe is not None:
+        pipe.join()
+    for v in values:
+        local = local + v
     return local, x, x_ind
 
 

@@ -183,10 +183,11 @@ int gpar_sample_stats(const double* samples, int S, long long count, long long s
                       double g_hi, double* mean, double* lo, double* hi, void* stream);
 
 /* Profiling hook for bench.py: when enabled, every trailing-update SYRK launched by gpar_potrf is
- * bracketed by hipEvents on its own stream; the accumulated (launches, milliseconds, flops) can be read
- * back (this call synchronises the recorded events). */
+ * bracketed by hipEvents on its own stream; the accumulated (launches, sum of their durations in ms, union of
+ * their intervals in ms - launches from different caller streams may overlap -, flops) can be read back (this
+ * call synchronises the recorded events). */
 int gpar_profile_enable(int on);
-int gpar_profile_read(int* launches, double* ms, double* flops, int reset);
+int gpar_profile_read(int* launches, double* ms, double* busy_ms, double* flops, int reset);
 
 #ifdef __cplusplus
 }

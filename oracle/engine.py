@@ -176,6 +176,9 @@ class OracleEngine:
             return mean, None, None
         return mean, torch.from_numpy(np.percentile(arr, q_lo, axis=0)), torch.from_numpy(np.percentile(arr, q_hi, axis=0))
 
+    def pipeline(self, depth=2):
+        return None  # one CPU, nothing to overlap
+
     _deferred = None
 
     def defer_checks(self):
