@@ -150,14 +150,27 @@ class GPAR:
         x, y, w = self._prep(*x_y_w)
         x_ind = self._prep_ind(self.x_ind)
         post = self.copy()
-        for is_last, ((yi, wi, mask), model) in last(zip(per_output(y, w, keep=self.impute), self.layers)):
-            complete = isinstance(mask, slice)
-            x = x[mask]
-            f, noise = model()
-            obs = self._obs(x, x_ind, yi, wi, f, noise, complete=complete)
-            post.layers.append(construct_model(f | obs, noise))
-            if not is_last:
-                x, x_ind = self._update_inputs(x, x_ind, yi, f, obs, complete=complete)
+        items = list(per_output(y, w, keep=self.impute))
+        eng = get_engine()
+        # Observed data only: no layer needs another's posterior, so the factorisations (otherwise done lazily, one
+        # after the other, when the posterior is first used) are issued now on alternating streams.
+        pipe = eng.pipeline() if self._independent(items) else None
+        with eng.defer_checks():
+            for stage, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, self.layers))):
+                complete = isinstance(mask, slice)
+                x = x[mask]
+                f, noise = model()
+                if pipe is not None and not _differentiable(f, noise):
+                    with pipe.stage(stage, x, yi, wi):
+                        obs = self._obs(x, x_ind, yi, wi, f, noise, complete=True)
+                        obs.factor()
+                else:
+                    obs = self._obs(x, x_ind, yi, wi, f, noise, complete=complete)
+                post.layers.append(construct_model(f | obs, noise))
+                if not is_last:
+                    x, x_ind = self._update_inputs(x, x_ind, yi, f, obs, complete=complete)
+            if pipe is not None:
+                pipe.join()
         return post
 
     # ---- log marginal likelihood -------------------------------------------------------------------

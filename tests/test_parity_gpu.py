@@ -139,6 +139,40 @@ def test_logpdf_condition_predict_match_oracle(name):
     np.testing.assert_allclose(got[2], ref[2], rtol=1e-6, atol=atol)
 
 
+def test_layer_pipeline_is_bit_identical_to_serial_evaluation(monkeypatch):
+    """Independent layers run on alternating streams (HipEngine.pipeline); values and their summation order are
+    those of the serial loop, so the result must not change by a single bit - at a size where the look-ahead path
+    (second stream inside gpar_potrf) is active too, so three kinds of concurrency are in play."""
+    from gpar_amd.model import GPAR
+    from gpar_amd.parallel import sharded_logpdf
+    from gpar_amd.regression import GPARRegressor, _construct_gpar
+
+    x, y = _problem(7300, 3, 5, seed=21)
+
+    def run():
+        import torch
+
+        from gpar_amd.engine import get_engine
+
+        reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1)
+        out = {}
+        for depth in ["0", "2", "3"]:
+            monkeypatch.setenv("GPAR_LAYER_PIPELINE", depth)
+            out[depth] = float(reg.logpdf(x, y))
+        eng = get_engine()
+        gpar = _construct_gpar(reg, reg.vs, 3, 5)
+        xd, yd = eng.tensor(x), eng.tensor(y)  # an unconditioned regressor applies identity transforms
+        for depth in ["0", "2"]:
+            monkeypatch.setenv("GPAR_LAYER_PIPELINE", depth)
+            out["sharded" + depth] = float(sharded_logpdf(gpar, xd, yd, torch.ones_like(yd)))
+        assert isinstance(gpar, GPAR)
+        return out
+
+    got = _on("hip", run)
+    assert got["0"] == got["2"] == got["3"], got
+    assert got["sharded0"] == got["sharded2"] == got["0"], got
+
+
 def test_predict_reduction_on_device_matches_numpy_reduction():
     """predict = device-side mean / percentiles of the same samples `sample` returns (row a10 of SURVEY section 8):
     same seed -> the HIP reduction equals numpy's on the HIP samples bit for bit, and the oracle's to sample parity."""
