@@ -4,7 +4,7 @@ symbol (gemm_f64_kernel<false, true, 1>).
 
 Corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: counter values are KiB; on gfx950 FETCH_SIZE reports
 half the bytes of a wide coalesced streaming read, so the read side is doubled (exact for the 16-byte operand
-streams, an upper bound for the 8-byte read-modify-write of C whose width is uncalibrated); WRITE_SIZE as reported.
+streams and, since the epilogue transposes through LDS, for the 16-byte read-modify-write of C); WRITE_SIZE as reported.
 
     python tools/pmc_traffic.py gpurun_out/pmc_bench_FETCH_SIZE gpurun_out/pmc_bench_WRITE_SIZE > profiles/r01_bench_pmc_traffic.json
 """
@@ -31,7 +31,7 @@ def main():
         "fetch_bytes_per_launch_x2_corrected": fetch_b, "fetch_bytes_per_launch_raw": fetch_b / 2,
         "write_bytes_per_launch": write_b,
         "traffic_bytes_per_launch": fetch_b + write_b,
-        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (exact for 16-byte coalesced streams; the 8-byte epilogue reads are uncalibrated), WRITE_SIZE as reported",
+        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (calibrated for 16-byte coalesced streams, which operands and C now both are), WRITE_SIZE as reported",
     }, indent=1))
 
 
