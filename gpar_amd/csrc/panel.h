@@ -298,8 +298,9 @@ __global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
     const int R = (p.N - p.k0 + 63) / 64;   // row blocks below (and including) the panel's first row
     const int S = p.S;
     // Under look-ahead this latency-bound kernel shares every CU with a trailing-update workgroup whose waves issue
-    // fp64 MFMAs back to back on the same double-precision pipes: at equal priority the serial pivot chain ran 3-4x
-    // slower than alone (tools/time_panel.hip).  Its waves are few and mostly waiting, so they take issue priority.
+    // fp64 MFMAs back to back on the same double-precision pipes, and its serial pivot chain runs ~3x slower than alone
+    // (tools/time_panel.hip).  Raised issue priority is kept because these few, mostly waiting waves should never lose an
+    // arbitration - but measured it changes little: an MFMA that has issued holds the pipe for its 16 cycles regardless.
     __builtin_amdgcn_s_setprio(3);
     if (p.stamps && t == 0) p.stamps[64 + g] = (long long)__builtin_amdgcn_s_memrealtime();   // dev aid: arrival (100 MHz wall clock)
 
