@@ -172,7 +172,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     // XCD a contiguous run of tiles so neighbouring tiles (shared operand panels) hit the same L2.
     const long long t_start = p.stamps ? (long long)__builtin_readcyclecounter() : 0;
     int idx;
-    {
+    if (p.flags & (GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_A_LOWER)) {
+        // tiles differ in K length by up to n / 128 x (long ones first in the enumeration): contiguous runs per XCD would
+        // hand one XCD all the long tiles (the triangular-aware inverse ran at 28 TF that way); deal them round-robin
+        idx = blockIdx.x;
+    } else {
         const int nb = gridDim.x, b = blockIdx.x;
         const int xcd = b & 7, q = nb >> 3, r = nb & 7;
         idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
