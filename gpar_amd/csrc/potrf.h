@@ -535,10 +535,112 @@ static int chol_inverse_run(const double* L, int n, int ldl, double* X, int ldx,
     return gemm_launch(0, 1, n, n, n, 1.0, X, ldx, X, ldx, 0.0, Kinv, ldk, GPAR_GEMM_C_LOWER | GPAR_GEMM_K_FROM_ROW, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// x L = b for ONE row vector (alpha^T = z^T L^-1, gpar/model.py:298-301 via stheno's posterior mean): backward
+// substitution.  The general path (64-row strips + GEMMs) spends 2 launches per 64 columns on a single row: 512
+// dependent launches, 9.6 ms at n = 16384 for 1 GB of reads.  Here: column blocks of 512 from last to first, one
+// single-workgroup kernel per block (64-wide triangular solves by one wave, lanes = columns, pivots broadcast by
+// v_readlane; in-block updates spread over the four waves) and one memory-bound GEMV-shaped update of everything
+// to the left of the block (one 64-column slice per workgroup, the 512 rows split over its waves).
+constexpr int TRSV_NB = 512;
+constexpr int TRSV_LD = 65;
+
+__global__ __launch_bounds__(256) void trsv_block_kernel(const double* __restrict__ L, int ldl, double* __restrict__ b, int c0, int c1) {
+    __shared__ double xb[TRSV_NB];
+    __shared__ double Ls[64 * TRSV_LD];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int W = c1 - c0;
+    for (int i = t; i < W; i += 256) xb[i] = b[c0 + i];
+    const int nsub = (W + 63) / 64;
+    for (int s = nsub - 1; s >= 0; --s) {
+        const int cs = c0 + 64 * s;
+        const int cb = (c1 - cs < 64) ? c1 - cs : 64;
+        __syncthreads();   // xb settled (initial fill / previous update), Ls free
+        // L_ss (lower part is all that is used) -> LDS, rows contiguous; clamped addresses, no branches around loads
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = t + 256 * q, i = e >> 6, j = e & 63;
+            const int ic = i < cb ? i : cb - 1, jc = j < cb ? j : cb - 1;
+            Ls[i * TRSV_LD + j] = L[(size_t)(cs + ic) * ldl + cs + (jc <= ic ? jc : ic)];
+        }
+        __syncthreads();
+        if (w == 0) {
+            double bj = lane < cb ? xb[64 * s + lane] : 0.0;
+            const double rinv = 1.0 / Ls[(lane < cb ? lane : 0) * TRSV_LD + (lane < cb ? lane : 0)];
+            double xval = 0.0;
+            for (int j = cb - 1; j >= 0; --j) {
+                const double xj = gpar_readlane_f64(bj * rinv, j);
+                if (lane == j) xval = xj;
+                const double lj = Ls[j * TRSV_LD + lane];   // L[j][lane], needed for lane < j
+                if (lane < j) bj = fma(-xj, lj, bj);
+            }
+            if (lane < cb) xb[64 * s + lane] = xval;
+        }
+        __syncthreads();
+        // b_c -= x_s L[s-block][c-block] for the sub-blocks to the left, inside this 512-column block
+        for (int c = w; c < s; c += 4) {
+            const double* Lp = L + (size_t)cs * ldl + c0 + 64 * c + lane;
+            // all 64 loads are in flight before the first is used (a rolled loop waits out a memory round trip per
+            // iteration); rows beyond cb are read from a clamped address and multiplied by zero
+            double lv[64];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) lv[i] = Lp[(size_t)(i < cb ? i : cb - 1) * ldl];
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < 64; ++i) acc[i & 3] = fma(i < cb ? xb[64 * s + i] : 0.0, lv[i], acc[i & 3]);
+            xb[64 * c + lane] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < W; i += 256) b[c0 + i] = xb[i];
+}
+
+__global__ __launch_bounds__(256) void trsv_update_kernel(const double* __restrict__ L, int ldl, double* __restrict__ b, int c0, int c1) {
+    __shared__ double xs[TRSV_NB];
+    __shared__ double part[4][64];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int W = c1 - c0;
+    for (int i = t; i < W; i += 256) xs[i] = b[c0 + i];
+    __syncthreads();
+    const int j = 64 * blockIdx.x + lane;
+    const int jc = j < c0 ? j : c0 - 1;
+    const int kw = (W + 3) / 4, k0 = w * kw, k1 = (k0 + kw < W) ? k0 + kw : W;
+    const double* Lp = L + (size_t)c0 * ldl + jc;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int kb = k0; kb < k1; kb += 32) {
+        double lv[32];   // 32 loads in flight per lane
+#pragma unroll
+        for (int i = 0; i < 32; ++i) lv[i] = Lp[(size_t)(kb + i < k1 ? kb + i : k1 - 1) * ldl];
+#pragma unroll
+        for (int i = 0; i < 32; i += 4) {
+            a0 = fma(kb + i < k1 ? xs[kb + i] : 0.0, lv[i], a0);
+            a1 = fma(kb + i + 1 < k1 ? xs[kb + i + 1] : 0.0, lv[i + 1], a1);
+            a2 = fma(kb + i + 2 < k1 ? xs[kb + i + 2] : 0.0, lv[i + 2], a2);
+            a3 = fma(kb + i + 3 < k1 ? xs[kb + i + 3] : 0.0, lv[i + 3], a3);
+        }
+    }
+    part[w][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (w == 0 && j < c0) b[j] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+static int trsv_rln_run(const double* L, int n, int ldl, double* b, hipStream_t stream) {
+    const int nblk = gpar_ceil_div(n, TRSV_NB);
+    for (int blk = nblk - 1; blk >= 0; --blk) {
+        const int c0 = blk * TRSV_NB;
+        const int c1 = (c0 + TRSV_NB < n) ? c0 + TRSV_NB : n;
+        hipLaunchKernelGGL(trsv_block_kernel, dim3(1), dim3(256), 0, stream, L, ldl, b, c0, c1);
+        if (c0 > 0) hipLaunchKernelGGL(trsv_update_kernel, dim3(gpar_ceil_div(c0, 64)), dim3(256), 0, stream, L, ldl, b, c0, c1);
+    }
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
 // B <- B L^-1 : backward over column blocks.  B[:, c:c+cb] solved against L_cc, then
 // B[:, :c] -= X_c L[c:c+cb, :c]  (NN GEMM, K = cb)
 static int trsm_rln_run(const double* L, int n, int ldl, double* B, int nrows, int ldb, hipStream_t stream) {
     if (nrows <= 0) return 0;
+    if (nrows == 1 && n >= 128 && env_int("GPAR_TRSV", 1)) return trsv_rln_run(L, n, ldl, B, stream);
     const int nblk = gpar_ceil_div(n, POTRF_NBI);
     for (int b = nblk - 1; b >= 0; --b) {
         const int c = b * POTRF_NBI;

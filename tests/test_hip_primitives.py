@@ -151,6 +151,19 @@ def test_trsm(env, n, rows):
     assert np.allclose(X, scipy.linalg.solve_triangular(L, B.T, lower=True, trans="T").T, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("n", [128, 130, 511, 512, 513, 1090, 1700])
+def test_single_row_backward_solve_takes_the_trsv_path(env, n):
+    """alpha^T = z^T L^-1 for one row (gpar_trsm_rln with nrows = 1, n >= 128) runs the dedicated TRSV kernels:
+    ragged last block, ragged 64-column sub-block, poisoned upper triangle."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    L = np.linalg.cholesky(_spd(rng, n))
+    b = rng.standard_normal((1, n))
+    dL = to_dev(L + np.triu(np.full((n, n), np.nan), 1))
+    x = hip.trsm_rln_(dL, to_dev(b)).cpu().numpy()
+    assert np.allclose(x, scipy.linalg.solve_triangular(L, b.T, lower=True, trans="T").T, rtol=1e-9, atol=1e-11)
+
+
 def test_randn_matches_philox_oracle(env):
     torch, hip, dev, to_dev = env
     from oracle import philox
