@@ -56,8 +56,8 @@ def c3_regressor():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--m", type=int, default=4)
     ap.add_argument("--p", type=int, default=8)
