@@ -57,50 +57,51 @@ def sharded_logpdf(gpar, x, y, w, group=None):
 
 
 def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
-    from .model import _differentiable
+    from .model import _differentiable, _joining
 
     items = list(per_output(y, w, keep=gpar.impute))
     # this rank's layers alternate over two streams when no layer feeds another (see HipEngine.pipeline)
     pipe = get_engine().pipeline() if gpar._independent(items) else None
     values, stage = [], 0
-    for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, gpar.layers))):
-        complete = isinstance(mask, slice)
-        x = x[mask]
-        mine = (i % size) == rank
-        f = obs = None
-        if mine:
-            f, noise = model()
-            if pipe is not None and _differentiable(f, noise):
-                pipe.join()
-                pipe = None
-            if pipe is not None:
-                with pipe.stage(stage, x, yi, wi):
-                    values.append(f.measure.logpdf(gpar._obs(x, x_ind, yi, wi, f, noise, complete=True)))
-                stage += 1
-            else:
-                obs = gpar._obs(x, x_ind, yi, wi, f, noise, complete=complete)
-                local = local + f.measure.logpdf(obs)
-        if is_last:
-            break
-        if not _needs_estimate(gpar, yi, complete):
-            x = torch.cat([x, yi], dim=1)  # observed data: already on every rank
-            continue
-        # dependent chain: the owner computes the forwarded column(s), everyone else receives them
-        n_i = x.shape[0]
-        col = torch.empty(n_i, 1, dtype=torch.float64, device=x.device)
-        ind_col = None if x_ind is None else torch.empty(x_ind.shape[0], 1, dtype=torch.float64, device=x.device)
-        if mine:
-            x_new, x_ind_new = gpar._update_inputs(x, x_ind, yi, f, obs, complete=complete)
-            col.copy_(x_new[:, -1:])
+    with _joining(pipe):
+        for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, gpar.layers))):
+            complete = isinstance(mask, slice)
+            x = x[mask]
+            mine = (i % size) == rank
+            f = obs = None
+            if mine:
+                f, noise = model()
+                if pipe is not None and _differentiable(f, noise):
+                    pipe.join()
+                    pipe = None
+                if pipe is not None:
+                    with pipe.stage(stage, x, yi, wi):
+                        values.append(f.measure.logpdf(gpar._obs(x, x_ind, yi, wi, f, noise, complete=True)))
+                    stage += 1
+                else:
+                    obs = gpar._obs(x, x_ind, yi, wi, f, noise, complete=complete)
+                    local = local + f.measure.logpdf(obs)
+            if is_last:
+                break
+            if not _needs_estimate(gpar, yi, complete):
+                x = torch.cat([x, yi], dim=1)  # observed data: already on every rank
+                continue
+            # dependent chain: the owner computes the forwarded column(s), everyone else receives them
+            n_i = x.shape[0]
+            col = torch.empty(n_i, 1, dtype=torch.float64, device=x.device)
+            ind_col = None if x_ind is None else torch.empty(x_ind.shape[0], 1, dtype=torch.float64, device=x.device)
+            if mine:
+                x_new, x_ind_new = gpar._update_inputs(x, x_ind, yi, f, obs, complete=complete)
+                col.copy_(x_new[:, -1:])
+                if ind_col is not None:
+                    ind_col.copy_(x_ind_new[:, -1:])
+            if size > 1:
+                dist.broadcast(col, src=_global_rank(i % size, group), group=group)
+                if ind_col is not None:
+                    dist.broadcast(ind_col, src=_global_rank(i % size, group), group=group)
+            x = torch.cat([x, col], dim=1)
             if ind_col is not None:
-                ind_col.copy_(x_ind_new[:, -1:])
-        if size > 1:
-            dist.broadcast(col, src=_global_rank(i % size, group), group=group)
-            if ind_col is not None:
-                dist.broadcast(ind_col, src=_global_rank(i % size, group), group=group)
-        x = torch.cat([x, col], dim=1)
-        if ind_col is not None:
-            x_ind = torch.cat([x_ind, ind_col], dim=1)
+                x_ind = torch.cat([x_ind, ind_col], dim=1)
     if pipe is not None:
         pipe.join()
     for v in values:

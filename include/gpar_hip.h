@@ -21,10 +21,13 @@
  *     hand-off flags of its persistent panel kernel there (two rows of 56 words per 512-column panel).
  *   - Plain pointers and sizes only.  The caller owns every buffer, including workspace; the library
  *     never allocates or frees device memory and never synchronises the device, so every call is
- *     asynchronous on `stream` (a hipStream_t passed as void*) and hipGraph-capturable.
+ *     asynchronous on `stream` (a hipStream_t passed as void*).
  *   - Return value: 0 = launched OK; < 0 = -(hipError_t) or -1000-x for argument errors.  Numerical
  *     failure (non-positive pivot) is reported LAPACK-style through a device-side `info` word
  *     (1-based index of the first bad pivot, 0 = success) so that no host sync is forced.
+ *   - gpar_potrf may use one internal low-priority stream per caller stream (look-ahead) and joins it back before
+ *     it returns control of `stream`; callers see one in-order stream.  The library keeps process-global state (those
+ *     streams, an event ring, the profile hook): drive it from ONE host thread per process (one process per GPU).
  *   - Pointers should be 16-byte aligned and leading dimensions even for the vectorised paths; other
  *     values are accepted and take a slower scalar path.
  */
