@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--p", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="skip the fit + predict leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-n", type=int, default=6144, help="rows of the bounded CPU sample")
+    ap.add_argument("--cpu-n", type=int, default=0, help="rows of the bounded CPU sample (0: all n rows, ~17 s at C3)")
     args = ap.parse_args()
 
     import torch
@@ -203,7 +203,7 @@ def main():
     if rank == 0 and not args.no_extras:
         out["fit_predict"] = fit_predict_leg(eng, x_np, y_np, n, m, p)
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline_leg(x_np, y_np, m, p, args.cpu_n, n)
+        out["cpu_baseline"] = cpu_baseline_leg(x_np, y_np, m, p, args.cpu_n if 0 < args.cpu_n < n else n, n)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -240,9 +240,8 @@ def fit_predict_leg(eng, x_np, y_np, n, m, p, fit_iters=2, num_samples=4, n_star
 
 
 def cpu_baseline_leg(x_np, y_np, m, p, n_sub, n_full):
-    """The CPU oracle (numpy Gram + LAPACK Cholesky; a port of the reference's torch-CPU path) on the first
-    `n_sub` rows, last layer (widest design matrix); the full-workload rate is extrapolated with the n^3 law of the
-    dominant Cholesky (stated in `sample`)."""
+    """The CPU oracle (numpy Gram + LAPACK Cholesky; a port of the reference's torch-CPU path) on ONE layer of the
+    workload (the last, widest design matrix) - at full size by default, ~17 s on the GPU box's host - times p."""
     from gpar_amd.engine import set_engine
     from gpar_amd.regression import _construct_gpar
     from oracle.engine import OracleEngine
@@ -266,14 +265,16 @@ def cpu_baseline_leg(x_np, y_np, m, p, n_sub, n_full):
     finally:
         set_engine(previous)
     per_layer_full = dt * (n_full / n_sub) ** 3
+    how = ("no extrapolation in n" if n_sub == n_full else
+           f"extrapolated to n={n_full} with the n^3 law (pessimistic for the CPU: the Gram build is n^2)")
     return {
         "value": 1.0 / (per_layer_full * p),
         "unit": "logpdf/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"one layer (the last, widest) of the same model on the first {n_sub} rows: {dt:.2f} s measured "
+        "sample": f"one of the p={p} layers (the last, widest) of the same model on {n_sub} of {n_full} rows: {dt:.2f} s measured "
                   f"(numpy fused-by-term Gram + LAPACK dpotrf via numpy/scipy, {threads} BLAS threads, host has "
-                  f"{os.cpu_count()} logical CPUs); extrapolated to n={n_full} with the n^3 law and multiplied by p={p} layers",
+                  f"{os.cpu_count()} logical CPUs); {how}; multiplied by p={p} near-equal layers",
         "measured_s": dt,
         "sample_logpdf": val,
     }
