@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=16384)  # --rows: torchrun's parser chokes on --n
     ap.add_argument("--m", type=int, default=4)
     ap.add_argument("--p", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="skip the fit + predict leg")
@@ -72,12 +72,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # development aid: GPAR_BENCH_ONE_GPU=1 lets several ranks share GPU 0 over gloo, to exercise the multi-rank control flow
+    # (collectives, sharded fit / predict) on a one-GPU box; timings of such a run mean nothing
+    one_gpu_dev = os.environ.get("GPAR_BENCH_ONE_GPU") == "1"
+    if one_gpu_dev:
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if one_gpu_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from gpar_amd import _lib
@@ -200,8 +208,13 @@ def main():
                                        "`avg_launch_ms` is the plain per-launch average that `rocprofv3 --stats` reports; see `isolated` "
                                        "for the kernel alone")
 
-    if rank == 0 and not args.no_extras:
-        out["fit_predict"] = fit_predict_leg(eng, x_np, y_np, n, m, p)
+    if not args.no_extras:  # every rank takes part (sharded fit / predict contain collectives)
+        try:
+            leg = fit_predict_leg(eng, x_np, y_np, n, m, p, world)
+        except Exception as exc:  # the headline line must survive a failure of the extra leg
+            leg = {"error": f"{type(exc).__name__}: {exc}", "n_gpus": world}
+        if rank == 0:
+            out["fit_predict"] = leg
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_leg(x_np, y_np, m, p, args.cpu_n if 0 < args.cpu_n < n else n, n)
     if world > 1:
@@ -221,22 +234,42 @@ def pmc_traffic(n, m, p):
         return json.load(f).get("traffic_bytes_per_launch")
 
 
-def fit_predict_leg(eng, x_np, y_np, n, m, p, fit_iters=2, num_samples=4, n_star=1024):
-    """Short fit (fixed L-BFGS-B iteration count) + predict on the same data, single GPU (rank 0's device)."""
+def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=2, num_samples=8, n_star=1024):
+    """Short fit (fixed L-BFGS-B iteration count) + predict on the same data - the other half of BASELINE.json's
+    metric.  One rank: GPARRegressor.fit / predict.  Several ranks: layer pi is trained on rank pi mod N
+    (parallel.sharded_fit, hyper-parameters broadcast afterwards) and the posterior samples are split over the ranks
+    (parallel.sharded_sample; every rank conditions all layers, so the conditioning part does not scale)."""
     import torch
 
+    from gpar_amd.parallel import sharded_fit, sharded_sample
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
     reg = c3_regressor()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reg.fit(x_np, y_np, iters=fit_iters)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
     xs = np.random.default_rng(5).uniform(0, 1, (n_star, m))
-    mean = reg.predict(xs, num_samples=num_samples, latent=True)
-    torch.cuda.synchronize()
+    sync()
+    t0 = time.perf_counter()
+    if world == 1:
+        reg.fit(x_np, y_np, iters=fit_iters)
+    else:
+        sharded_fit(reg, x_np, y_np, iters=fit_iters)
+    sync()
+    t1 = time.perf_counter()
+    if world == 1:
+        mean = reg.predict(xs, num_samples=num_samples, latent=True)
+    else:
+        mean = np.mean(sharded_sample(reg, xs, num_samples=num_samples, latent=True), axis=0)
+    sync()
     t2 = time.perf_counter()
     return {"fit_ms": 1e3 * (t1 - t0), "fit_iters": fit_iters, "predict_ms": 1e3 * (t2 - t1), "num_samples": num_samples,
-            "n_star": n_star, "predict_mean_abs": float(np.mean(np.abs(mean))), "n_gpus": 1}
+            "n_star": n_star, "predict_mean_abs": float(np.mean(np.abs(mean))), "n_gpus": world,
+            "timing": "barrier-bracketed wall-clock on rank 0"}
 
 
 def cpu_baseline_leg(x_np, y_np, m, p, n_sub, n_full):
