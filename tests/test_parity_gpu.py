@@ -257,9 +257,10 @@ def test_gradient_matches_oracle(hip):
 
 # ---- properties at benchmark sizes (no oracle: too large for the CPU) -----------------------------------------
 
-@pytest.mark.parametrize("n,m,p_cols", [(4096, 2, [2, 3]), (16384, 4, [9, 10])])
+@pytest.mark.parametrize("n,m,p_cols", [(4096, 2, [2, 3]), (16384, 4, [9, 10]), (20011, 3, [4])])
 def test_full_size_cholesky_properties(hip, n, m, p_cols):
-    """K v = L (L^T v) and the augmented row equals L^-1 y, on the layer kernel at BASELINE sizes."""
+    """K v = L (L^T v) and the augmented row equals L^-1 y, on the layer kernel at BASELINE sizes - and beyond them at
+    a ragged n with more 64-row blocks than CUs (panel workgroups then own several row blocks each)."""
     from gpar_amd import hip as H
     from gpar_amd.kernels import EQ, Linear, compile_kernel
 
