@@ -1,5 +1,6 @@
 // libgpar_hip.so — C ABI (include/gpar_hip.h) over the gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC gpar_hip.hip -o ../libgpar_hip.so
+#include <mutex>
 #include "common.h"
 #include "gemm_f64.h"
 #include "potrf.h"
@@ -125,6 +126,12 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(const double* __restr
     if (hi) hi[e] = np_lerp(a1, b1, g_hi);
 }
 
+// The library keeps process-global state (look-ahead side streams and events, the profile hook, one-time kernel
+// attributes).  Entry points only ENQUEUE work, so serialising them costs nothing measurable and makes the library safe
+// to call from several host threads (GPARRegressor.fit trains independent layers from two threads, each on its stream).
+static std::mutex g_api_mutex;
+#define GPAR_API_GUARD std::lock_guard<std::mutex> gpar_api_guard(g_api_mutex)
+
 extern "C" {
 
 int gpar_abi_version(void) { return GPAR_ABI_VERSION; }
@@ -132,6 +139,7 @@ size_t gpar_sizeof_fspec(void) { return sizeof(gpar_fspec_t); }
 size_t gpar_sizeof_kspec(void) { return sizeof(gpar_kspec_t); }
 
 int gpar_featurize(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* z, int ldz, void* stream) {
+    GPAR_API_GUARD;
     if (!fs || fs->dz < 0 || fs->dz > GPAR_MAX_DIMS) return GPAR_ARG_ERROR(2);
     if (n <= 0 || fs->dz == 0) return 0;
     const long total = (long)n * fs->dz;
@@ -143,6 +151,7 @@ int gpar_featurize(const gpar_fspec_t* fs, const double* x, int n, int ldx, doub
 
 int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz,
               double* K, int ldk, int flags, const double* diag_add, double diag_const, void* stream) {
+    GPAR_API_GUARD;
     if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS)
         return GPAR_ARG_ERROR(3);
     if (dz < 0 || dz > GPAR_MAX_DIMS) return GPAR_ARG_ERROR(4);
@@ -158,6 +167,7 @@ int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const 
 }
 
 int gpar_gram_diag(const gpar_kspec_t* ks, const double* z, int n, int ldz, int dz, double* out, void* stream) {
+    GPAR_API_GUARD;
     (void)dz;
     if (!ks) return GPAR_ARG_ERROR(3);
     if (n <= 0) return 0;
@@ -167,6 +177,7 @@ int gpar_gram_diag(const gpar_kspec_t* ks, const double* z, int n, int ldz, int 
 }
 
 int gpar_featurize_dfreq(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* zd, int ldz, void* stream) {
+    GPAR_API_GUARD;
     if (!fs || fs->dz < 0 || fs->dz > GPAR_MAX_DIMS) return GPAR_ARG_ERROR(2);
     if (n <= 0 || fs->dz == 0) return 0;
     const long total = (long)n * fs->dz;
@@ -180,6 +191,7 @@ int gpar_grad_nacc(void) { return GRAD_NACC; }
 
 int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, int n, int ldz, int dz, const double* W,
                    int ldw, double* workspace, int nblocks, double* out, void* stream) {
+    GPAR_API_GUARD;
     if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS)
         return GPAR_ARG_ERROR(3);
     if (dz < 0 || dz > GPAR_MAX_DIMS || nblocks <= 0) return GPAR_ARG_ERROR(4);
@@ -206,39 +218,47 @@ int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, in
 }
 
 int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, void* stream) {
+    GPAR_API_GUARD;
     if (N <= 0 || nf <= 0) return 0;
     return potrf_run(A, N, nf, lda, logdet, info, (hipStream_t)stream);
 }
 
 int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream) {
+    GPAR_API_GUARD;
     return trsm_rlt_run(L, n, ldl, B, nrows, ldb, (hipStream_t)stream);
 }
 
 int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream) {
+    GPAR_API_GUARD;
     return trsm_rln_run(L, n, ldl, B, nrows, ldb, (hipStream_t)stream);
 }
 
 int gpar_chol_inverse(const double* L, int n, int ldl, double* X, int ldx, double* Kinv, int ldk, void* stream) {
+    GPAR_API_GUARD;
     return chol_inverse_run(L, n, ldl, X, ldx, Kinv, ldk, (hipStream_t)stream);
 }
 
 int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B, int ldb,
               double beta, double* C, int ldc, int flags, void* stream) {
+    GPAR_API_GUARD;
     return gemm_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, (hipStream_t)stream);
 }
 
 int gpar_gemm_splitk(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B, int ldb,
                      double beta, double* C, int ldc, int flags, int splits, double* workspace, void* stream) {
+    GPAR_API_GUARD;
     return gemm_splitk_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, splits, workspace, (hipStream_t)stream);
 }
 
 int gpar_logpdf_finalize(const double* logdet, const double* quad, double quad_sign, int n, double* out, void* stream) {
+    GPAR_API_GUARD;
     hipLaunchKernelGGL(logpdf_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logdet, quad, quad_sign, n, out);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
 
 int gpar_copy_strided(const double* src, int lds, double* dst, int ldd, int n, void* stream) {
+    GPAR_API_GUARD;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(copy_strided_kernel, dim3(gpar_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (long)lds, dst,
                        (long)ldd, n);
@@ -247,6 +267,7 @@ int gpar_copy_strided(const double* src, int lds, double* dst, int ldd, int n, v
 }
 
 int gpar_fill(double* dst, int rows, int cols, int ldd, double value, void* stream) {
+    GPAR_API_GUARD;
     if (rows <= 0 || cols <= 0) return 0;
     hipLaunchKernelGGL(fill_kernel, dim3(gpar_ceil_div(cols, 256), rows), dim3(256), 0, (hipStream_t)stream, dst, rows, cols, ldd,
                        value);
@@ -255,12 +276,14 @@ int gpar_fill(double* dst, int rows, int cols, int ldd, double value, void* stre
 }
 
 int gpar_dot(const double* x, int incx, const double* y, int incy, int n, double* out, int accumulate, void* stream) {
+    GPAR_API_GUARD;
     hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)incx, y, (long)incy, n, out, accumulate);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
 
 int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, int ldo, void* stream) {
+    GPAR_API_GUARD;
     if (rows <= 0 || cols <= 0) return 0;
     const size_t pairs = ((size_t)rows * cols + 1) / 2;
     hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, offset, out,
@@ -271,6 +294,7 @@ int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, 
 
 int gpar_sample_stats(const double* samples, int S, long long count, long long stride, int k_lo, double g_lo, int k_hi,
                       double g_hi, double* mean, double* lo, double* hi, void* stream) {
+    GPAR_API_GUARD;
     if (count <= 0) return 0;
     if (S <= 0 || S > 65536 || !samples || !mean) return GPAR_ARG_ERROR(2);
     if ((lo || hi) && (k_lo < 0 || k_lo >= S || k_hi < 0 || k_hi >= S)) return GPAR_ARG_ERROR(5);
@@ -281,11 +305,13 @@ int gpar_sample_stats(const double* samples, int S, long long count, long long s
 }
 
 int gpar_profile_enable(int on) {
+    GPAR_API_GUARD;
     g_prof.on = on != 0;
     return 0;
 }
 
 int gpar_profile_read(int* launches, double* ms, double* busy_ms, double* flops, int reset) {
+    GPAR_API_GUARD;
     profile_collect();
     if (launches) *launches = g_prof.launches;
     if (ms) *ms = g_prof.ms_done;

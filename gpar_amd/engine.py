@@ -23,6 +23,7 @@ Primitive set (all tensors float64, row-major, lower triangles authoritative):
 """
 import contextlib
 import os
+import threading
 
 import torch
 
@@ -53,7 +54,7 @@ class HipEngine:
         self.epsilon = float(epsilon)  # lab's B.epsilon: diagonal jitter added before every Cholesky
         self._seed = int(seed)
         self._calls = 0
-        self._deferred = None  # list of pending device-side info words while a defer_checks() block is open
+        self._tls = threading.local()  # per host thread: pending device-side info words of an open defer_checks() block
         self._pipe_streams = []  # streams of pipeline(), created on first use
 
     # ---- memory ----------------------------------------------------------------------------------
@@ -155,6 +156,17 @@ class HipEngine:
             self._pipe_streams += [torch.cuda.Stream(device=self.device) for _ in range(depth - len(self._pipe_streams))]
         return _LayerPipeline(self, self._pipe_streams[:depth])
 
+    def worker_streams(self, depth=None):
+        """The same streams, for callers that drive them from separate host threads (GPARRegressor.fit trains
+        independent layers concurrently).  Empty when disabled (GPAR_FIT_THREADS=0/1)."""
+        if depth is None:
+            depth = int(os.environ.get("GPAR_FIT_THREADS", "2"))
+        if depth < 2:
+            return []
+        if len(self._pipe_streams) < depth:
+            self._pipe_streams += [torch.cuda.Stream(device=self.device) for _ in range(depth - len(self._pipe_streams))]
+        return self._pipe_streams[:depth]
+
     # ---- status ----------------------------------------------------------------------------------
     def defer_checks(self):
         """Context manager: inside it `check_info` only records the device-side info words (no host sync), so a
@@ -165,10 +177,19 @@ class HipEngine:
     def check_info(self, info):
         """Synchronise on the device-side LAPACK-style info word and raise if a pivot failed (or record it while a
         defer_checks() block is open)."""
-        if self._deferred is not None:
-            self._deferred.append(info)
+        pending = self._deferred
+        if pending is not None:
+            pending.append(info)
             return
         self._raise_for(info)
+
+    @property
+    def _deferred(self):
+        return getattr(self._tls, "deferred", None)
+
+    @_deferred.setter
+    def _deferred(self, value):
+        self._tls.deferred = value
 
     @staticmethod
     def _raise_for(info):

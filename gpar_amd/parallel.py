@@ -115,6 +115,14 @@ def _global_rank(group_rank, group):
     return dist.get_global_rank(group, group_rank)
 
 
+def layers_train_independently(reg, y):
+    """With `fix=True`, is the training of layer pi independent of the training of the other layers?  Its inputs must be
+    data only (no `replace`, no inducing points, nothing to impute) and it must not share a hyper-parameter with
+    another layer (`scale_tie` reads "0/input/scales", which only layer 0 trains)."""
+    return not (reg.replace or reg.sparse or reg.model_config.get("scale_tie", False)
+                or (reg.impute and bool(torch.isnan(y).any())))
+
+
 def sharded_fit(reg, x, y, w=None, group=None, **kw_args):
     """`GPARRegressor.fit(x, y, w, fix=True)` with layer pi trained on rank pi mod G, then synchronised."""
     from .optimise import minimise_l_bfgs_b
@@ -125,8 +133,7 @@ def sharded_fit(reg, x, y, w=None, group=None, **kw_args):
     reg.condition(x, y, w)
     x_dev, y_dev, w_dev = eng.tensor(reg.x), eng.tensor(reg.y), eng.tensor(reg.w)
     y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
-    independent = not (reg.replace or reg.sparse or (reg.impute and bool(torch.isnan(y_dev).any())))
-    if not independent:
+    if not layers_train_independently(reg, y_dev):
         # inputs of layer pi depend on the trained layers < pi: the chain is sequential; train replicated
         reg.fit(x, y, w, fix=True, **kw_args)
         return

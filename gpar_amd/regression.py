@@ -133,6 +133,35 @@ def _init_weights(w, y):
     return _uprank(_to_torch(w))
 
 
+def _run_on_streams(eng, streams, shares, fn):
+    """fn(item) for every item of shares[k] on stream k, one host thread per stream; exceptions re-raised here."""
+    import threading
+
+    main = torch.cuda.current_stream(eng.device)
+    errors = []
+
+    def work(stream, items):
+        try:
+            with torch.cuda.device(eng.device), torch.cuda.stream(stream):
+                for item in items:
+                    fn(item)
+        except BaseException as exc:  # noqa: BLE001 - handed to the caller's thread
+            errors.append(exc)
+
+    threads = []
+    for stream, items in zip(streams, shares):
+        stream.wait_stream(main)
+        threads.append(threading.Thread(target=work, args=(stream, items), daemon=True))
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for stream in streams:
+        main.wait_stream(stream)
+    if errors:
+        raise errors[0]
+
+
 class GPARRegressor:
     """GPAR regressor.  See the reference docstring (regression.py:200-262) for the meaning of every keyword;
     signature and defaults are identical."""
@@ -198,7 +227,8 @@ class GPARRegressor:
         eng = get_engine()
         x_dev, y_dev, w_dev = eng.tensor(self.x), eng.tensor(self.y), eng.tensor(self.w)
         y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
-        for pi in range(self.p):
+
+        def train_layer(pi):
             if fix:
                 gpar = _construct_gpar(self, self.vs, self.m, pi + 1)
                 fixed_x, fixed_x_ind = gpar.logpdf(
@@ -213,6 +243,21 @@ class GPARRegressor:
 
             names = [f"{pi}/*"] if fix else [f"{i}/*" for i in range(pi + 1)]
             minimise_l_bfgs_b(objective, self.vs, names=names, **kw_args)
+
+        from .parallel import layers_train_independently
+
+        streams = eng.worker_streams() if hasattr(eng, "worker_streams") else []
+        if fix and self.p > 1 and len(streams) > 1 and layers_train_independently(self, y_dev):
+            # Layers whose inputs are data and whose hyper-parameters are their own train independently of one another:
+            # two host threads, each on its own stream, keep two L-BFGS-B drivers in flight so that one layer's
+            # latency-bound stretches (panel chains, host-side optimiser steps) run under the other's GEMMs.  The result
+            # is the serial one: every evaluation is the same deterministic device computation.
+            with torch.no_grad():  # lazily created variables must all exist before the store is shared between threads
+                _construct_gpar(self, self.vs, self.m, self.p).logpdf(x_dev[:2], y_dev[:2], w_dev[:2])
+            _run_on_streams(eng, streams, [[pi for pi in range(k, self.p, len(streams))] for k in range(len(streams))], train_layer)
+        else:
+            for pi in range(self.p):
+                train_layer(pi)
 
     def logpdf(self, x, y, w=None, sample_missing=False, posterior=False):
         """Log-density of observations under the prior (or, with `posterior`, the conditioned model).  Returns a

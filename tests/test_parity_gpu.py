@@ -173,6 +173,36 @@ def test_layer_pipeline_is_bit_identical_to_serial_evaluation(monkeypatch):
     assert got["sharded0"] == got["sharded2"] == got["0"], got
 
 
+def test_concurrent_layer_training_equals_serial_training(monkeypatch):
+    """fit(fix=True) on observed data trains independent layers from two host threads on two streams; every objective
+    evaluation is the same deterministic device computation, so the trained hyper-parameters are those of the serial
+    loop, bit for bit.  With a shared hyper-parameter (scale_tie) the layers are NOT independent and fit stays serial."""
+    from gpar_amd.parallel import layers_train_independently
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(900, 2, 4, seed=12)
+
+    def run():
+        out = {}
+        for threads in ["1", "2"]:
+            monkeypatch.setenv("GPAR_FIT_THREADS", threads)
+            reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1)
+            reg.fit(x, y, iters=4)
+            out[threads] = {k: np.array(v) for k, v in reg.get_variables().items()}
+        tied = GPARRegressor(scale=0.5, scale_tie=True, linear=True, nonlinear=True, noise=0.1)
+        tied.condition(x, y)
+        import torch
+
+        out["tied_independent"] = layers_train_independently(tied, torch.as_tensor(y))
+        return out
+
+    got = _on("hip", run)
+    assert got["1"].keys() == got["2"].keys() and len(got["1"]) > 8
+    for name in got["1"]:
+        assert np.array_equal(got["1"][name], got["2"][name]), name
+    assert got["tied_independent"] is False
+
+
 def test_predict_reduction_on_device_matches_numpy_reduction():
     """predict = device-side mean / percentiles of the same samples `sample` returns (row a10 of SURVEY section 8):
     same seed -> the HIP reduction equals numpy's on the HIP samples bit for bit, and the oracle's to sample parity."""
