@@ -26,8 +26,9 @@
  *     failure (non-positive pivot) is reported LAPACK-style through a device-side `info` word
  *     (1-based index of the first bad pivot, 0 = success) so that no host sync is forced.
  *   - gpar_potrf may use one internal low-priority stream per caller stream (look-ahead) and joins it back before
- *     it returns control of `stream`; callers see one in-order stream.  The library keeps process-global state (those
- *     streams, an event ring, the profile hook): drive it from ONE host thread per process (one process per GPU).
+ *     it returns control of `stream`; callers see one in-order stream.  Process-global state (those streams, an event
+ *     ring, the profile hook) sits behind one mutex: entry points only enqueue, so calls from several host threads
+ *     (each with its own stream) are safe and simply serialise their enqueueing.
  *   - Pointers should be 16-byte aligned and leading dimensions even for the vectorised paths; other
  *     values are accepted and take a slower scalar path.
  */
