@@ -358,6 +358,7 @@ struct LookaheadState {
     hipStream_t caller[MAXS];
     hipStream_t side[MAXS];
     int nside = 0;
+    int next_victim = 0;
     static constexpr int MAXE = 4096;
     hipEvent_t ev[MAXE];
     int nev = 0;
@@ -379,18 +380,26 @@ static bool la_init() {
 }
 
 // Side stream paired with `caller`: lowest priority, non-blocking (a blocking stream would serialise with the null
-// stream: tools/probe_queue_concurrency2.hip).  Returns nullptr when the table is full (look-ahead is then skipped).
+// stream: tools/probe_queue_concurrency2.hip).
 static hipStream_t la_side(hipStream_t caller) {
     for (int i = 0; i < g_la.nside; ++i)
         if (g_la.caller[i] == caller) return g_la.side[i];
-    if (g_la.nside >= LookaheadState::MAXS) return nullptr;
     int lo = 0, hi = 0;
     hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least urgent
     hipStream_t s = nullptr;
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
-    g_la.caller[g_la.nside] = caller;
-    g_la.side[g_la.nside] = s;
-    ++g_la.nside;
+    int slot = g_la.nside;
+    if (slot >= LookaheadState::MAXS) {
+        // table full (a process that keeps creating caller streams): recycle round-robin; destroying a stream lets its
+        // pending work finish first, and every gpar_potrf joins its side stream before it returns anyway
+        slot = g_la.next_victim;
+        g_la.next_victim = (g_la.next_victim + 1) % LookaheadState::MAXS;
+        hipStreamDestroy(g_la.side[slot]);
+    } else {
+        ++g_la.nside;
+    }
+    g_la.caller[slot] = caller;
+    g_la.side[slot] = s;
     return s;
 }
 

@@ -55,7 +55,6 @@ class HipEngine:
         self._seed = int(seed)
         self._calls = 0
         self._tls = threading.local()  # per host thread: pending device-side info words of an open defer_checks() block
-        self._pipe_streams = []  # streams of pipeline(), created on first use
 
     # ---- memory ----------------------------------------------------------------------------------
     def tensor(self, x):
@@ -152,9 +151,7 @@ class HipEngine:
             depth = int(os.environ.get("GPAR_LAYER_PIPELINE", "2"))  # 0 / 1 disable
         if depth < 2:
             return None
-        if len(self._pipe_streams) < depth:
-            self._pipe_streams += [torch.cuda.Stream(device=self.device) for _ in range(depth - len(self._pipe_streams))]
-        return _LayerPipeline(self, self._pipe_streams[:depth])
+        return _LayerPipeline(self, _device_streams(self.device, depth))
 
     def worker_streams(self, depth=None):
         """The same streams, for callers that drive them from separate host threads (GPARRegressor.fit trains
@@ -163,9 +160,7 @@ class HipEngine:
             depth = int(os.environ.get("GPAR_FIT_THREADS", "2"))
         if depth < 2:
             return []
-        if len(self._pipe_streams) < depth:
-            self._pipe_streams += [torch.cuda.Stream(device=self.device) for _ in range(depth - len(self._pipe_streams))]
-        return self._pipe_streams[:depth]
+        return _device_streams(self.device, depth)
 
     # ---- status ----------------------------------------------------------------------------------
     def defer_checks(self):
@@ -198,6 +193,17 @@ class HipEngine:
             raise RuntimeError(f"gpar_potrf: device-side hand-off timed out (code {code}); is another kernel holding the CUs?")
         if code != 0:
             raise NotPositiveDefiniteError(code)
+
+
+_STREAMS = {}  # device -> extra streams, shared by every engine of the process (the library pairs each caller stream
+               # with an internal side stream, so the set of caller streams is kept small and stable)
+
+
+def _device_streams(device, depth):
+    pool = _STREAMS.setdefault(str(device), [])
+    while len(pool) < depth:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:depth]
 
 
 class _LayerPipeline:
