@@ -94,6 +94,7 @@ SIGNATURES = {
     "gpar_fill": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_dbl, _ptr]),
     "gpar_dot": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "gpar_randn": (_c_int, [_u64, _u64, _ptr, _c_int, _c_int, _c_int, _ptr]),
+    "gpar_trmv_lower": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr]),
     "gpar_sample_stats": (
         _c_int,
         [_ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_dbl, _c_int, _c_dbl, _ptr, _ptr, _ptr, _ptr],

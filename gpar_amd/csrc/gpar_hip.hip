@@ -89,6 +89,26 @@ __global__ __launch_bounds__(256) void randn_kernel(uint64_t seed, uint64_t offs
 
 using namespace gpar;
 
+// ---- y = L x for a lower-triangular L and one vector: one wave per row, lanes stride the row (coalesced), wave reduce
+__global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ L, int n, int ldl, const double* __restrict__ x,
+                                                         int incx, double* __restrict__ y, int incy) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const double* Lr = L + (size_t)row * ldl;
+    double a0 = 0.0, a1 = 0.0;
+    int j = lane;
+    for (; j + 64 <= row; j += 128) {
+        a0 = fma(Lr[j], x[(size_t)j * incx], a0);
+        a1 = fma(Lr[j + 64], x[(size_t)(j + 64) * incx], a1);
+    }
+    if (j <= row) a0 = fma(Lr[j], x[(size_t)j * incx], a0);
+    double s = a0 + a1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) y[(size_t)row * incy] = s;
+}
+
 // ---- Monte-Carlo reduction over posterior samples (reference regression.py:589-595)
 __device__ __forceinline__ double np_lerp(double a, double b, double t) {
     // numpy's _lerp: a + (b - a) t, replaced by b - (b - a)(1 - t) when t >= 0.5; numpy rounds the product and the
@@ -288,6 +308,14 @@ int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, 
     const size_t pairs = ((size_t)rows * cols + 1) / 2;
     hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, offset, out,
                        rows, cols, ldo);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_trmv_lower(const double* L, int n, int ldl, const double* x, int incx, double* y, int incy, void* stream) {
+    GPAR_API_GUARD;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, L, n, ldl, x, incx, y, incy);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

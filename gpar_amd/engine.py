@@ -30,7 +30,7 @@ import torch
 from . import _lib, hip
 from .kernels import compile_kernel
 
-__all__ = ["HipEngine", "get_engine", "set_engine", "NotPositiveDefiniteError"]
+__all__ = ["HipEngine", "get_engine", "set_engine", "NotPositiveDefiniteError", "joining"]
 
 
 class NotPositiveDefiniteError(ArithmeticError):
@@ -99,6 +99,10 @@ class HipEngine:
     def chol_inverse(self, L):
         return hip.chol_inverse(L)
 
+    def trmv_lower(self, L, x):
+        """L x for lower-triangular L and a single column x."""
+        return hip.trmv_lower(self._mat(L), x)
+
     def kernel_grads(self, ck, x, W):
         """1/2 sum_ab W_ab dK_ab/dtheta for every parameter of the compiled kernel (W: lower triangle of a symmetric
         matrix).  One fused device pass produces per-term / per-factor / per-feature moment sums (csrc/gram.h); the
@@ -147,8 +151,10 @@ class HipEngine:
         the tail of a blocked factorisation is a latency-bound chain of small panels that leaves most of the chip
         idle, the front of the next one is throughput-bound - on alternating streams the two overlap.  Returns None
         when disabled (GPAR_LAYER_PIPELINE=0)."""
-        if depth is None:
-            depth = int(os.environ.get("GPAR_LAYER_PIPELINE", "2"))  # 0 / 1 disable
+        default = int(os.environ.get("GPAR_LAYER_PIPELINE", "2"))  # 0 / 1 disable every use
+        if default < 2:
+            return None
+        depth = default if depth is None else depth
         if depth < 2:
             return None
         return _LayerPipeline(self, _device_streams(self.device, depth))
@@ -204,6 +210,17 @@ def _device_streams(device, depth):
     while len(pool) < depth:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:depth]
+
+
+@contextlib.contextmanager
+def joining(pipe):
+    """Whatever happens inside (a failed factorisation raises at the end of a deferred-check block), the stage streams of
+    `pipe` (may be None) are joined back into the caller's stream before control returns."""
+    try:
+        yield pipe
+    finally:
+        if pipe is not None:
+            pipe.join()
 
 
 class _LayerPipeline:

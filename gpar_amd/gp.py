@@ -20,12 +20,13 @@ This module provides those names with the same call signatures; the arithmetic i
 
 All heavy steps are engine primitives (HIP kernels); torch is used here only for O(n) vector plumbing.
 """
+import contextlib
 import math
 
 import numpy as np
 import torch
 
-from .engine import get_engine
+from .engine import get_engine, joining
 from .kernels import Kernel
 
 __all__ = ["Measure", "GP", "FDD", "Obs", "PseudoObs", "SparseObs"]
@@ -298,7 +299,7 @@ class FDD:
         _, info = eng.potrf_(S)
         eng.check_info(info)
         zr = eng.randn(n, num)
-        out = eng.gemm(S, zr, a_lower=True)
+        out = eng.trmv_lower(S, zr) if num == 1 else eng.gemm(S, zr, a_lower=True)
         return out + mean
 
 
@@ -415,17 +416,22 @@ class Obs:
                     eng.gram(ck, zs, z, out=B[k * ns : (k + 1) * ns])
                 eng.trsm_rlt_(fac.L, B)  # every V_s = K(x_s, X) L^-T in one solve
                 means = eng.gemm(B, fac.zrow, tb=True)
-            for k, zs in enumerate(zss):
-                cov = eng.new_matrix(ns, ns)
-                eng.gram(ck, zs, lower=True, diag_add=noise_vec, diag_const=eng.epsilon, out=cov)
-                mean = 0.0
-                if n > 0:
-                    V = B[k * ns : (k + 1) * ns]
-                    eng.gemm(V, V, tb=True, alpha=-1.0, beta=1.0, out=cov, c_lower=True)
-                    mean = means[k * ns : (k + 1) * ns]
-                _, info = eng.potrf_(cov)
-                eng.check_info(info)
-                out[:, s0 + k : s0 + k + 1] = eng.gemm(cov, zr[:, s0 + k : s0 + k + 1], a_lower=True) + mean
+            # the per-sample blocks (Gram, SYRK downdate, an n* x n* factorisation, one matvec) are independent: a small
+            # factorisation is a latency-bound chain, so they are dealt over a few streams and checked once at the end
+            pipe = eng.pipeline(min(4, s1 - s0)) if s1 - s0 > 1 else None
+            with eng.defer_checks(), joining(pipe):  # streams are joined BEFORE the deferred info words are read
+                for k, zs in enumerate(zss):
+                    with (pipe.stage(k, B, zr, out, zs, noise_vec, means if n > 0 else None) if pipe is not None else contextlib.nullcontext()):
+                        cov = eng.new_matrix(ns, ns)
+                        eng.gram(ck, zs, lower=True, diag_add=noise_vec, diag_const=eng.epsilon, out=cov)
+                        mean = 0.0
+                        if n > 0:
+                            V = B[k * ns : (k + 1) * ns]
+                            eng.gemm(V, V, tb=True, alpha=-1.0, beta=1.0, out=cov, c_lower=True)
+                            mean = means[k * ns : (k + 1) * ns]
+                        _, info = eng.potrf_(cov)
+                        eng.check_info(info)
+                        out[:, s0 + k : s0 + k + 1] = eng.trmv_lower(cov, zr[:, s0 + k : s0 + k + 1]) + mean
         return out
 
     def posterior_moments(self, fdd, block, jitter):

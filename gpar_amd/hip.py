@@ -28,6 +28,7 @@ __all__ = [
     "dot",
     "randn",
     "sample_stats",
+    "trmv_lower",
 ]
 
 
@@ -244,6 +245,19 @@ def randn(seed, offset, rows, cols, device):
         "gpar_randn",
     )
     return out
+
+
+def trmv_lower(L, x):
+    """L x for the lower triangle of the square matrix L and one column x (n x 1, any row stride); new n x 1 tensor."""
+    lib = _lib.load()
+    _check_mat(L, "L")
+    n = L.shape[0]
+    if x.dim() != 2 or x.shape[0] != n or x.shape[1] != 1 or x.dtype != torch.float64:
+        raise ValueError("x must be an n x 1 fp64 matrix")
+    y = torch.empty(n, 1, dtype=torch.float64, device=L.device)
+    _lib.check(lib.gpar_trmv_lower(L.data_ptr(), n, _ld(L), x.data_ptr(), int(x.stride(0)), y.data_ptr(), 1, stream_ptr(L.device)),
+               "gpar_trmv_lower")
+    return y
 
 
 def percentile_index(num, q):

@@ -9,12 +9,11 @@ library.  Layer i models output i given the inputs and the previous outputs: its
 
 Tensors are torch float64 on the engine's device; numpy inputs are accepted and converted.
 """
-import contextlib
-
 import numpy as np
 import torch
 
 from .engine import get_engine
+from .engine import joining as _joining
 from .gp import Obs, PseudoObs
 
 __all__ = ["GPAR", "merge", "construct_model", "last", "per_output"]
@@ -70,17 +69,6 @@ def last(xs, select=None):
         current, index = upcoming, index + 1
     if wanted is None or index in wanted:
         yield True, current
-
-
-@contextlib.contextmanager
-def _joining(pipe):
-    """Whatever happens inside (a failed factorisation raises at the end of a deferred-check block), the stage streams
-    are joined back into the caller's stream before control returns."""
-    try:
-        yield pipe
-    finally:
-        if pipe is not None:
-            pipe.join()
 
 
 def _differentiable(f, noise):
@@ -168,7 +156,7 @@ class GPAR:
         # Observed data only: no layer needs another's posterior, so the factorisations (otherwise done lazily, one
         # after the other, when the posterior is first used) are issued now on alternating streams.
         pipe = eng.pipeline() if self._independent(items) else None
-        with _joining(pipe), eng.defer_checks():
+        with eng.defer_checks(), _joining(pipe):  # streams are joined BEFORE the deferred info words are read
             for stage, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, self.layers))):
                 complete = isinstance(mask, slice)
                 x = x[mask]
@@ -201,7 +189,7 @@ class GPAR:
         # layers that do not feed one another (observed data only) are spread over alternating streams
         pipe = eng.pipeline() if self._independent(items) and not return_inputs else None
         values, stage = [], 0
-        with _joining(pipe), eng.defer_checks():
+        with eng.defer_checks(), _joining(pipe):  # streams are joined BEFORE the deferred info words are read
             for is_last, ((yi, wi, mask), model) in last(zip(items, self.layers), select=outputs):
                 complete = isinstance(mask, slice)
                 x = x[mask]

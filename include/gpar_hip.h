@@ -177,6 +177,11 @@ int gpar_dot(const double* x, int incx, const double* y, int incy, int n, double
  * identified by (seed, offset).   [B.randn in Normal.sample] */
 int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, int ldo, void* stream);
 
+/* y[i*incy] = sum_{j<=i} L[i][j] * x[j*incx], i < n: lower-triangular matrix times ONE vector (the strict upper triangle
+ * is not read).  [the chol(cov) * z product of Normal.sample for a single draw; a 128-wide GEMM tile for one column is
+ * all latency] */
+int gpar_trmv_lower(const double* L, int n, int ldl, const double* x, int incx, double* y, int incy, void* stream);
+
 /* Monte-Carlo reduction of predict [gpar/regression.py:589-595: np.mean / np.percentile over the sample axis]:
  * samples[s * stride + e], s < S, e < count.  mean[e] = (sum over s, in order) / S.  If lo / hi are non-null they
  * receive the order-statistic interpolations  v[k] + g (v[k+1] - v[k])  (numpy's "linear" method, evaluated with

@@ -168,6 +168,9 @@ class OracleEngine:
         self._calls += 1
         return out
 
+    def trmv_lower(self, L, x):
+        return torch.from_numpy(np.tril(_np(L)) @ _np(x))
+
     def sample_stats(self, samples, q_lo=None, q_hi=None):
         """numpy, exactly as the reference does it (regression.py:589-595)."""
         arr = _np(samples)

@@ -197,6 +197,18 @@ def test_sample_stats_is_numpy_mean_and_percentile(env, S, shape):
     assert only_mean[1] is None and only_mean[2] is None and np.array_equal(only_mean[0].cpu().numpy(), np.mean(x, axis=0))
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 300, 2048])
+def test_trmv_lower(env, n):
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    L = np.tril(rng.standard_normal((n, n)))
+    x = rng.standard_normal((n, 3))
+    dL = to_dev(L + np.triu(np.full((n, n), np.nan), 1))  # the strict upper triangle must not be read
+    dx = to_dev(x)
+    got = hip.trmv_lower(dL, dx[:, 1:2]).cpu().numpy()  # a strided column
+    np.testing.assert_allclose(got, L @ x[:, 1:2], rtol=1e-12, atol=1e-12 * np.sqrt(n))
+
+
 def test_small_utilities(env):
     torch, hip, dev, to_dev = env
     rng = np.random.default_rng(5)
