@@ -81,6 +81,19 @@ class _Factor:
         self.quad = -A[n, n]  # |L^-1 rhs|^2 (device scalar)
         self._alpha = None
 
+    @classmethod
+    def placeholder(cls, eng, n):
+        """Buffers of a factor that another process computes (parallel.sharded_condition receives into `A`)."""
+        self = cls.__new__(cls)
+        self.eng, self.n = eng, n
+        self.A = eng.new_matrix(n + 1, n + 1)
+        self.L = self.A[:n, :n]
+        self.zrow = self.A[n : n + 1, :n]
+        self.logdet = None  # not exchanged: a received factor serves posterior means / samples, not logpdf
+        self.quad = None
+        self._alpha = None
+        return self
+
     def logpdf(self):
         """-1/2 (log|S| + n log 2 pi + rhs^T S^-1 rhs) as a 0-d tensor: on the CPU (synchronises), or left on the
         device while the engine is deferring checks (the caller then reads the sum of many layers once)."""
@@ -340,6 +353,11 @@ class Obs:
         ck, _ = self.fdd.features()
         grads = eng.kernel_grads(ck, self.fdd.x, W)
         return 0.5 * torch.diagonal(W).clone(), grads
+
+    def adopt_factor(self):
+        """Install an empty factor whose buffer the caller fills (a factor computed by another rank)."""
+        self._fac = _Factor.placeholder(self.eng, self.fdd.n)
+        return self._fac
 
     def factor(self):
         """Cholesky of K + D + eps I and L^-1 y; valid when the fdd belongs to the prior."""

@@ -227,8 +227,10 @@ class GPAR:
     def _independent(self, items):
         """No layer needs anything a previous layer computes: complete data (slice masks), no `replace`, no
         inducing points - the design matrix of layer i is just [x, y_<i]."""
-        return (not self.replace and not self.sparse and len(items) > 1
-                and all(isinstance(mask, slice) for _, _, mask in items))
+        def all_rows(mask):  # slices on the GPU (per_output); an all-True boolean mask on the CPU (free to test there)
+            return isinstance(mask, slice) or (not mask.is_cuda and bool(mask.all()))
+
+        return not self.replace and not self.sparse and len(items) > 1 and all(all_rows(mask) for _, _, mask in items)
 
     # ---- sampling ----------------------------------------------------------------------------------
     def sample(self, x, w, latent=False):

@@ -277,7 +277,7 @@ class GPARRegressor:
             value = value.detach().cpu().numpy()
         return value
 
-    def _sample_device(self, x, w, p, posterior, num_samples, latent):
+    def _sample_device(self, x, w, p, posterior, num_samples, latent, conditioned=None):
         """The samples of `sample` as engine tensors (n* x p each), output transforms undone."""
         x = _uprank(_to_torch(x))
         if posterior and not self.is_conditioned:
@@ -288,17 +288,20 @@ class GPARRegressor:
             w = torch.ones(x.shape[0], self.p if posterior else p, dtype=torch.float64)
         else:
             w = _uprank(_to_torch(w))
-        if posterior:
+        if posterior and conditioned is not None:
+            gpar = conditioned  # parallel.sharded_condition: factors computed across ranks
+        elif posterior:
             gpar = _construct_gpar(self, self.vs, self.m, self.p)
             gpar = gpar | (self.x, self.y, self.w)
         else:
             gpar = _construct_gpar(self, self.vs, x.shape[1], p)
         return [self._untransform_y(self._unnormalise_y(s)).detach() for s in gpar.sample_many(x, w, num_samples, latent=latent)]
 
-    def sample(self, x, w=None, p=None, posterior=False, num_samples=1, latent=False):
+    def sample(self, x, w=None, p=None, posterior=False, num_samples=1, latent=False, _conditioned=None):
         """Draw samples from the prior or the posterior at inputs x; a single ndarray for num_samples=1, otherwise
-        a list (reference regression.py:508-564)."""
-        samples = [s.cpu().numpy() for s in self._sample_device(x, w, p, posterior, num_samples, latent)]
+        a list (reference regression.py:508-564).  (`_conditioned`: an already conditioned GPAR, used by the
+        multi-GPU path.)"""
+        samples = [s.cpu().numpy() for s in self._sample_device(x, w, p, posterior, num_samples, latent, _conditioned)]
         return samples[0] if num_samples == 1 else samples
 
     def predict(self, x, w=None, num_samples=100, latent=False, credible_bounds=False):

@@ -66,6 +66,17 @@ def _worker(rank, size, port, results):
         out["fit"] = (sorted(va) == sorted(vb), max(float(np.max(np.abs(va[k] - vb[k]))) for k in va))
         samples = sharded_sample(b, x[:5], None, num_samples=5)
         out["samples"] = (len(samples), samples[0].shape)
+        # layer-parallel conditioning (factors computed by their owners, broadcast to everybody) == local conditioning
+        from gpar_amd.engine import get_engine
+        from gpar_amd.parallel import sharded_condition
+
+        post = sharded_condition(b)
+        get_engine().seed(99)
+        via_exchange = np.stack(b.sample(x[:7], posterior=True, num_samples=3, _conditioned=post))
+        get_engine().seed(99)
+        local = np.stack(b.sample(x[:7], posterior=True, num_samples=3))
+        received = [i for i, layer in enumerate(post.layers) if layer()[0]._obs._fac.logdet is None]
+        out["condition"] = (float(np.max(np.abs(via_exchange - local))), received)
         results[rank] = out
     finally:
         dist.destroy_process_group()
@@ -92,5 +103,8 @@ def test_layer_parallel_matches_serial_world_size_2():
         same_names, maxdiff = out["fit"]
         assert same_names and maxdiff < 1e-9
         assert out["samples"] == (5, (5, 3))
+        maxdiff, received = out["condition"]
+        assert maxdiff == 0.0, maxdiff
+        assert received == [i for i in range(3) if i % size != rank], (rank, received)  # the others' layers came over the wire
     # both ranks hold the same totals
     assert results[0]["independent"][1] == results[1]["independent"][1]
