@@ -77,6 +77,11 @@ SIGNATURES = {
         _c_int,
         [ctypes.POINTER(KSpec), _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr],
     ),
+    "gpar_gram_grad_cross": (
+        _c_int,
+        [ctypes.POINTER(KSpec), _ptr, _ptr, _c_int, _c_int, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int,
+         _ptr, _ptr],
+    ),
     "gpar_potrf": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "gpar_trsm_rlt": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),
     "gpar_trsm_rln": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),

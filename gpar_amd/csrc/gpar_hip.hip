@@ -209,12 +209,15 @@ int gpar_featurize_dfreq(const gpar_fspec_t* fs, const double* x, int n, int ldx
 
 int gpar_grad_nacc(void) { return GRAD_NACC; }
 
-int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, int n, int ldz, int dz, const double* W,
-                   int ldw, double* workspace, int nblocks, double* out, void* stream) {
-    GPAR_API_GUARD;
+static int gram_grad_launch(const gpar_kspec_t* ks, const double* z1, const double* zd1, int n1, int ldz1, const double* z2,
+                            const double* zd2, int n2, int ldz2, int dz, const double* W, int ldw, int mode, double* workspace,
+                            int nblocks, double* out, void* stream) {
     if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS)
         return GPAR_ARG_ERROR(3);
     if (dz < 0 || dz > GPAR_MAX_DIMS || nblocks <= 0) return GPAR_ARG_ERROR(4);
+    if (mode != GPAR_GRAD_SYM && mode != GPAR_GRAD_RECT && mode != GPAR_GRAD_DIAG) return GPAR_ARG_ERROR(13);
+    if (mode != GPAR_GRAD_RECT && (n2 != n1 || z2 != z1)) return GPAR_ARG_ERROR(9);
+    if ((zd1 == nullptr) != (zd2 == nullptr)) return GPAR_ARG_ERROR(8);
     {   // the pass handles at most GRAD_MAXF factors per product term
         int cnt[GPAR_MAX_TERMS] = {0};
         for (int f = 0; f < ks->nfactors; ++f) {
@@ -229,12 +232,25 @@ int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, in
         attr_done = true;
     }
     if (lds > 160 * 1024) return GPAR_ARG_ERROR(7);
-    hipLaunchKernelGGL(gram_grad_kernel, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, *ks, z, zd, n, ldz, dz, W, ldw,
-                       workspace);
+    hipLaunchKernelGGL(gram_grad_kernel, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, *ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2,
+                       dz, W, ldw, mode, workspace);
     hipLaunchKernelGGL(gram_grad_reduce_kernel, dim3(gpar_ceil_div(GRAD_NACC, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const double*)workspace, nblocks, out);
     GPAR_LAUNCH_CHECK();
     return 0;
+}
+
+int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, int n, int ldz, int dz, const double* W,
+                   int ldw, double* workspace, int nblocks, double* out, void* stream) {
+    GPAR_API_GUARD;
+    return gram_grad_launch(ks, z, zd, n, ldz, z, zd, n, ldz, dz, W, ldw, GPAR_GRAD_SYM, workspace, nblocks, out, stream);
+}
+
+int gpar_gram_grad_cross(const gpar_kspec_t* ks, const double* z1, const double* zd1, int n1, int ldz1, const double* z2,
+                         const double* zd2, int n2, int ldz2, int dz, const double* W, int ldw, int mode, double* workspace,
+                         int nblocks, double* out, void* stream) {
+    GPAR_API_GUARD;
+    return gram_grad_launch(ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2, dz, W, ldw, mode, workspace, nblocks, out, stream);
 }
 
 int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, void* stream) {

@@ -195,9 +195,13 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void gram_grad_kernel(gpar_kspec_t ks, const double* __restrict__ z,
-                                                        const double* __restrict__ zd, int n, int ldz, int dz,
-                                                        const double* __restrict__ W, int ldw,
+// mode GPAR_GRAD_SYM : one point set (z2 == z1), W symmetric n1 x n1 given by its lower triangle (sum over ALL pairs);
+//      GPAR_GRAD_RECT: two point sets, W a full n1 x n2 matrix (cross-Gram weights of the inducing-point bound);
+//      GPAR_GRAD_DIAG: one point set, W a vector: only the pairs (a, a) (derivative of the prior variances k(x_a, x_a)).
+__global__ __launch_bounds__(256) void gram_grad_kernel(gpar_kspec_t ks, const double* __restrict__ z, const double* __restrict__ zd,
+                                                        int n, int ldz, const double* __restrict__ z2,
+                                                        const double* __restrict__ zd2, int n2, int ldz2, int dz,
+                                                        const double* __restrict__ W, int ldw, int mode,
                                                         double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     const int dzl = dz > 0 ? dz : 1;
@@ -210,25 +214,33 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(gpar_kspec_t ks, const d
     for (int i = t; i < 4 * GRAD_NACC; i += 256) acc[i] = 0.0;
     double* myacc = acc + wv * GRAD_NACC;
     const int tx = t & 15, ty = t >> 4;
-    const int nt = (n + GRAM_T - 1) / GRAM_T;
-    const int ntiles = nt * (nt + 1) / 2;
+    const int nt = (n + GRAM_T - 1) / GRAM_T, nt2 = (n2 + GRAM_T - 1) / GRAM_T;
+    const int ntiles = mode == GPAR_GRAD_SYM ? nt * (nt + 1) / 2 : (mode == GPAR_GRAD_RECT ? nt * nt2 : nt);
     const bool has_zd = zd != nullptr;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int bm = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
-        while ((bm + 1) * (bm + 2) / 2 <= tile) ++bm;
-        while (bm * (bm + 1) / 2 > tile) --bm;
-        const int bn = tile - bm * (bm + 1) / 2;
+        int bm, bn;
+        if (mode == GPAR_GRAD_SYM) {
+            bm = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+            while ((bm + 1) * (bm + 2) / 2 <= tile) ++bm;
+            while (bm * (bm + 1) / 2 > tile) --bm;
+            bn = tile - bm * (bm + 1) / 2;
+        } else if (mode == GPAR_GRAD_RECT) {
+            bm = tile / nt2;
+            bn = tile - bm * nt2;
+        } else {
+            bm = bn = tile;
+        }
         const int row0 = bm * GRAM_T, col0 = bn * GRAM_T;
         __syncthreads();
         for (int idx = t; idx < GRAM_T * dz; idx += 256) {
             const int r = idx / dz, d = idx - r * dz;
-            const bool ra = row0 + r < n, rb = col0 + r < n;
+            const bool ra = row0 + r < n, rb = col0 + r < n2;
             Za[d * GRAM_LD + r] = ra ? z[(size_t)(row0 + r) * ldz + d] : 0.0;
-            Zb[d * GRAM_LD + r] = rb ? z[(size_t)(col0 + r) * ldz + d] : 0.0;
+            Zb[d * GRAM_LD + r] = rb ? z2[(size_t)(col0 + r) * ldz2 + d] : 0.0;
             if (has_zd) {
                 Zda[d * GRAM_LD + r] = ra ? zd[(size_t)(row0 + r) * ldz + d] : 0.0;
-                Zdb[d * GRAM_LD + r] = rb ? zd[(size_t)(col0 + r) * ldz + d] : 0.0;
+                Zdb[d * GRAM_LD + r] = rb ? zd2[(size_t)(col0 + r) * ldz2 + d] : 0.0;
             }
         }
         __syncthreads();
@@ -240,9 +252,15 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(gpar_kspec_t ks, const d
             for (int j = 0; j < 4; ++j) {
                 const int row = row0 + 4 * ty + i, col = col0 + 4 * tx + j;
                 double v = 0.0;
-                if (row < n && col < n) {
-                    if (bm == bn) v = (col <= row) ? W[(size_t)row * ldw + col] : W[(size_t)col * ldw + row];
-                    else v = 2.0 * W[(size_t)row * ldw + col];
+                if (row < n && col < n2) {
+                    if (mode == GPAR_GRAD_SYM) {
+                        if (bm == bn) v = (col <= row) ? W[(size_t)row * ldw + col] : W[(size_t)col * ldw + row];
+                        else v = 2.0 * W[(size_t)row * ldw + col];
+                    } else if (mode == GPAR_GRAD_RECT) {
+                        v = W[(size_t)row * ldw + col];
+                    } else {
+                        v = (row == col) ? W[row] : 0.0;
+                    }
                 }
                 w[i][j] = v;
             }

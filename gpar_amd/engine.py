@@ -107,27 +107,50 @@ class HipEngine:
         """1/2 sum_ab W_ab dK_ab/dtheta for every parameter of the compiled kernel (W: lower triangle of a symmetric
         matrix).  One fused device pass produces per-term / per-factor / per-feature moment sums (csrc/gram.h); the
         chain rule from features to length scales, periods and alphas is applied here on the host."""
-        import numpy as np
-
         x = self._mat(x)
         z = hip.featurize(ck, x)
-        periodic = any(f.periods is not None for t in ck.kernel.terms for f in t.factors)
-        zd = hip.featurize_dfreq(ck, x) if periodic else None
+        zd = hip.featurize_dfreq(ck, x) if self._periodic(ck) else None
         raw = hip.gram_grad(ck, z, zd, W).cpu().numpy()
+        return self._grads_from_moments(ck, raw, 0.5)
+
+    def kernel_grads_vfe(self, ck, x, z, W_fu, W_uu, wdiag):
+        """sum_aj W_fu[a, j] dK(x_a, z_j) + sum_ij W_uu[i, j] dK(z_i, z_j) + sum_a wdiag[a] dk(x_a, x_a) for every kernel
+        parameter (the gradient of the inducing-point bound, gp.PseudoObs.gradients): three fused device passes whose
+        moment sums add, then the same host chain rule.  W_uu is symmetric (its lower triangle is read)."""
+        x, zp = self._mat(x), self._mat(z)
+        fx, fz = hip.featurize(ck, x), hip.featurize(ck, zp)
+        periodic = self._periodic(ck)
+        dx = hip.featurize_dfreq(ck, x) if periodic else None
+        dz = hip.featurize_dfreq(ck, zp) if periodic else None
+        raw = hip.gram_grad_cross(ck, fx, dx, fz, dz, self._mat(W_fu), hip.GRAD_RECT)
+        raw = raw + hip.gram_grad_cross(ck, fz, dz, fz, dz, self._mat(W_uu), hip.GRAD_SYM)
+        raw = raw + hip.gram_grad_cross(ck, fx, dx, fx, dx, wdiag.contiguous(), hip.GRAD_DIAG)
+        return self._grads_from_moments(ck, raw.cpu().numpy(), 1.0)
+
+    @staticmethod
+    def _periodic(ck):
+        return any(f.periods is not None for t in ck.kernel.terms for f in t.factors)
+
+    @staticmethod
+    def _grads_from_moments(ck, raw, scale):
+        """Host chain rule: moment sums (csrc/gram.h) -> d/d coefficient, length scales, periods, RQ alphas."""
+        import numpy as np
+
         nT, nF, nD = _lib.GPAR_MAX_TERMS, _lib.GPAR_MAX_FACTORS, _lib.GPAR_MAX_DIMS
         C, Al = raw[:nT], raw[nT : nT + nF]
         A, P = raw[nT + nF : nT + nF + nD], raw[nT + nF + nD :]
-        out = {"coef": [0.5 * C[t] for t in range(len(ck.kernel.terms))], "factors": [[] for _ in ck.kernel.terms]}
+        two = 2.0 * scale
+        out = {"coef": [scale * C[t] for t in range(len(ck.kernel.terms))], "factors": [[] for _ in ck.kernel.terms]}
         for flat, (ti, fi, off, nd) in enumerate(ck.layout):
             f = ck.kernel.terms[ti].factors[fi]
             scales = f.scales_value()
-            g = {"scales": -A[off : off + nd] / scales, "periods": None, "alpha": None}
+            g = {"scales": -two * A[off : off + nd] / scales, "periods": None, "alpha": None}
             if f.type == "rq":
-                g["alpha"] = 0.5 * Al[flat]
+                g["alpha"] = scale * Al[flat]
             if f.periods is not None:
                 periods = f.periods_value()
                 ncol = len(f.cols)
-                g["periods"] = -(P[off : off + ncol] + P[off + ncol : off + 2 * ncol]) * 2.0 * np.pi / periods**2
+                g["periods"] = -two * (P[off : off + ncol] + P[off + ncol : off + 2 * ncol]) * 2.0 * np.pi / periods**2
             out["factors"][ti].append(g)
         return out
 

@@ -129,7 +129,8 @@ def kernel_parameters(kernel):
 
 
 class _LogMarginal(torch.autograd.Function):
-    """log N(y; 0, K_theta + D) as a differentiable function of the kernel parameters and the noise vector.
+    """log N(y; 0, K_theta + D) - or, for inducing-point observations, the VFE bound - as a differentiable function of
+    the kernel parameters and the noise vector.
 
     Forward is the fused Gram + augmented Cholesky on the device.  Backward is analytic:
     with W = alpha alpha^T - K^-1,  d/dtheta = 1/2 sum_ab W_ab dK_ab/dtheta; K^-1 comes from L (TRSM on the
@@ -142,7 +143,7 @@ class _LogMarginal(torch.autograd.Function):
         ctx.obs = obs
         ctx.noise_shape = None if noise is None else tuple(noise.shape)
         ctx.shapes = [tuple(t.shape) for t in tensors]
-        return obs.factor().logpdf()
+        return obs._value()
 
     @staticmethod
     def backward(ctx, g):
@@ -344,6 +345,9 @@ class Obs:
                 return _LogMarginal.apply(self, noise, *[p[3] for p in params])
         return self.factor().logpdf()
 
+    def _value(self):
+        return self.factor().logpdf()
+
     def gradients(self):
         """(1/2 diag(W) as a device vector, kernel-parameter gradients) with W = alpha alpha^T - (K + D)^-1."""
         eng, fac, n = self.eng, self.factor(), self.fdd.n
@@ -524,13 +528,77 @@ class PseudoObs:
         # v = L_z^-T A^-1 c, so that mean(x*) = K_*z v
         v = facA.alpha().clone()  # (A^-1 c)^T, 1 x M
         eng.trsm_rln_(Lz, v)
-        self._state = {"ck": ck, "zu": zu, "Lz": Lz, "La": facA.L, "v": v, "elbo": elbo.detach().cpu()}
+        deferring = getattr(eng, "_deferred", None) is not None
+        self._state = {"ck": ck, "zu": zu, "Lz": Lz, "La": facA.L, "v": v, "elbo": elbo.detach() if deferring else elbo.detach().cpu(),
+                       "Bt": Bt, "facA": facA, "kdiag": kdiag}
         return self._state
 
-    def logpdf(self):
+    def _value(self):
         return self._compute()["elbo"]
 
+    def logpdf(self):
+        """The VFE bound; differentiable with respect to kernel parameters and noise when they carry a graph."""
+        if torch.is_grad_enabled():
+            params = kernel_parameters(self.fdd.p.kernel)
+            noise = self.fdd.noise_arg if _needs_grad(self.fdd.noise_arg) else None
+            if params or noise is not None:
+                self._params = params
+                self._noise_device = None if noise is None else noise.device
+                return _LogMarginal.apply(self, noise, *[p[3] for p in params])
+        return self._value()
+
     elbo = logpdf
+
+    def gradients(self):
+        """(dF/dd as a device vector, kernel-parameter gradients) of the VFE bound F (Titsias 2009, eq. 9).
+
+        With S = Q + D, Q = K_fu K_uu^-1 K_uf, G = alpha alpha^T - S^-1 (alpha = S^-1 y) and P = K_uu^-1 K_uf:
+            dF = sum_aj [W_fu]_aj dK_fu[a, j] + sum_ij [W_uu]_ij dK_uu[i, j] - 1/2 sum_a dk_aa / d_a + sum_a g_a dd_a,
+            W_fu = (G + D^-1) P^T,   W_uu = -1/2 P (G + D^-1) P^T,   g_a = 1/2 (G_aa + (k_aa - q_aa) / d_a^2).
+        Nothing n x n is formed: with B = L_z^-1 K_uf, A = I + B D^-1 B^T (both available from the forward pass),
+            G + D^-1 = alpha alpha^T + D^-1 B^T A^-1 B D^-1,
+            W_fu = [alpha beta^T + D^-1 B^T (I - A^-1)] L_z^-1,   beta = B alpha,
+            W_uu = -1/2 L_z^-T (beta beta^T + A - 2 I + A^-1) L_z^-1,
+            (S^-1)_aa = 1/d_a - |L_A^-1 B_:a|^2 / d_a^2.
+        The three weighted sums over kernel derivatives are one fused device pass each (`kernel_grads_vfe`)."""
+        eng = self.eng
+        st = self._compute()
+        n, M = self.fdd.n, self.u.n
+        d = self.fdd.noise
+        Bt, facA, Lz = st["Bt"], st["facA"], st["Lz"]
+        a = facA.alpha()  # (A^-1 B D^-1 y)^T, 1 x M
+        alpha = (self.y.reshape(-1) - eng.gemm(Bt, a, tb=True).reshape(-1)) / d  # S^-1 y
+        beta = eng.gemm(alpha.reshape(1, n), Bt)  # 1 x M
+        Ainv = eng.chol_inverse(facA.L)  # lower triangle of A^-1
+        Ainv_full = torch.tril(Ainv) + torch.tril(Ainv, -1).T
+        # W_fu
+        T = eng.new_matrix(n, M)
+        T.copy_(Bt)
+        eng.gemm(Bt, Ainv_full, alpha=-1.0, beta=1.0, out=T)  # B^T (I - A^-1)
+        T.div_(d[:, None])
+        T.add_(alpha[:, None] * beta.reshape(1, M))
+        eng.trsm_rln_(Lz, T)  # ... L_z^-1
+        # W_uu
+        S = eng.new_matrix(M, M)
+        S.copy_(beta.reshape(M, 1) * beta.reshape(1, M) + Ainv_full)
+        A_minus_I = eng.gemm(Bt / torch.sqrt(d)[:, None], Bt / torch.sqrt(d)[:, None], ta=True)  # B D^-1 B^T
+        S.add_(A_minus_I)
+        S.diagonal().sub_(1.0)
+        eng.trsm_rln_(Lz, S)  # S L_z^-1
+        St = eng.new_matrix(M, M)
+        St.copy_(S.T)
+        eng.trsm_rln_(Lz, St)  # L_z^-T S L_z^-1 (symmetric)
+        Wuu = eng.new_matrix(M, M)
+        Wuu.copy_(-0.25 * (St + St.T))
+        # per-point terms
+        E = eng.new_matrix(n, M)
+        E.copy_(Bt)
+        eng.trsm_rlt_(facA.L, E)  # rows: (L_A^-1 B_:a)^T
+        e = torch.sum(E * E, dim=1)
+        q = torch.sum(Bt * Bt, dim=1)
+        noise_grad = 0.5 * (alpha * alpha - 1.0 / d + e / (d * d) + (st["kdiag"] - q) / (d * d))
+        grads = eng.kernel_grads_vfe(st["ck"], self.fdd.x, self.u.x, T, Wuu, -0.5 / d)
+        return noise_grad, grads
 
     def posterior_mean(self, x):
         st = self._compute()

@@ -5,7 +5,6 @@ call into libgpar_hip.so on the tensor's `data_ptr()`.  All matrices are float64
 stride (`stride(1) == 1`); the leading dimension is `stride(0)`.
 """
 import ctypes
-
 import math
 
 import torch
@@ -29,6 +28,9 @@ __all__ = [
     "randn",
     "sample_stats",
     "trmv_lower",
+    "gram_grad",
+    "gram_grad_cross",
+    "chol_inverse",
 ]
 
 
@@ -333,6 +335,44 @@ def gram_grad(ck, z, zd, W, nblocks=None):
             out.data_ptr(), stream_ptr(z.device),
         ),
         "gpar_gram_grad",
+    )
+    return out
+
+
+GRAD_SYM, GRAD_RECT, GRAD_DIAG = 0, 1, 2
+
+
+def gram_grad_cross(ck, z1, zd1, z2, zd2, W, mode, nblocks=None):
+    """Raw moment sums (length GRAD_NACC, device tensor) of sum W dK/dtheta for the weight shapes of the VFE bound:
+    GRAD_SYM (z2 is z1, W symmetric, lower triangle read), GRAD_RECT (W: n1 x n2), GRAD_DIAG (z2 is z1, W: n1 weights of
+    the pairs (a, a)).  Full sums: no factor 1/2."""
+    lib = _lib.load()
+    _check_mat(z1, "z1")
+    _check_mat(z2, "z2")
+    n1, n2 = z1.shape[0], z2.shape[0]
+    nt1, nt2 = (n1 + 63) // 64, (n2 + 63) // 64
+    ntiles = nt1 * (nt1 + 1) // 2 if mode == GRAD_SYM else (nt1 * nt2 if mode == GRAD_RECT else nt1)
+    if nblocks is None:
+        nblocks = max(1, min(ntiles, 1024))
+    if mode == GRAD_DIAG:
+        if W.dim() != 1 or not W.is_contiguous() or W.numel() != n1:
+            raise ValueError("GRAD_DIAG takes a contiguous vector of n1 weights")
+        ldw = 1
+    else:
+        _check_mat(W, "W")
+        ldw = _ld(W)
+    work = torch.empty(nblocks * _lib.GRAD_NACC, dtype=torch.float64, device=z1.device)
+    out = torch.empty(_lib.GRAD_NACC, dtype=torch.float64, device=z1.device)
+    for a, b in ((zd1, z1), (zd2, z2)):
+        if a is not None and _ld(a) != _ld(b):
+            raise ValueError("features and their frequency derivatives must share a leading dimension")
+    _lib.check(
+        lib.gpar_gram_grad_cross(
+            ctypes.byref(ck.kspec), z1.data_ptr(), None if zd1 is None else zd1.data_ptr(), n1, _ld(z1), z2.data_ptr(),
+            None if zd2 is None else zd2.data_ptr(), n2, _ld(z2), ck.dz, W.data_ptr(), ldw, int(mode), work.data_ptr(), nblocks,
+            out.data_ptr(), stream_ptr(z1.device),
+        ),
+        "gpar_gram_grad_cross",
     )
     return out
 

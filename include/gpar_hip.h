@@ -127,6 +127,18 @@ int gpar_featurize_dfreq(const gpar_fspec_t* fs, const double* x, int n, int ldx
 int gpar_grad_nacc(void);
 int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, int n, int ldz, int dz, const double* W,
                    int ldw, double* workspace, int nblocks, double* out, void* stream);
+/* The same moment sums of  sum W dK/dtheta  for the other weight shapes the inducing-point (VFE) bound needs
+ * [gradient of the PseudoObs elbo, gpar/model.py:226,286-287 under varz's optimiser]:
+ *   GPAR_GRAD_SYM   z2 == z1: W symmetric n1 x n1, lower triangle read, sum over all pairs (what gpar_gram_grad does);
+ *   GPAR_GRAD_RECT  W a full n1 x n2 matrix of cross-Gram weights K(x1_a, x2_j);
+ *   GPAR_GRAD_DIAG  z2 == z1: W a vector of n1 weights of the prior variances k(x_a, x_a).
+ * Sums are FULL sums (no factor 1/2).  zd1 / zd2 may both be NULL.  nblocks <= number of 64 x 64 tiles of the mode. */
+#define GPAR_GRAD_SYM 0
+#define GPAR_GRAD_RECT 1
+#define GPAR_GRAD_DIAG 2
+int gpar_gram_grad_cross(const gpar_kspec_t* ks, const double* z1, const double* zd1, int n1, int ldz1, const double* z2,
+                         const double* zd2, int n2, int ldz2, int dz, const double* W, int ldw, int mode, double* workspace,
+                         int nblocks, double* out, void* stream);
 
 /* Partial right-looking blocked Cholesky of the leading `nf` columns of the symmetric N x N matrix A
  * (lower triangle).  On exit A[:, :nf] holds L (N x nf, lower trapezoid) and A[nf:, nf:] holds the Schur

@@ -85,6 +85,24 @@ class OracleEngine:
         w = w + np.tril(w, -1).T
         return ok.kernel_grads(ck.spec, _np(x), w)
 
+    def kernel_grads_vfe(self, ck, x, z, W_fu, W_uu, wdiag):
+        """sum_aj W_fu[a, j] dK(x_a, z_j) + sum_ij W_uu[i, j] dK(z_i, z_j) + sum_a wdiag[a] dk(x_a, x_a) for every kernel
+        parameter, through the explicit derivative matrices of the symmetric routine on the stacked points [z; x]:
+        each cross pair appears twice in a symmetric sum, hence the halves, and the routine returns half the sum."""
+        xz = np.concatenate([_np(z), _np(x)], axis=0)
+        M, n = _np(z).shape[0], _np(x).shape[0]
+        big = np.zeros((M + n, M + n))
+        wuu = _np(W_uu)
+        big[:M, :M] = 0.5 * (wuu + wuu.T)
+        big[M:, :M] = 0.5 * _np(W_fu)
+        big[:M, M:] = 0.5 * _np(W_fu).T
+        big[M:, M:] = np.diag(_np(wdiag).reshape(-1))
+        half = ok.kernel_grads(ck.spec, xz, big)
+        out = {"coef": [2.0 * c for c in half["coef"]], "factors": []}
+        for fgrads in half["factors"]:
+            out["factors"].append([{k: (None if v is None else 2.0 * np.asarray(v)) for k, v in g.items()} for g in fgrads])
+        return out
+
     # ---- factorisations ----------------------------------------------------------------------------
     def potrf_(self, A, nf=None):
         a = A.numpy()

@@ -190,6 +190,43 @@ def test_kernel_gradients_match_finite_differences(config):
                 assert abs(fd - g["alpha"]) < 1e-5 * (1 + abs(fd))
 
 
+def test_vfe_bound_gradient_matches_finite_differences(oracle_engine):
+    """d(VFE bound)/d(kernel parameters, noise) (gp.PseudoObs.gradients: W_fu, W_uu, diagonal and noise terms) against
+    central differences of the bound itself - every kernel family incl. periodic, non-uniform observation weights, a
+    scale shared by two factors (torch chains it), on the oracle engine."""
+    from gpar_amd.gp import GP, PseudoObs
+    from gpar_amd.kernels import EQ, RQ, Linear
+
+    rng = np.random.default_rng(0)
+    n, M = 32, 7
+    x, z = rng.uniform(0, 1, (n, 2)), rng.uniform(0, 1, (M, 2))
+    y = np.sin(4 * x[:, 0]) + x[:, 1] ** 2 + 0.05 * rng.standard_normal(n)
+    w = torch.tensor(rng.uniform(0.5, 1.5, n))
+
+    def bound(theta):
+        c1, s1, s2, a, c2, ls, noise, period, sp = theta
+        k = (
+            c1 * EQ().stretch(torch.stack([s1, s2]))
+            + c2 * RQ(a).stretch(ls).select([0])
+            + Linear().stretch(torch.stack([s2 * 2.0])).select([1])
+            + 0.7 * (EQ().stretch(torch.stack([sp, sp])).periodic(torch.stack([period])) * EQ().stretch(torch.stack([s1 * 3.0]))).select([0])
+        )
+        f = GP(k)
+        return PseudoObs(f(z), f(x, noise / w), y).elbo()
+
+    theta = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in [1.3, 0.6, 0.9, 1.7, 0.4, 0.5, 0.08, 0.8, 1.1]]
+    bound(theta).backward()
+    h = 1e-6
+    for i, t in enumerate(theta):
+        up = [u.detach().clone() for u in theta]
+        dn = [u.detach().clone() for u in theta]
+        up[i] += h
+        dn[i] -= h
+        with torch.no_grad():
+            fd = (float(bound(up)) - float(bound(dn))) / (2 * h)
+        assert abs(float(t.grad) - fd) <= 2e-6 * (1 + abs(fd)), (i, float(t.grad), fd)
+
+
 def _load_golden():
     with open(GOLDEN) as f:
         return json.load(f)
