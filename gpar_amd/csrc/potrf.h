@@ -495,7 +495,7 @@ static int trsm_rlt_run(const double* L, int n, int ldl, double* B, int nrows, i
 // column r, so block [c0, c1) only involves rows < c1 - the n^3 of a full solve becomes n^3 / 3.
 static int trsm_rlt_run2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int upper_tri, hipStream_t stream) {
     if (nrows <= 0) return 0;
-    const int NB = n >= 4096 ? 512 : (n >= 1024 ? 256 : 64);
+    const int NB = env_int("GPAR_TRSM_NB", n >= 4096 ? 512 : (n >= 1024 ? 256 : 64));
     const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && NB > 64 && gpar_aligned16(L) && gpar_aligned16(B) && (ldl % 2 == 0) && (ldb % 2 == 0);
     for (int c0 = 0, c1 = 0; c0 < n; c0 = c1) {
         c1 = (c0 + NB < n) ? c0 + NB : n;
