@@ -52,6 +52,7 @@ struct GemmArgs {
 };
 
 typedef double gpar_d2 __attribute__((ext_vector_type(2)));
+typedef double gpar_d4 __attribute__((ext_vector_type(4)));
 
 // Global -> register stage of one operand tile (4 x 16-byte chunks per thread).
 //   KC: tile element (r, kk) lives at g[(r0 + r) * ld + k0 + kk]     (r < 128, kk < 16)
@@ -110,7 +111,7 @@ __device__ __forceinline__ void gemm_sstore(double* __restrict__ s, int t, const
 // K loop of one 128 x 128 tile.  FAST (interior tile, aligned operands, k % 16 == 0) is branch-free so the loads
 // of stage s+1 stay in flight under the MFMAs of stage s; the other instantiation handles every edge case.
 template <bool A_KC, bool B_KC, bool FAST>
-__device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, double (&acc)[16][4], int m0, int n0,
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, gpar_d4 (&acc)[4][4], int m0, int n0,
                                               int kbeg, int kend, int nk, bool a_lower, int t, int lane, int wm, int wn) {
     gpar_d2 ra[4], rb[4];
     if (nk > 0) {
@@ -121,7 +122,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, d
     }
     __syncthreads();
 
-    const int l3 = lane & 3, l15 = lane & 15, lk = lane >> 4;
+    const int l15 = lane & 15, lk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const double* As = smem + (kt & 1) * 2 * GEMM_TILE;
         const double* Bs = As + GEMM_TILE;
@@ -130,25 +131,25 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, d
             gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, kbeg + (kt + 1) * GEMM_BK, kend, a_lower, t, ra);
             gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, kbeg + (kt + 1) * GEMM_BK, kend, false, t, rb);
         }
-#pragma unroll 1
+#pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const int kk = k4 * 4 + lk;
-            double pf[16], qf[4];
+            double af[4], bf[4];   // lane l: row / column l & 15 of each 16-wide block, k = 4 k4 + (l >> 4)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int r = wm * 64 + 16 * mi + l15;
+                af[mi] = A_KC ? As[r * GEMM_LDKC + kk] : As[kk * GEMM_LDMC + r];
+            }
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) {
                 const int c = wn * 64 + 16 * nj + l15;
-                qf[nj] = B_KC ? Bs[c * GEMM_LDKC + kk] : Bs[kk * GEMM_LDMC + c];
+                bf[nj] = B_KC ? Bs[c * GEMM_LDKC + kk] : Bs[kk * GEMM_LDMC + c];
             }
 #pragma unroll
-            for (int mi = 0; mi < 16; ++mi) {
-                const int r = wm * 64 + 4 * mi + l3;
-                pf[mi] = A_KC ? As[r * GEMM_LDKC + kk] : As[kk * GEMM_LDMC + r];
-            }
-#pragma unroll
-            for (int mi = 0; mi < 16; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int nj = 0; nj < 4; ++nj)
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f64_4x4x4f64(qf[nj], pf[mi], acc[mi][nj], 0, 0, 0);
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
         }
         if (more) {
             double* An = smem + ((kt + 1) & 1) * 2 * GEMM_TILE;
@@ -217,22 +218,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     }
     const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
 
-    double acc[16][4];
+    gpar_d4 acc[4][4];   // acc[mi][nj][v]: row 16 mi + (lane >> 4) + 4 v, column 16 nj + (lane & 15) of the wave tile
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+        for (int j = 0; j < 4; ++j) acc[i][j] = gpar_d4{0.0, 0.0, 0.0, 0.0};
 
     const bool fast = p.fastA && p.fastB && !a_lower && (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n) && ((kend - kbeg) % GEMM_BK == 0);
     if (fast) gemm_mainloop<A_KC, B_KC, true>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
     else gemm_mainloop<A_KC, B_KC, false>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
     const long long t_main = p.stamps ? (long long)__builtin_readcyclecounter() : 0;
-    const int l3 = lane & 3, lk = lane >> 4;
+    const int l15 = lane & 15, lk = lane >> 4;
 
-    // epilogue: lane l of acc[mi][nj] holds C[4*mi + (l&3)][16*nj + 4*((l>>2)&3) + (l>>4)] of the wave tile
+    // epilogue: register v of acc[mi][nj] holds C[16 mi + (lane >> 4) + 4 v][16 nj + (lane & 15)] of the wave tile
     const bool c_lower = (p.flags & GPAR_GEMM_C_LOWER) != 0;
-    const int colw = n0 + wn * 64 + 4 * ((lane >> 2) & 3) + lk;
-    const int roww = m0 + wm * 64 + l3;
+    const int colw = n0 + wn * 64 + l15;
+    const int roww = m0 + wm * 64 + lk;
     const double alpha = p.alpha, beta = p.beta;
     // Loads of C are never placed behind a per-element condition (hipcc would fence each with vmcnt(0): 64 serial
     // memory round trips per tile, measured as a fixed ~20 us per tile): interior tiles use plain loads/stores, edge
@@ -240,15 +241,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     const bool interior = (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n) && (!c_lower || n0 + GEMM_BN - 1 <= m0);
     if (interior && p.fastC) {
         // Interior tile, 16-byte aligned C: transpose the accumulators through LDS (the operand stages are dead
-        // after the K loop; every wave owns a private 18 KB slice, so no workgroup barrier is needed) so that each
-        // lane ends up with two ADJACENT columns of one row.  In the MFMA D layout neighbouring lanes hold different
-        // rows: a wave-level 8-byte access is 64 separate requests to four 128-byte lines, and the 64 loads + 64
-        // stores per lane of the straightforward epilogue cost ~30 k cycles per tile (tools/time_gemm_phases.hip).
-        // Transposed, a wave-level 16-byte access covers two full 512-byte row segments.
+        // after the K loop; every wave owns a private slice, so no workgroup barrier is needed) so that each lane ends
+        // up with two ADJACENT columns of one row: 16-byte accesses, two full 512-byte row segments per wave
+        // instruction, instead of 8-byte accesses in 128-byte runs straight from the MFMA layout.
         double* S = smem + w * GEMM_TILE;                     // [16][GEMM_LDT] doubles, private to this wave
         const int rrow = lane >> 5, rcol = (lane & 31) * 2;   // read-back: row 2 q + rrow, columns rcol, rcol + 1
         double* cbase = p.C + (size_t)(m0 + wm * 64 + rrow) * p.ldc + n0 + wn * 64 + rcol;
-        // four quarters of 16 rows; the C values of quarter h + 1 are requested before quarter h is processed
+        // four quarters of 16 rows (one mi each); the C values of quarter h + 1 are requested before quarter h is processed
         gpar_d2 cv[2][8];
         if (beta != 0.0) {
 #pragma unroll
@@ -257,10 +256,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj)
-                    S[(4 * mi + l3) * GEMM_LDT + 16 * nj + 4 * ((lane >> 2) & 3) + lk] = acc[4 * h + mi][nj];
+                for (int v = 0; v < 4; ++v) S[(lk + 4 * v) * GEMM_LDT + 16 * nj + l15] = acc[h][nj][v];
             if (h < 3 && beta != 0.0) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
@@ -269,57 +267,59 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            gpar_d2 v[8];
+            gpar_d2 v2[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const gpar_d2*>(S + (2 * q + rrow) * GEMM_LDT + rcol);
+            for (int q = 0; q < 8; ++q) v2[q] = *reinterpret_cast<const gpar_d2*>(S + (2 * q + rrow) * GEMM_LDT + rcol);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the next quarter overwrites S
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                gpar_d2 o = v[q] * alpha;
+                gpar_d2 o = v2[q] * alpha;
                 if (beta != 0.0) o = gpar_d2{fma(beta, cv[h & 1][q][0], o[0]), fma(beta, cv[h & 1][q][1], o[1])};
                 *reinterpret_cast<gpar_d2*>(cbase + (size_t)(16 * h + 2 * q) * p.ldc) = o;
             }
         }
     } else if (interior) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            double cv[8][4];
+        for (int mi = 0; mi < 4; ++mi) {
+            double cv[4][4];
             if (beta != 0.0) {
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
+                for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-                    for (int nj = 0; nj < 4; ++nj)
-                        cv[mi][nj] = p.C[(size_t)(roww + 4 * (8 * half + mi)) * p.ldc + colw + 16 * nj];
+                    for (int v = 0; v < 4; ++v)
+                        cv[nj][v] = p.C[(size_t)(roww + 16 * mi + 4 * v) * p.ldc + colw + 16 * nj];
             }
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
+            for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) {
-                    double v = alpha * acc[8 * half + mi][nj];
-                    if (beta != 0.0) v = fma(beta, cv[mi][nj], v);
-                    p.C[(size_t)(roww + 4 * (8 * half + mi)) * p.ldc + colw + 16 * nj] = v;
+                for (int v = 0; v < 4; ++v) {
+                    double x = alpha * acc[mi][nj][v];
+                    if (beta != 0.0) x = fma(beta, cv[nj][v], x);
+                    p.C[(size_t)(roww + 16 * mi + 4 * v) * p.ldc + colw + 16 * nj] = x;
                 }
         }
     } else {
 #pragma unroll
-        for (int mi = 0; mi < 16; ++mi) {
-            const int row = roww + 4 * mi;
-            const int rowc = min(row, p.m - 1);
-            double cv[4] = {0.0, 0.0, 0.0, 0.0};
-            if (beta != 0.0) {
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 4; ++nj) cv[nj] = p.C[(size_t)rowc * p.ldc + min(colw + 16 * nj, p.n - 1)];
-            }
+            for (int v = 0; v < 4; ++v) {
+                const int row = roww + 16 * mi + 4 * v;
+                const int rowc = min(row, p.m - 1);
+                double cv[4] = {0.0, 0.0, 0.0, 0.0};
+                if (beta != 0.0) {
 #pragma unroll
-            for (int nj = 0; nj < 4; ++nj) {
-                const int col = colw + 16 * nj;
-                const bool ok = row < p.m && col < p.n && (!c_lower || col <= row);
-                double v = alpha * acc[mi][nj];
-                if (beta != 0.0) v = fma(beta, cv[nj], v);
-                if (ok) p.C[(size_t)row * p.ldc + col] = v;
+                    for (int nj = 0; nj < 4; ++nj) cv[nj] = p.C[(size_t)rowc * p.ldc + min(colw + 16 * nj, p.n - 1)];
+                }
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    const int col = colw + 16 * nj;
+                    const bool ok = row < p.m && col < p.n && (!c_lower || col <= row);
+                    double x = alpha * acc[mi][nj][v];
+                    if (beta != 0.0) x = fma(beta, cv[nj], x);
+                    if (ok) p.C[(size_t)row * p.ldc + col] = x;
+                }
             }
-        }
     }
     if (p.stamps && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
