@@ -222,18 +222,18 @@ __device__ __forceinline__ void pnl_strip(const double* __restrict__ Cs, double*
 }
 
 // C (64 x 64 block at rows r0, cols c0 of A) -= Xs Bs^T, both LDS tiles [64][PNL_LD] with k contiguous.
-// Wave w owns rows 16 w .. 16 w + 15 (4 row patches) x all 64 columns (4 column patches): 16 accumulators.
-// In the MFMA D layout neighbouring lanes hold different rows, so reading / writing C straight from that layout is
-// 64 separate 8-byte requests per wave instruction: C is read and written row-contiguously instead (16 bytes per
-// lane, 256-byte row segments) and the accumulators are transposed into that layout, half a row patch (4 x 32) at a
-// time, through a small wave-private LDS buffer Tw ([4][PNL_LDT]).  The buffer is kept that small on purpose: the
+// Wave w owns rows 16 w .. 16 w + 15 x all 64 columns: four 16 x 16 v_mfma_f64_16x16x4 accumulators.
+// C is read and written row-contiguously (16 bytes per lane, 256-byte row segments: the accesses of the first version,
+// 8 bytes per lane straight from a 4x4x4 MFMA layout in which neighbouring lanes held different rows, were most of this
+// routine's time) and the accumulators are transposed into that layout, half a row patch (4 x 32) at a time, through a
+// small wave-private LDS buffer Tw ([4][PNL_LDT]).  The buffer is kept that small on purpose: the
 // whole workgroup must stay below the 73.7 KB of a SYRK workgroup, because LDS is allocated contiguously and the
 // hole a retiring SYRK workgroup leaves is exactly that big (a 76 KB version of this kernel was not dispatched
 // until the co-running trailing update had drained: tools/time_panel.hip).
 __device__ __forceinline__ void pnl_update(const PanelArgs& p, int r0, int c0, const double* __restrict__ Xs,
                                            const double* __restrict__ Bs, double* __restrict__ Tw, int t, bool lower_only) {
     const int lane = t & 63, w = t >> 6;
-    const int l3 = lane & 3, l15 = lane & 15, lk = lane >> 4;
+    const int l15 = lane & 15, lk = lane >> 4;
     const int rrow = lane >> 4, rcol = (lane & 15) * 2;
     // the C values of this lane are requested first so their memory latency runs under the MFMA loop
     pan_d2 cv[4][2];
@@ -243,24 +243,22 @@ __device__ __forceinline__ void pnl_update(const PanelArgs& p, int r0, int c0, c
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) cv[mi][hf] = *reinterpret_cast<const pan_d2*>(p.A + (size_t)row * p.lda + c0 + 32 * hf + rcol);
     }
-    double acc[4][4];
+    // v_mfma_f64_16x16x4: A lane l = (row l & 15, k = l >> 4), B lane l = (column l & 15, k = l >> 4); register v of the
+    // result holds row (l >> 4) + 4 v, column l & 15 (probed: profiles/r01_probe_mfma_f64_16x16x4.txt)
+    pan_d4 acc[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int b = 0; b < 4; ++b) acc[b] = pan_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
     for (int k4 = 0; k4 < 16; ++k4) {
         const int kk = 4 * k4 + lk;
-        double pf[4], qf[4];
+        const double af = Xs[(16 * w + l15) * PNL_LD + kk];
+        double bf[4];
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) qf[nj] = Bs[(16 * nj + l15) * PNL_LD + kk];
+        for (int nj = 0; nj < 4; ++nj) bf[nj] = Bs[(16 * nj + l15) * PNL_LD + kk];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) pf[mi] = Xs[(16 * w + 4 * mi + l3) * PNL_LD + kk];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_4x4x4f64(qf[nj], pf[mi], acc[mi][nj], 0, 0, 0);
+        for (int nj = 0; nj < 4; ++nj) acc[nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf[nj], acc[nj], 0, 0, 0);
     }
+    // rows 4 v .. 4 v + 3 of this wave's 16 sit in register v: one 4 x 64 patch per v, transposed half (4 x 32) at a time
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int rloc = 16 * w + 4 * mi + rrow;
@@ -268,7 +266,7 @@ __device__ __forceinline__ void pnl_update(const PanelArgs& p, int r0, int c0, c
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-            for (int nj = 0; nj < 2; ++nj) Tw[l3 * PNL_LDT + 16 * nj + 4 * ((lane >> 2) & 3) + lk] = acc[mi][2 * hf + nj];
+            for (int nj = 0; nj < 2; ++nj) Tw[lk * PNL_LDT + 16 * nj + l15] = acc[2 * hf + nj][mi];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

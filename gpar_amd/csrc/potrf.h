@@ -27,6 +27,7 @@ constexpr int POTRF_NBI = 64;   // inner block (diag / strip width)
 constexpr int PAN_LD = 66;   // LDS row pitch (doubles): even -> 16-byte aligned rows for ds_read_b128
 
 typedef double pan_d2 __attribute__((ext_vector_type(2)));
+typedef double pan_d4 __attribute__((ext_vector_type(4)));
 
 // 64 x 64 (or smaller, cb <= 64) diagonal block, one wave; lane i owns row i.  Blocked left-looking Cholesky:
 // for each 8-column block, (1) subtract the contribution of all previous columns (own row entries: lane-private
