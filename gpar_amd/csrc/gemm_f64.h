@@ -2,20 +2,17 @@
 //
 //   C <- alpha * op(A) op(B) + beta * C,   op(A): m x k, op(B): k x n, all row-major.
 //
-// Instruction choice (measured on MI355X, tools/ubench_mfma_f64.hip, profiles/r01_ubench_mfma_f64.txt):
-// v_mfma_f64_16x16x4_f64 saturates at 47-49 TFLOP/s on gfx950 (~100+ cycles per instruction), whereas
-// v_mfma_f64_4x4x4_4b_f64 issues every ~18 cycles: 64 TFLOP/s from one wave per SIMD, 71 TFLOP/s with
-// four (spec fp64 matrix peak: 78.6).  The kernel is therefore built on the 4x4x4 4-block form.
-//
-// Lane maps of v_mfma_f64_4x4x4_4b_f64 (probed, tools/probe_mfma_f64_4x4x4.hip; CBSZ/ABID broadcast is
-// ignored for this opcode):   A-operand lane l: k = l>>4, x = l&15;   B-operand lane l: k = l>>4, y = l&15;
-//   D lane l (block b=(l>>2)&3, i=l>>4, j=l&3) = sum_k A[x=4b+i][k] * B[y=4b+j][k]   (block-diagonal only).
-// We feed the N-side operand (16 distinct columns) as "A" and the M-side operand (4 rows, replicated over
-// the four blocks via an LDS broadcast read) as "B", so one instruction yields a 4(row) x 16(col) patch of C
-// with lane l holding C[row = l&3][col = 4*((l>>2)&3) + (l>>4)]: each row is a full 128-byte line on store.
+// Instruction: v_mfma_f64_16x16x4_f64.  With its accumulators pinned in registers it issues every ~64 cycles:
+// 72-75 TFLOP/s from one wave per SIMD, 78 from two (tools/probe_mfma_f64_16x16x4.hip; spec fp64 matrix peak 78.6);
+// rocBLAS' Tensile kernels for these shapes use it too (MI16x16x4x1, 76.6 TFLOP/s at 8192^3).  [The first version of
+// this kernel was built on v_mfma_f64_4x4x4_4b_f64 because an earlier micro-benchmark had "measured" 16x16x4 at 47-49
+// TFLOP/s: that benchmark let the compiler shuttle the 8-register accumulators between AGPRs and VGPRs on every
+// iteration and so timed the shuttle, not the instruction.  The 4x4x4 form tops out at 71 and needs 2.5x the LDS reads.]
+// Lane maps (probed, profiles/r01_probe_mfma_f64_16x16x4.txt): A-operand lane l = (row l & 15, k = l >> 4);
+// B-operand lane l = (column l & 15, k = l >> 4); register v of D holds row (l >> 4) + 4 v, column l & 15.
 //
 // Work decomposition: 256 threads = 4 waves (2 x 2), workgroup tile 128 x 128, wave tile 64 x 64 =
-// 16 (row patches) x 4 (column patches) accumulators = 64 f64 = 128 VGPRs; BK = 16 per stage, two LDS
+// 4 x 4 accumulators of 16 x 16 = 64 f64 = 128 VGPRs (arch VGPRs: no AGPR traffic); BK = 16 per stage, two LDS
 // stages (73.7 KB) so two workgroups share a CU (2 waves per SIMD) and cover each other's barrier/staging.
 // Operand tiles are staged global -> registers -> LDS (the loads for stage s+1 are issued before the
 // MFMAs of stage s), in one of two padded, bank-conflict-free LDS images:

@@ -14,7 +14,7 @@
 //   * every workgroup, for each of its row blocks rb > s: waits for flag1[s], solves its 64 rows against L_ss
 //     (blocked substitution, one wave), writes X = L[rb][s], publishes it if rb < S (flag2[s][rb]: those rows are
 //     the B operands of everybody's updates), then applies  A[rb][c] -= X L[c][s]^T  for c = s+1 .. min(rb, S-1)
-//     on the matrix cores (v_mfma_f64_4x4x4_4b; X and L[c][s] in LDS, C read-modify-written in global memory).
+//     on the matrix cores (v_mfma_f64_16x16x4; X and L[c][s] in LDS, C read-modify-written in global memory).
 // Hand-offs follow the agent-scope release / acquire recipe (cdna_hip_programming.md Guideline 16): plain stores ->
 // every wave drains vmcnt -> barrier -> one lane: release fence + asm vmcnt(0) + relaxed agent-scope flag store;
 // consumer: one lane polls relaxed, one acquire fence, barrier, plain loads.  The flag words live in the strict

@@ -164,7 +164,7 @@ int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb
 int gpar_chol_inverse(const double* L, int n, int ldl, double* X, int ldx, double* Kinv, int ldk, void* stream);
 
 /* C <- alpha * op(A) op(B) + beta * C with op(A) m x k, op(B) k x n.  ta: A is stored k x m (transposed);
- * tb: B is stored n x k (transposed).  fp64 on the matrix cores (v_mfma_f64_4x4x4_4b).
+ * tb: B is stored n x k (transposed).  fp64 on the matrix cores (v_mfma_f64_16x16x4).
  * [B.matmul in lab: K_*x alpha, V^T V, chol(var) z] */
 int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
               int ldb, double beta, double* C, int ldc, int flags, void* stream);
