@@ -10,7 +10,7 @@ streams and, since the epilogue transposes through LDS, for the 16-byte read-mod
 """
 import csv, json, sys
 
-KERNEL = "gemm_f64_kernel<false, true, 1>"
+KERNEL = "gemm_f64_kernel<false, true, 1>"  # every trailing-update launch of gpar_potrf, look-ahead slices included
 
 
 def read(dirname, counter):
