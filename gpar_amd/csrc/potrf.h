@@ -257,7 +257,8 @@ struct PotrfPolicy {
     int lookahead;  // overlap panel k+1 with the trailing update of panel k on a second stream
     int split;      // factor the diagonal block first, then solve the rows below (see potrf_panel_split)
     int fused;      // factor each top-level panel with the persistent fused kernel (panel.h)
-    int pair_rows;  // panels with at least this many rows left are factored in pairs (one rank-2*nbo trailing update)
+    int pair_rows;  // panels with at least this many rows left are factored in groups (one rank-group*nbo trailing update)
+    int group;      // panels per group
 };
 
 static int env_int(const char* name, int dflt) {
@@ -288,6 +289,7 @@ static PotrfPolicy potrf_policy(int N) {
     p.lookahead = env_int("GPAR_POTRF_LOOKAHEAD", p.lookahead);
     p.split = env_int("GPAR_POTRF_SPLIT", 0);
     p.pair_rows = env_int("GPAR_POTRF_PAIR_ROWS", 8192);
+    p.group = env_int("GPAR_POTRF_GROUP", 2);
     if (p.nbo < 64) p.nbo = 64;
     if (p.nbm < 64) p.nbm = 64;
     return p;
@@ -441,26 +443,28 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // writes every remaining element once per 1024 columns instead of once per 512, and a K = 1024 SYRK runs ~8 % faster
     // than two K = 512 ones.  The price is a longer serial stretch per step (two panels + the narrow update), so the
     // pairing stops once the trailing update is too short to hide it (`pair_rows`).
-    auto pairable = [&](int k) {
-        return pol.fused && nbo % 64 == 0 && k + 2 * nbo <= nf && (N - k) >= pol.pair_rows && (k % 2 == 0) && (lda % 2 == 0) &&
+    const int G = pol.group;
+    auto groupable = [&](int k) {
+        return G > 1 && pol.fused && nbo % 64 == 0 && k + G * nbo <= nf && (N - k) >= pol.pair_rows && (k % 2 == 0) && (lda % 2 == 0) &&
                gpar_aligned16(A);
     };
     for (int k0 = 0, knext = 0; k0 < nf; k0 = knext) {
         int kend = (k0 + nbo < nf) ? k0 + nbo : nf;
         // a ragged tail (nf not a multiple of 64) becomes its own narrow panel so the wide part stays fusable
         if (pol.fused && (kend - k0) > 64 && (kend - k0) % 64 != 0) kend = k0 + (kend - k0) / 64 * 64;
-        int rc;
-        if (pairable(k0)) {
-            const int kmid = k0 + nbo;
-            kend = k0 + 2 * nbo;
-            rc = potrf_panel_fused(A, N, lda, k0, nbo, logdet, info, stream);
-            if (!rc) {   // the second panel's columns, rank nbo
-                bool pb;
-                prof_begin(stream, pb);
-                rc = potrf_gemm_update(c, k0, kmid, kend, stream, 1);
-                prof_end(stream, pb, N - kmid, kend - kmid, kmid - k0);
+        int rc = 0;
+        if (groupable(k0)) {
+            kend = k0 + G * nbo;
+            for (int i = 0; i < G && !rc; ++i) {
+                const int ks = k0 + i * nbo;
+                if (i > 0) {   // this panel's columns: one update by the i panels of the group factored so far
+                    bool pb;
+                    prof_begin(stream, pb);
+                    rc = potrf_gemm_update(c, k0, ks, ks + nbo, stream, 1);
+                    prof_end(stream, pb, N - ks, nbo, ks - k0);
+                }
+                if (!rc) rc = potrf_panel_fused(A, N, lda, ks, nbo, logdet, info, stream);
             }
-            if (!rc) rc = potrf_panel_fused(A, N, lda, kmid, nbo, logdet, info, stream);
         } else {
             const int w = kend - k0;
             const bool fused_ok = pol.fused && w % 64 == 0 && w <= 1024 && N - k0 >= 64 && (k0 % 2 == 0) && (lda % 2 == 0) && gpar_aligned16(A);
@@ -471,7 +475,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         if (rc) return rc;
         if (kend >= N) break;
         // columns the next step factors (one panel, or two if it pairs): [kend, next_end)
-        const int next_w = pairable(kend) ? 2 * nbo : nbo;
+        const int next_w = groupable(kend) ? G * nbo : nbo;
         const int next_end = (kend + next_w < nf) ? kend + next_w : nf;
         bool pa;
         if (!la || kend >= nf) {
