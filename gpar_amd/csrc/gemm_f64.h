@@ -128,6 +128,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, g
             gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, kbeg + (kt + 1) * GEMM_BK, kend, a_lower, t, ra);
             gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, kbeg + (kt + 1) * GEMM_BK, kend, false, t, rb);
         }
+        // the wave that is in its MFMA phase wins issue arbitration over its neighbour's staging instructions (measured:
+        // 68.5 -> 70.3 TFLOP/s at 8192^3, 63.1 -> 64.3 at the K = 512 trailing-update shape; priority 3 is no better than 1)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const int kk = k4 * 4 + lk;
@@ -148,6 +151,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, g
                 for (int nj = 0; nj < 4; ++nj)
                     acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         if (more) {
             double* An = smem + ((kt + 1) & 1) * 2 * GEMM_TILE;
             gemm_sstore<A_KC>(An, t, ra);
