@@ -313,6 +313,42 @@ def test_kernel_gradients_match_oracle(env, m, p_cols, n):
                     assert np.allclose(gf[key], rf[key], rtol=1e-10, atol=1e-12 * scale), (name, key, t, fi)
 
 
+@pytest.mark.parametrize("n,M", [(70, 9), (257, 65), (130, 200)])
+def test_cross_and_diagonal_gradient_passes_match_oracle(env, n, M):
+    """gpar_gram_grad_cross in its three modes (rectangular n x M weights, symmetric M x M, diagonal) through
+    HipEngine.kernel_grads_vfe vs the oracle's explicit derivative matrices on the stacked points: ragged tiles,
+    more columns than rows, every kernel family."""
+    torch, hip, dev, to_dev = env
+    from gpar_amd.engine import HipEngine
+    from gpar_amd.kernels import compile_kernel
+    from oracle.engine import OracleEngine
+
+    eng, ora = HipEngine(), OracleEngine()
+    m, p_cols = 2, [2, 3]
+    width = 4
+    rng = np.random.default_rng(n + M)
+    x, z = rng.standard_normal((n, width)), rng.standard_normal((M, width))
+    Wfu = rng.standard_normal((n, M))
+    Wuu = rng.standard_normal((M, M))
+    Wuu = Wuu + Wuu.T
+    wd = rng.standard_normal(n)
+    for name, k in _kernels(m, p_cols).items():
+        if name == "zero":
+            continue
+        ck = compile_kernel(k, width)
+        got = eng.kernel_grads_vfe(ck, to_dev(x), to_dev(z), to_dev(Wfu), to_dev(np.tril(Wuu) + np.triu(np.full((M, M), np.nan), 1)),
+                                   torch.tensor(wd, device=dev))
+        ref = ora.kernel_grads_vfe(ora.compile(k, width), torch.tensor(x), torch.tensor(z), torch.tensor(Wfu), torch.tensor(Wuu), torch.tensor(wd))
+        scale = np.abs(Wfu).sum() + np.abs(Wuu).sum() + np.abs(wd).sum()
+        for t in range(len(ref["coef"])):
+            assert abs(got["coef"][t] - ref["coef"][t]) <= 1e-12 * scale, (name, "coef", t)
+            for fi, (gf, rf) in enumerate(zip(got["factors"][t], ref["factors"][t])):
+                for key in ("scales", "periods", "alpha"):
+                    if rf[key] is None:
+                        continue
+                    assert np.allclose(gf[key], rf[key], rtol=1e-10, atol=1e-12 * scale), (name, key, t, fi)
+
+
 @pytest.mark.parametrize("n", [1, 50, 64, 129, 700, 1500, 4200])
 def test_chol_inverse(env, n):
     """Triangular-aware (L L^T)^-1: two-level TRSM of the identity + SYRK that starts k at the tile's first row."""
