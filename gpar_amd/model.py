@@ -155,7 +155,7 @@ class GPAR:
         eng = get_engine()
         # Observed data only: no layer needs another's posterior, so the factorisations (otherwise done lazily, one
         # after the other, when the posterior is first used) are issued now on alternating streams.
-        pipe = eng.pipeline() if self._independent(items) else None
+        pipe = eng.pipeline(rows=int(x.shape[0])) if self._independent(items) else None
         with eng.defer_checks(), _joining(pipe):  # streams are joined BEFORE the deferred info words are read
             for stage, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, self.layers))):
                 complete = isinstance(mask, slice)
@@ -187,7 +187,7 @@ class GPAR:
         items = list(per_output(y, w, keep=self.impute or sample_missing))
         eng = get_engine()
         # layers that do not feed one another (observed data only) are spread over alternating streams
-        pipe = eng.pipeline() if self._independent(items) and not return_inputs else None
+        pipe = eng.pipeline(rows=int(x.shape[0])) if self._independent(items) and not return_inputs else None
         values, stage = [], 0
         with eng.defer_checks(), _joining(pipe):  # streams are joined BEFORE the deferred info words are read
             for is_last, ((yi, wi, mask), model) in last(zip(items, self.layers), select=outputs):

@@ -61,7 +61,7 @@ def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
 
     items = list(per_output(y, w, keep=gpar.impute))
     # this rank's layers alternate over two streams when no layer feeds another (see HipEngine.pipeline)
-    pipe = get_engine().pipeline() if gpar._independent(items) else None
+    pipe = get_engine().pipeline(rows=int(x.shape[0])) if gpar._independent(items) else None
     values, stage = [], 0
     with _joining(pipe):
         for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, gpar.layers))):
@@ -180,7 +180,7 @@ def sharded_condition(reg, group=None):
     from .engine import joining
 
     post = gpar.copy()
-    pipe = eng.pipeline()
+    pipe = eng.pipeline(rows=int(x.shape[0]))
     factors = []
     with eng.defer_checks(), joining(pipe):
         for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, gpar.layers))):

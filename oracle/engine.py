@@ -197,7 +197,7 @@ class OracleEngine:
             return mean, None, None
         return mean, torch.from_numpy(np.percentile(arr, q_lo, axis=0)), torch.from_numpy(np.percentile(arr, q_hi, axis=0))
 
-    def pipeline(self, depth=2):
+    def pipeline(self, depth=None, rows=None):
         return None  # one CPU, nothing to overlap
 
     _deferred = None
