@@ -11,7 +11,7 @@ for n in [int(a) for a in sys.argv[1:]] or [32768]:
     K.copy_(torch.exp(-0.5 * torch.cdist(X, X) ** 2 / 0.25)); K.diagonal().add_(0.1)
     v = torch.randn(n, 3, dtype=torch.float64, generator=g).to(dev)
     Kv = K[:, :n] @ v
-    A = K.clone()
+    A = hip.alloc_matrix(n, n, dev); A.copy_(K)   # (K.clone() would be contiguous: an odd leading dimension takes the scalar paths)
     logdet = torch.zeros(1, dtype=torch.float64, device=dev); info = torch.zeros(1, dtype=torch.int32, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); hip.potrf_(A, logdet=logdet, info=info); e1.record(); e1.synchronize()
