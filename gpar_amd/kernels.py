@@ -12,7 +12,6 @@ include/gpar_hip.h, so that the whole layer kernel and its noise diagonal are pr
 pass.  Hyper-parameters may be Python floats, numpy arrays or torch tensors (the latter keep their autograd
 graph; only their values are lowered).
 """
-import ctypes
 import math
 
 import numpy as np

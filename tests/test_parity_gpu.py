@@ -10,7 +10,6 @@ well-conditioned problems (noise >= 1e-2 of the signal); posterior moments rtol 
 shared Philox stream atol 1e-8; trained hyper-parameters after identical L-BFGS-B iteration counts rtol 1e-5.
 """
 import json
-import os
 
 import numpy as np
 import pytest
