@@ -323,3 +323,19 @@ def test_batched_sampling_agrees_with_sequential_sampling(engine, kw):
     scale = sequential.std(axis=0) + 0.02
     assert np.all(np.abs(batched.mean(axis=0) - sequential.mean(axis=0)) < 4 * scale / np.sqrt(S) * 2)
     assert np.all(np.abs(batched.std(axis=0) - sequential.std(axis=0)) < 0.35 * scale)
+
+
+def test_paper_synthetic_experiment_gpar_beats_independent_gps(engine):
+    """BASELINE configs[0] (reference examples/paper/synthetic.py): three mutually dependent outputs, 25 noisy observations;
+    GPAR's latent predictive means must be clearly closer to the truth than independent GPs' on the dependent outputs."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "synthetic_paper.py")
+    spec = importlib.util.spec_from_file_location("synthetic_paper", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run(iters=60, num_samples=60)
+    gpar, igp = out["gpar"]["rmse"], out["independent"]["rmse"]
+    assert gpar[1] < 0.75 * igp[1] and gpar[2] < 0.75 * igp[2], (gpar, igp)
+    assert out["gpar"]["logpdf"] > out["independent"]["logpdf"]
