@@ -97,10 +97,24 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
                         }
                 }
             }
+            // the type is uniform: dispatch once, and keep only four exponentials in flight at a time (all sixteen at once
+            // cost ~60 VGPRs of temporaries and halve the occupancy of a kernel that lives on latency hiding)
+            if (type == GPAR_K_EQ) {
+#pragma unroll 1
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) prod[i][j] *= exp(-0.5 * s[i][j]);
+            } else if (type == GPAR_K_RQ) {
+#pragma unroll 1
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) prod[i][j] *= gram_nonlin(type, s[i][j], alpha);
+                    for (int j = 0; j < 4; ++j) prod[i][j] *= exp(-alpha * log1p(s[i][j] / (2.0 * alpha)));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) prod[i][j] *= s[i][j];
+            }
             ++f;
         }
 #pragma unroll
