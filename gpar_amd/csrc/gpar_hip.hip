@@ -179,7 +179,9 @@ int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const 
     const int sym = (z1 == z2 && n1 == n2) ? 1 : 0;
     if ((flags & GPAR_GRAM_LOWER) && !sym) return GPAR_ARG_ERROR(5);
     const size_t lds = (size_t)2 * (dz > 0 ? dz : 1) * GRAM_LD * sizeof(double);
-    dim3 grid(gpar_ceil_div(n2, GRAM_T), gpar_ceil_div(n1, GRAM_T));
+    const int nt1 = gpar_ceil_div(n1, GRAM_T), nt2 = gpar_ceil_div(n2, GRAM_T);
+    dim3 grid(nt2, nt1);
+    if (flags & GPAR_GRAM_LOWER) grid = dim3((unsigned)((long long)nt1 * (nt1 + 1) / 2), 1);
     hipLaunchKernelGGL(gram_kernel, grid, dim3(256), lds, (hipStream_t)stream, *ks, z1, n1, ldz1, z2, n2, ldz2, dz, K, ldk,
                        flags, diag_add, diag_const, sym);
     GPAR_LAUNCH_CHECK();

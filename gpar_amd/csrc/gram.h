@@ -41,8 +41,15 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
                                                    double* __restrict__ K, int ldk, int flags,
                                                    const double* __restrict__ diag_add, double diag_const, int sym) {
     extern __shared__ __attribute__((aligned(16))) double gsm[];
-    const int bm = blockIdx.y, bn = blockIdx.x;
-    if ((flags & GPAR_GRAM_LOWER) && bn > bm) return;
+    int bm = blockIdx.y, bn = blockIdx.x;
+    if (flags & GPAR_GRAM_LOWER) {
+        // 1-D grid over the tiles of the lower triangle (a 2-D grid would launch as many empty workgroups again)
+        const int tile = blockIdx.x;
+        bm = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+        while ((bm + 1) * (bm + 2) / 2 <= tile) ++bm;
+        while (bm * (bm + 1) / 2 > tile) --bm;
+        bn = tile - bm * (bm + 1) / 2;
+    }
     double* Za = gsm;
     double* Zb = gsm + (size_t)dz * GRAM_LD;
     const int t = threadIdx.x;
