@@ -61,95 +61,81 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
     }
     __syncthreads();
     const int tx = t & 15, ty = t >> 4;
-    double total[4][4];
+    const bool vec = ((ldk & 1) == 0) && ((((uintptr_t)K) & 15u) == 0);
+    // Two passes of a 4 x 2 micro-tile per thread (columns 2 tx, 2 tx + 1 of the left, then of the right half of the tile)
+    // instead of one 4 x 4: half the live accumulators (the 4 x 4 form needed 183-206 VGPRs: two waves per SIMD for a kernel
+    // that lives on latency hiding), and every 16-byte store of a row group is one contiguous 256-byte run.
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const int cb = 32 * h + 2 * tx;   // first of this thread's two columns within the tile
+        double total[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) total[i][0] = total[i][1] = 0.0;
+        int f = 0;
+        for (int term = 0; term < ks.nterms; ++term) {
+            double prod[4][2];
+            const double coef = ks.coef[term];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) total[i][j] = 0.0;
-
-    int f = 0;
-    for (int term = 0; term < ks.nterms; ++term) {
-        double prod[4][4];
-        const double coef = ks.coef[term];
+            for (int i = 0; i < 4; ++i) prod[i][0] = prod[i][1] = coef;
+            while (f < ks.nfactors && ks.factor[f].term == term) {
+                const int type = ks.factor[f].type, off = ks.factor[f].off, nd = ks.factor[f].nd;
+                const double alpha = ks.factor[f].alpha;
+                double s[4][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) s[i][0] = s[i][1] = 0.0;
+                for (int d = off; d < off + nd; ++d) {
+                    double za[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) prod[i][j] = coef;
-        while (f < ks.nfactors && ks.factor[f].term == term) {
-            const int type = ks.factor[f].type, off = ks.factor[f].off, nd = ks.factor[f].nd;
-            const double alpha = ks.factor[f].alpha;
-            double s[4][4];
+                    for (int i = 0; i < 4; ++i) za[i] = Za[d * GRAM_LD + 4 * ty + i];
+                    const double zb0 = Zb[d * GRAM_LD + cb], zb1 = Zb[d * GRAM_LD + cb + 1];
+                    if (type == GPAR_K_LINEAR) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < 4; ++i) { s[i][0] = fma(za[i], zb0, s[i][0]); s[i][1] = fma(za[i], zb1, s[i][1]); }
+                    } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s[i][j] = 0.0;
-            for (int d = off; d < off + nd; ++d) {
-                double za[4], zb[4];
+                        for (int i = 0; i < 4; ++i) {
+                            const double d0 = za[i] - zb0, d1 = za[i] - zb1;
+                            s[i][0] = fma(d0, d0, s[i][0]);
+                            s[i][1] = fma(d1, d1, s[i][1]);
+                        }
+                    }
+                }
+                if (type == GPAR_K_EQ) {   // the type is uniform: dispatch once per factor, not per entry
 #pragma unroll
-                for (int i = 0; i < 4; ++i) za[i] = Za[d * GRAM_LD + 4 * ty + i];
+                    for (int i = 0; i < 4; ++i) { prod[i][0] *= exp(-0.5 * s[i][0]); prod[i][1] *= exp(-0.5 * s[i][1]); }
+                } else if (type == GPAR_K_RQ) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) zb[j] = Zb[d * GRAM_LD + 4 * tx + j];
-                if (type == GPAR_K_LINEAR) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) s[i][j] = fma(za[i], zb[j], s[i][j]);
+                    for (int i = 0; i < 4; ++i) {
+                        prod[i][0] *= exp(-alpha * log1p(s[i][0] / (2.0 * alpha)));
+                        prod[i][1] *= exp(-alpha * log1p(s[i][1] / (2.0 * alpha)));
+                    }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const double df = za[i] - zb[j];
-                            s[i][j] = fma(df, df, s[i][j]);
-                        }
+                    for (int i = 0; i < 4; ++i) { prod[i][0] *= s[i][0]; prod[i][1] *= s[i][1]; }
                 }
+                ++f;
             }
-            // the type is uniform: dispatch once, and keep only four exponentials in flight at a time (all sixteen at once
-            // cost ~60 VGPRs of temporaries and halve the occupancy of a kernel that lives on latency hiding)
-            if (type == GPAR_K_EQ) {
-#pragma unroll 1
-                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) prod[i][j] *= exp(-0.5 * s[i][j]);
-            } else if (type == GPAR_K_RQ) {
-#pragma unroll 1
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) { total[i][0] += prod[i][0]; total[i][1] += prod[i][1]; }
+        }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) prod[i][j] *= exp(-alpha * log1p(s[i][j] / (2.0 * alpha)));
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * ty + i;
+            if (row >= n1) continue;
+            const int col = col0 + cb;
+            if (sym) {
+                const double dadd = (diag_add ? diag_add[row] : 0.0) + diag_const;
+                if (col == row) total[i][0] += dadd;
+                if (col + 1 == row) total[i][1] += dadd;
+            }
+            double* out = K + (size_t)row * ldk + col;
+            if (vec && col + 1 < n2) {
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<d2*>(out) = d2{total[i][0], total[i][1]};
             } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) prod[i][j] *= s[i][j];
+                if (col < n2) out[0] = total[i][0];
+                if (col + 1 < n2) out[1] = total[i][1];
             }
-            ++f;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) total[i][j] += prod[i][j];
-    }
-
-    const bool vec = ((ldk & 1) == 0) && ((((uintptr_t)K) & 15u) == 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + 4 * ty + i;
-        if (row >= n1) continue;
-        const int col = col0 + 4 * tx;
-        if (sym) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (col + j == row) total[i][j] += (diag_add ? diag_add[row] : 0.0) + diag_const;
-        }
-        double* out = K + (size_t)row * ldk + col;
-        if (vec && col + 3 < n2) {
-            typedef double d2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<d2*>(out) = d2{total[i][0], total[i][1]};
-            *reinterpret_cast<d2*>(out + 2) = d2{total[i][2], total[i][3]};
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (col + j < n2) out[j] = total[i][j];
         }
     }
 }
