@@ -34,7 +34,7 @@ print(json.dumps({
     "traffic_over_algorithmic": (wb + fb) / algorithmic,
     "duration_ms": 1e3 * t,
     "achieved_GBps": (wb + fb) / t * 1e-9, "hbm_peak_GBps": 8000.0, "frac_of_hbm_peak": (wb + fb) / t / 8e12,
-    "note": "every entry is written exactly once and nothing n x n is read (traffic = 1.0x algorithmic); the kernel is bound by the "
-            "vector ALUs (generic evaluation of a run-time kernel specification: 0.50 ms remain with exponentials and stores removed), "
-            "which is why it sits at a fifth of the HBM roofline; it is 1.3 % of the step",
+    "note": "every entry is written exactly once and nothing n x n is read; the fetches are the 64-row feature panels of the tiles "
+            "(L2 misses of a 2 MB array that every tile re-reads).  The kernel is bound by the vector ALUs (generic evaluation of a "
+            "run-time kernel specification + two fp64 exponentials per entry), not by HBM; it is ~1 % of the step",
 }, indent=1))
