@@ -358,6 +358,23 @@ def test_full_size_cholesky_properties(hip, n, m, p_cols):
     assert abs(float(logdet) - 2 * float(torch.log(torch.diagonal(L)).sum())) <= 1e-10 * abs(float(logdet))
 
 
+@pytest.mark.parametrize("n,bad", [(10000, 7777), (16384, 100), (16384, 16000)])
+def test_non_positive_pivot_is_reported_at_full_size(hip, n, bad):
+    """LAPACK-style info through every fast path at once (fused panels, paired panels, look-ahead on the side stream):
+    the first non-positive pivot is reported 1-based, whatever garbage the later panels then compute."""
+    from gpar_amd import hip as H
+
+    dev = hip.device
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(n, 3, generator=g, dtype=torch.float64).to(dev)
+    A = H.alloc_matrix(n, n, dev)
+    A.copy_(torch.exp(-0.5 * torch.cdist(x, x) ** 2 / 0.25))
+    A.diagonal().add_(0.1)
+    A[bad, bad] = -5.0
+    _, info = H.potrf_(A)
+    assert int(info.item()) == bad + 1
+
+
 def test_c2_logpdf_chain_rule_and_vfe_tightness(hip):
     """n = 4096, m = 2, p = 4 (BASELINE C2): the joint log-likelihood equals the sum of the per-layer conditionals
     computed one at a time, and with inducing points at a subset == all inputs of a small problem the bound is tight."""
