@@ -115,18 +115,17 @@ __device__ __forceinline__ void pnl_store_tile(const PanelArgs& p, int r0, int c
     }
 }
 
-// Rank-8 right-looking update shared by the diagonal factorisation and the strip solve, all four waves:
-//   D[i][k] -= sum_{j<8} D[i][8 jb + j] * Cf[k][8 jb + j]      for k = 8 jb + 8 .. 63 (wave w takes k = w mod 4),
+// Rank-8 right-looking update shared by the diagonal factorisation and the strip solve:
+//   D[i][k] -= sum_{j<8} D[i][8 jb + j] * Cf[k][8 jb + j]      for k = kbeg, kbeg + kstep, ... < 64,
 // lane i = row.  The row's own 8 values are one lane-private read; the 8 coefficients of column k are a
 // wave-uniform broadcast read.
-__device__ __forceinline__ void pnl_rank8(double* __restrict__ D, const double* __restrict__ Cf, int jb, int t) {
-    const int i = t & 63, w = t >> 6;
+__device__ __forceinline__ void pnl_rank8(double* __restrict__ D, const double* __restrict__ Cf, int jb, int i, int kbeg, int kstep) {
     double mine[8];
     const pan_d2* ms = reinterpret_cast<const pan_d2*>(&D[i * PNL_LD + 8 * jb]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const pan_d2 v = ms[q]; mine[2 * q] = v[0]; mine[2 * q + 1] = v[1]; }
 #pragma unroll 2
-    for (int k = 8 * jb + 8 + w; k < 64; k += 4) {
+    for (int k = kbeg; k < 64; k += kstep) {
         const pan_d2* cs = reinterpret_cast<const pan_d2*>(&Cf[k * PNL_LD + 8 * jb]);
         const pan_d2 c0 = cs[0], c1 = cs[1], c2 = cs[2], c3 = cs[3];
         double v0 = D[i * PNL_LD + k], v1 = 0.0;
@@ -138,19 +137,51 @@ __device__ __forceinline__ void pnl_rank8(double* __restrict__ D, const double* 
     }
 }
 
-// Right-looking Cholesky of the 64 x 64 tile T (lower) in 8-column blocks: wave 0 (lane = row) factors the block
-// (pivots broadcast by v_readlane, reciprocal pivots by v_rsq_f64 + Newton), then all four waves apply the
-// rank-8 update to the columns to the right.  All waves take every barrier.
+// The 8 values D[i][8 jb .. 8 jb + 7] of lane i's row with the rank-8 update of block jb - 1 applied, in registers
+// (wave 0's share of the update: exactly the columns it is about to factor / solve).
+__device__ __forceinline__ void pnl_rank8_next(const double* __restrict__ D, const double* __restrict__ Cf, int jb, int i, double (&acc)[8]) {
+    const pan_d2* src = reinterpret_cast<const pan_d2*>(&D[i * PNL_LD + 8 * jb]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
+    if (jb == 0) return;
+    double mine[8];
+    const pan_d2* ms = reinterpret_cast<const pan_d2*>(&D[i * PNL_LD + 8 * (jb - 1)]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const pan_d2 v = ms[q]; mine[2 * q] = v[0]; mine[2 * q + 1] = v[1]; }
+    // four columns at a time: their 16 broadcast reads first, then the FMAs (independent chains) - all eight at once cost
+    // 64 VGPRs and pushed the kernel over the register budget it has to keep (see potrf_panel_kernel)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        pan_d2 c[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const pan_d2* cs = reinterpret_cast<const pan_d2*>(&Cf[(8 * jb + 4 * kh + k) * PNL_LD + 8 * (jb - 1)]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[k][q] = cs[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[4 * kh + k] = fma(-mine[2 * q], c[k][q][0], acc[4 * kh + k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[4 * kh + k] = fma(-mine[2 * q + 1], c[k][q][1], acc[4 * kh + k]);
+        }
+    }
+}
+
+// Right-looking Cholesky of the 64 x 64 tile T (lower) in 8-column blocks, software-pipelined over the waves: in round
+// jb wave 0 (lane = row) applies the rank-8 update of block jb - 1 to the 8 columns of block jb only and factors them
+// (pivots broadcast by v_readlane, reciprocal pivots by v_rsq_f64 + Newton) while waves 1-3 apply the same update to all
+// columns to the right of block jb - one barrier per round, and the serial pivot work no longer waits for the bulk of
+// the update.  All waves take every barrier.
 __device__ __forceinline__ void pnl_diag(double* __restrict__ T, int col0, const PanelArgs& p, int t) {
-    const int i = t;   // lane = row (wave 0 only)
+    const int i = t & 63, w = t >> 6;
     double mydiag = 1.0;
     int bad = 0;
     for (int jb = 0; jb < 8; ++jb) {
-        if (t < 64) {
+        if (w == 0) {
             double acc[8];
-            const pan_d2* src = reinterpret_cast<const pan_d2*>(&T[i * PNL_LD + 8 * jb]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
+            pnl_rank8_next(T, T, jb, i, acc);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int col = 8 * jb + j;
@@ -172,12 +203,10 @@ __device__ __forceinline__ void pnl_diag(double* __restrict__ T, int col0, const
             pan_d2* dst = reinterpret_cast<pan_d2*>(&T[i * PNL_LD + 8 * jb]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
+        } else if (jb > 0) {
+            pnl_rank8(T, T, jb - 1, i, 8 * jb + 8 + (w - 1), 3);
         }
         __syncthreads();
-        if (jb < 7) {
-            pnl_rank8(T, T, jb, t);
-            __syncthreads();
-        }
     }
     if (t < 64) {
         double ld = 2.0 * log(mydiag);
@@ -190,17 +219,15 @@ __device__ __forceinline__ void pnl_diag(double* __restrict__ T, int col0, const
     }
 }
 
-// X L^T = B for the 64 rows in Xs against the lower-triangular tile Cs, right-looking in 8-column blocks: wave 0
-// solves the 8 x 8 diagonal part for every row (lane = row), then all four waves eliminate the solved columns
-// from the remaining ones.  All waves take every barrier.
+// X L^T = B for the 64 rows in Xs against the lower-triangular tile Cs, right-looking in 8-column blocks with the same
+// pipeline: in round jb wave 0 (lane = row) brings the 8 columns of block jb up to date with block jb - 1 and solves
+// their 8 x 8 diagonal part, waves 1-3 eliminate block jb - 1 from the columns to the right.  All waves take every barrier.
 __device__ __forceinline__ void pnl_strip(const double* __restrict__ Cs, double* __restrict__ Xs, const double* __restrict__ rinvs, int t) {
+    const int lane = t & 63, w = t >> 6;
     for (int jb = 0; jb < 8; ++jb) {
-        if (t < 64) {
-            const int lane = t;
+        if (w == 0) {
             double acc[8];
-            const pan_d2* src = reinterpret_cast<const pan_d2*>(&Xs[lane * PNL_LD + 8 * jb]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
+            pnl_rank8_next(Xs, Cs, jb, lane, acc);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const double* crow = &Cs[(8 * jb + j) * PNL_LD + 8 * jb];
@@ -212,12 +239,10 @@ __device__ __forceinline__ void pnl_strip(const double* __restrict__ Cs, double*
             pan_d2* dst = reinterpret_cast<pan_d2*>(&Xs[lane * PNL_LD + 8 * jb]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
+        } else if (jb > 0) {
+            pnl_rank8(Xs, Cs, jb - 1, lane, 8 * jb + 8 + (w - 1), 3);
         }
         __syncthreads();
-        if (jb < 7) {
-            pnl_rank8(Xs, Cs, jb, t);
-            __syncthreads();
-        }
     }
 }
 
@@ -284,7 +309,9 @@ __device__ __forceinline__ void pnl_update(const PanelArgs& p, int r0, int c0, c
     }
 }
 
-__global__ __launch_bounds__(256, 1) void potrf_panel_kernel(PanelArgs p) {
+// launch bounds (256, 2): at most 256 unified registers per wave.  The kernel must fit beside a trailing-update wave (240
+// registers of the 512 per SIMD lane): a build that used 256 + 54 AGPRs was not dispatched until the update had drained.
+__global__ __launch_bounds__(256, 2) void potrf_panel_kernel(PanelArgs p) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
     double* Cs = psm;                    // L_ss (strip coefficients) / diagonal work tile
     double* Xs = psm + PNL_TILE;         // this row block's X
