@@ -531,7 +531,23 @@ static int trsm_rlt_run2(const double* L, int n, int ldl, double* B, int nrows, 
     if (nrows <= 0) return 0;
     const int NB = env_int("GPAR_TRSM_NB", n >= 4096 ? 512 : (n >= 1024 ? 256 : 64));
     const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && NB > 64 && gpar_aligned16(L) && gpar_aligned16(B) && (ldl % 2 == 0) && (ldb % 2 == 0);
+    // As in gpar_potrf, while many columns remain two blocks are solved back to back (the second after a narrow update of
+    // its own columns by the first) and everything to the right then gets ONE rank-2*NB update instead of two rank-NB ones.
+    const int pair_cols = env_int("GPAR_TRSM_PAIR_COLS", 4096);
     for (int c0 = 0, c1 = 0; c0 < n; c0 = c1) {
+        const bool pair = fusable && NB == 512 && c0 + 2 * NB < n && (n - c0) >= pair_cols;
+        if (pair) {
+            const int cm = c0 + NB;
+            c1 = c0 + 2 * NB;
+            const int rows_a = upper_tri ? (nrows < cm ? nrows : cm) : nrows;
+            const int rows = upper_tri ? (nrows < c1 ? nrows : c1) : nrows;   // rows beyond rows_a are still zero in block A
+            int rc = trsm_block_fused(L, n, ldl, B, rows_a, ldb, c0, NB / 64, upper_tri, stream);
+            if (!rc) rc = gemm_launch(0, 1, rows_a, NB, NB, -1.0, B + c0, ldb, L + (size_t)cm * ldl + c0, ldl, 1.0, B + cm, ldb, 0, stream);
+            if (!rc) rc = trsm_block_fused(L, n, ldl, B, rows, ldb, cm, NB / 64, upper_tri, stream);
+            if (!rc) rc = gemm_launch(0, 1, rows, n - c1, 2 * NB, -1.0, B + c0, ldb, L + (size_t)c1 * ldl + c0, ldl, 1.0, B + c1, ldb, 0, stream);
+            if (rc) return rc;
+            continue;
+        }
         c1 = (c0 + NB < n) ? c0 + NB : n;
         // a ragged tail (n not a multiple of 64) becomes its own narrow block so the wide part stays fusable
         if (fusable && (c1 - c0) > 64 && (c1 - c0) % 64 != 0) c1 = c0 + (c1 - c0) / 64 * 64;

@@ -151,6 +151,22 @@ def test_trsm(env, n, rows):
     assert np.allclose(X, scipy.linalg.solve_triangular(L, B.T, lower=True, trans="T").T, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("n,rows", [(5000, 130), (6145, 70)])
+def test_trsm_forward_with_paired_blocks(env, n, rows):
+    """n >= 4096 + 1024: the forward solve pairs 512-column blocks (one rank-1024 update per pair), also with a ragged
+    tail; the triangular-aware inverse built on it is checked against numpy at the same size."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    L = np.linalg.cholesky(_spd(rng, n, cond=50.0))
+    B = rng.standard_normal((rows, n))
+    dL = to_dev(L + np.triu(np.full((n, n), np.nan), 1))
+    X = hip.trsm_rlt_(dL, to_dev(B)).cpu().numpy()
+    assert np.allclose(X, scipy.linalg.solve_triangular(L, B.T, lower=True).T, rtol=1e-9, atol=1e-10)
+    Kinv = np.tril(hip.chol_inverse(dL).cpu().numpy())
+    ref = np.tril(np.linalg.inv(L @ L.T))
+    assert np.allclose(Kinv, ref, rtol=1e-8, atol=1e-9 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("n", [128, 130, 511, 512, 513, 1090, 1700])
 def test_single_row_backward_solve_takes_the_trsv_path(env, n):
     """alpha^T = z^T L^-1 for one row (gpar_trsm_rln with nrows = 1, n >= 128) runs the dedicated TRSV kernels:
