@@ -9,14 +9,14 @@
 // Decomposition: 64-row blocks; workgroup g owns row blocks g, g + G, ... (G = grid size <= resident capacity, so
 // every workgroup is resident and spinning is safe; every spin is bounded and reports through `info`).
 // For step s (column block s):
-//   * the owner of row block s factors the 64 x 64 diagonal block (blocked left-looking Cholesky, one wave) and
-//     publishes it (flag1[s]);
+//   * the owner of row block s factors the 64 x 64 diagonal block (right-looking in 8-column blocks, pivots on wave 0,
+//     rank-8 updates pipelined over the other waves: pnl_diag) and publishes it (flag1[s]);
 //   * every workgroup, for each of its row blocks rb > s: waits for flag1[s], solves its 64 rows against L_ss
-//     (blocked substitution, one wave), writes X = L[rb][s], publishes it if rb < S (flag2[s][rb]: those rows are
+//     (the same 8-column pipeline: pnl_strip), writes X = L[rb][s], publishes it if rb < S (flag2[s][rb]: those rows are
 //     the B operands of everybody's updates), then applies  A[rb][c] -= X L[c][s]^T  for c = s+1 .. min(rb, S-1)
 //     on the matrix cores (v_mfma_f64_16x16x4; X and L[c][s] in LDS, C read-modify-written in global memory).
-// Hand-offs follow the agent-scope release / acquire recipe (cdna_hip_programming.md Guideline 16): plain stores ->
-// every wave drains vmcnt -> barrier -> one lane: release fence + asm vmcnt(0) + relaxed agent-scope flag store;
+// Hand-offs follow the agent-scope recipe (cdna_hip_programming.md Guideline 16 / R1): write-through (sc1) payload
+// stores -> every wave drains vmcnt -> barrier -> one lane: relaxed agent-scope flag store;
 // consumer: one lane polls relaxed, one acquire fence, barrier, plain loads.  The flag words live in the strict
 // upper triangle of the panel's diagonal block (scratch by the ABI's convention) and are zeroed by a memset node
 // on the stream before every launch.

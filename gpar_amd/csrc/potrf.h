@@ -1,8 +1,9 @@
 // Blocked right-looking Cholesky (partial), triangular solves.
 //
-// Two-level blocking: outer panels of NBO columns whose trailing update is one SYRK-shaped MFMA GEMM with
-// K = NBO (arithmetic intensity NBO/8 flop per HBM byte of C traffic: 32 at NBO = 256, above the fp64
-// ridge of ~12.5), inner steps of 64 columns inside a panel:
+// Two-level blocking: outer panels of NBO = 512 columns, each factored by ONE persistent fused kernel (panel.h), whose
+// trailing update is a SYRK-shaped MFMA GEMM with K = NBO (K = 2 NBO while panels are paired: potrf_run); the next
+// panel runs under that update on a side stream (look-ahead).  The leaf kernels below serve ragged tails, unaligned
+// inputs and the GPAR_POTRF_FUSED=0 fallback - inner steps of 64 columns inside a panel:
 //     potrf_diag64   one wave factors the 64 x 64 diagonal block: lane i owns row i in registers, the
 //                    pivot is broadcast with a wave shuffle, the scaled column goes through LDS;
 //     trsm_strip     rows below the block: one row per lane, substitution against L_cc^T held in LDS;
