@@ -55,7 +55,11 @@ typedef double gpar_d4 __attribute__((ext_vector_type(4)));
 //   KC: tile element (r, kk) lives at g[(r0 + r) * ld + k0 + kk]     (r < 128, kk < 16)
 //   MC: tile element (r, kk) lives at g[(k0 + kk) * ld + r0 + r]
 // `lower`: entries with global k > global r are treated as zero (triangular op(A)).
-template <bool KC, bool FAST>
+// FAST: 0 = general, 1 = interior tile, 2 = tile that overhangs the operand's last row, k-contiguous operand: the same
+// 16-byte loads from row indices clamped to the last valid row (the duplicated rows only feed accumulators that the
+// epilogue never stores).  Without it the one-row overhang of the augmented matrix [[K, .], [y^T, c]] sent a whole row of
+// tiles per trailing update down the general path - and those tiles are the last ones dispatched.
+template <bool KC, int FAST>
 __device__ __forceinline__ void gemm_gload(const double* __restrict__ g, int ld, int r0, int rmax, int k0,
                                            int kmax, bool lower, int t, gpar_d2 (&reg)[4]) {
     if (FAST) {
@@ -66,7 +70,8 @@ __device__ __forceinline__ void gemm_gload(const double* __restrict__ g, int ld,
             const int c = t + 256 * q;
             if (KC) {
                 const int r = c >> 3, kk = (c & 7) * 2;
-                reg[q] = *reinterpret_cast<const gpar_d2*>(g + (size_t)(r0 + r) * ld + k0 + kk);
+                const int row = (FAST == 2) ? min(r0 + r, rmax - 1) : r0 + r;
+                reg[q] = *reinterpret_cast<const gpar_d2*>(g + (size_t)row * ld + k0 + kk);
             } else {
                 const int kk = c >> 6, r = (c & 63) * 2;
                 reg[q] = *reinterpret_cast<const gpar_d2*>(g + (size_t)(k0 + kk) * ld + r0 + r);
@@ -107,7 +112,7 @@ __device__ __forceinline__ void gemm_sstore(double* __restrict__ s, int t, const
 
 // K loop of one 128 x 128 tile.  FAST (interior tile, aligned operands, k % 16 == 0) is branch-free so the loads
 // of stage s+1 stay in flight under the MFMAs of stage s; the other instantiation handles every edge case.
-template <bool A_KC, bool B_KC, bool FAST>
+template <bool A_KC, bool B_KC, int FAST>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, gpar_d4 (&acc)[4][4], int m0, int n0,
                                               int kbeg, int kend, int nk, bool a_lower, int t, int lane, int wm, int wn) {
     gpar_d2 ra[4], rb[4];
@@ -227,9 +232,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = gpar_d4{0.0, 0.0, 0.0, 0.0};
 
-    const bool fast = p.fastA && p.fastB && !a_lower && (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n) && ((kend - kbeg) % GEMM_BK == 0);
-    if (fast) gemm_mainloop<A_KC, B_KC, true>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
-    else gemm_mainloop<A_KC, B_KC, false>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
+    const bool fastk = p.fastA && p.fastB && !a_lower && ((kend - kbeg) % GEMM_BK == 0);
+    const bool inner = (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n);
+    if (fastk && inner) gemm_mainloop<A_KC, B_KC, 1>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
+    else if (fastk && A_KC && B_KC) gemm_mainloop<A_KC, B_KC, (A_KC && B_KC) ? 2 : 0>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
+    else gemm_mainloop<A_KC, B_KC, 0>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
     const long long t_main = p.stamps ? (long long)__builtin_readcyclecounter() : 0;
     const int l15 = lane & 15, lk = lane >> 4;
 
@@ -304,7 +311,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         }
     } else {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi) {
+            // wave-uniform: 16-row blocks entirely below the last row (all but one block of the one-row overhang of an
+            // augmented matrix) or entirely above the diagonal have nothing to store
+            const int blk0 = m0 + wm * 64 + 16 * mi;
+            if (blk0 >= p.m || (c_lower && n0 + wn * 64 > blk0 + 15)) continue;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int row = roww + 16 * mi + 4 * v;
@@ -323,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
                     if (ok) p.C[(size_t)row * p.ldc + col] = x;
                 }
             }
+        }
     }
     if (p.stamps && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -403,7 +403,23 @@ static int panel_grid_cap() {
     return cap;
 }
 
-static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream) {
+// The flag words of every 64-aligned diagonal block, zeroed in ONE launch at the start of a factorisation: nothing in
+// gpar_potrf writes the strict upper triangle of a diagonal block before that block's own panel kernel does, and two
+// hipMemsetAsync per panel were ~12 us of idle chip on the serial chain (32 panels at n = 16384).
+constexpr int PNL_FLAG_ROWS = (PNL_MAX_S + PNL_MAX_S * PNL_MAX_S + PNL_FLAG_SLOTS - 1) / PNL_FLAG_SLOTS;
+__global__ __launch_bounds__(256) void potrf_zero_flags_kernel(double* __restrict__ A, int lda) {
+    const int k0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < PNL_FLAG_ROWS * PNL_FLAG_SLOTS; i += blockDim.x)
+        A[(size_t)(k0 + i / PNL_FLAG_SLOTS) * lda + k0 + 8 + i % PNL_FLAG_SLOTS] = 0.0;
+}
+// true if the flags of a panel starting at k0 are covered by potrf_zero_flags(A, N, ...)
+static inline bool potrf_flags_prezeroed(int N, int k0) { return k0 % 64 == 0 && k0 + 64 <= N; }
+static void potrf_zero_flags(double* A, int N, int lda, hipStream_t stream) {
+    if (N >= 64) hipLaunchKernelGGL(potrf_zero_flags_kernel, dim3(N / 64), dim3(256), 0, stream, A, lda);
+}
+
+static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream,
+                             bool prezeroed = false) {
     PanelArgs p{A, N, lda, k0, W / 64, logdet, info, nullptr};
     static bool attr_done = false;
     if (!attr_done) {
@@ -414,8 +430,9 @@ static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* l
     // block: rows 0..7 have columns 8..63 strictly above the diagonal, which bounds S at 16)
     const int nflags = p.S + p.S * p.S;
     if (p.S > PNL_MAX_S) return GPAR_ARG_ERROR(5);
-    for (int r = 0; r * PNL_FLAG_SLOTS < nflags; ++r)
-        hipMemsetAsync(A + (size_t)(k0 + r) * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream);
+    if (!(prezeroed && potrf_flags_prezeroed(N, k0)))
+        for (int r = 0; r * PNL_FLAG_SLOTS < nflags; ++r)
+            hipMemsetAsync(A + (size_t)(k0 + r) * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream);
     const int R = (N - k0 + 63) / 64;
     int G = R < panel_grid_cap() ? R : panel_grid_cap();
     hipLaunchKernelGGL(potrf_panel_kernel, dim3(G), dim3(256), PNL_LDS_BYTES, stream, p);

@@ -355,7 +355,8 @@ static int potrf_panel_split(const PotrfCtx& c, int k0, int kend, int nb, hipStr
 static int trsm_block_fused(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
                             hipStream_t stream);
 // defined in panel.h (one persistent launch per panel)
-static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream);
+static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed);
+static void potrf_zero_flags(double* A, int N, int lda, hipStream_t stream);
 
 struct LookaheadState {
     // one low-priority side stream per caller stream (callers that pipeline independent layers over two or three
@@ -445,6 +446,9 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // than two K = 512 ones.  The price is a longer serial stretch per step (two panels + the narrow update), so the
     // pairing stops once the trailing update is too short to hide it (`pair_rows`).
     const int G = pol.group;
+    // hand-off flags of all panels zeroed once, ahead of the first panel (panel.h)
+    const bool prezero = pol.fused && env_int("GPAR_POTRF_PREZERO", 1) && nf >= 128;
+    if (prezero) potrf_zero_flags(A, N, lda, stream);
     auto groupable = [&](int k) {
         return G > 1 && pol.fused && nbo % 64 == 0 && k + G * nbo <= nf && (N - k) >= pol.pair_rows && (k % 2 == 0) && (lda % 2 == 0) &&
                gpar_aligned16(A);
@@ -464,12 +468,12 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
                     rc = potrf_gemm_update(c, k0, ks, ks + nbo, stream, 1);
                     prof_end(stream, pb, N - ks, nbo, ks - k0);
                 }
-                if (!rc) rc = potrf_panel_fused(A, N, lda, ks, nbo, logdet, info, stream);
+                if (!rc) rc = potrf_panel_fused(A, N, lda, ks, nbo, logdet, info, stream, prezero);
             }
         } else {
             const int w = kend - k0;
             const bool fused_ok = pol.fused && w % 64 == 0 && w <= 1024 && N - k0 >= 64 && (k0 % 2 == 0) && (lda % 2 == 0) && gpar_aligned16(A);
-            rc = fused_ok ? potrf_panel_fused(A, N, lda, k0, w, logdet, info, stream)
+            rc = fused_ok ? potrf_panel_fused(A, N, lda, k0, w, logdet, info, stream, prezero)
                           : (pol.split ? potrf_panel_split(c, k0, kend, nbo, stream) : potrf_panel(c, k0, kend, nbo, stream));
         }
         knext = kend;
