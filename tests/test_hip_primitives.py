@@ -41,7 +41,10 @@ def _spd(rng, n, cond=1e3):
 
 @pytest.mark.parametrize("ta", [False, True])
 @pytest.mark.parametrize("tb", [False, True])
-@pytest.mark.parametrize("mnk", [(1, 1, 1), (5, 7, 3), (128, 128, 16), (130, 257, 33), (300, 64, 200), (64, 515, 129)])
+@pytest.mark.parametrize("mnk", [(1, 1, 1), (5, 7, 3), (128, 128, 16), (130, 257, 33), (300, 64, 200), (64, 515, 129),
+                                 # K a multiple of 16 with tiles overhanging m and n: the clamped-row fast K loop (NT) beside
+                                 # the general one (other transpositions); 129 = one row past a tile, as the augmented matrix
+                                 (129, 129, 64), (333, 257, 32)])
 @pytest.mark.parametrize("pad", [True, False])
 def test_gemm(env, ta, tb, mnk, pad):
     torch, hip, dev, to_dev = env
