@@ -168,6 +168,81 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, g
     }
 }
 
+// One 16-deep stage of the K loop out of LDS images As / Bs; after the first quarter of its MFMAs the global loads of a
+// LATER stage (k offset `knext`) are issued into (ra, rb).
+template <bool A_KC, bool B_KC, int FAST>
+__device__ __forceinline__ void gemm_stage(const GemmArgs& p, const double* __restrict__ As, const double* __restrict__ Bs,
+                                           gpar_d4 (&acc)[4][4], int m0, int n0, int knext, int kend, int t, int l15, int lk,
+                                           int wm, int wn, gpar_d2 (&ra)[4], gpar_d2 (&rb)[4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+        const int kk = k4 * 4 + lk;
+        double af[4], bf[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int r = wm * 64 + 16 * mi + l15;
+            af[mi] = A_KC ? As[r * GEMM_LDKC + kk] : As[kk * GEMM_LDMC + r];
+        }
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const int c = wn * 64 + 16 * nj + l15;
+            bf[nj] = B_KC ? Bs[c * GEMM_LDKC + kk] : Bs[kk * GEMM_LDMC + c];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj)
+                acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+        if (k4 == 0) {
+            gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, knext, kend, false, t, ra);
+            gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, knext, kend, false, t, rb);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// K loop with the global loads issued TWO stages ahead (two register sets, the loop unrolled by two so that both are
+// statically named): one stage of MFMAs (4096 cycles for a wave that has its SIMD to itself) is shorter than a trip to
+// HBM, so with a one-stage distance a workgroup that is alone on its CU - every launch with fewer tiles than CUs: the
+// look-ahead slices and the whole tail of a factorisation - waited for memory in every stage.  Fast modes only (the
+// prefetch index is clamped to the last stage instead of being guarded, which needs branch-free loads).
+template <bool A_KC, bool B_KC, int FAST>
+__device__ __forceinline__ void gemm_mainloop_pf2(const GemmArgs& p, double* smem, gpar_d4 (&acc)[4][4], int m0, int n0,
+                                                  int kbeg, int kend, int nk, int t, int lane, int wm, int wn) {
+    static_assert(FAST != 0, "branch-free loads only");
+    if (nk <= 0) return;
+    gpar_d2 ra0[4], rb0[4], ra1[4], rb1[4];
+    double* buf0 = smem;
+    double* buf1 = smem + 2 * GEMM_TILE;
+    const int klast = kbeg + (nk - 1) * GEMM_BK;
+    gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, kbeg, kend, false, t, ra0);
+    gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, kbeg, kend, false, t, rb0);
+    gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, min(kbeg + GEMM_BK, klast), kend, false, t, ra1);
+    gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, min(kbeg + GEMM_BK, klast), kend, false, t, rb1);
+    gemm_sstore<A_KC>(buf0, t, ra0);
+    gemm_sstore<B_KC>(buf0 + GEMM_TILE, t, rb0);
+    __syncthreads();
+    const int l15 = lane & 15, lk = lane >> 4;
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even stage: compute buf0; (ra1, rb1) carry stage kt + 1; stage kt + 2 is requested into (ra0, rb0)
+        gemm_stage<A_KC, B_KC, FAST>(p, buf0, buf0 + GEMM_TILE, acc, m0, n0, min(kbeg + (kt + 2) * GEMM_BK, klast), kend, t, l15,
+                                     lk, wm, wn, ra0, rb0);
+        if (kt + 1 >= nk) break;
+        gemm_sstore<A_KC>(buf1, t, ra1);
+        gemm_sstore<B_KC>(buf1 + GEMM_TILE, t, rb1);
+        __syncthreads();
+        // odd stage: compute buf1; (ra0, rb0) carry stage kt + 2; stage kt + 3 is requested into (ra1, rb1)
+        gemm_stage<A_KC, B_KC, FAST>(p, buf1, buf1 + GEMM_TILE, acc, m0, n0, min(kbeg + (kt + 3) * GEMM_BK, klast), kend, t, l15,
+                                     lk, wm, wn, ra1, rb1);
+        if (kt + 2 >= nk) break;
+        gemm_sstore<A_KC>(buf0, t, ra0);
+        gemm_sstore<B_KC>(buf0 + GEMM_TILE, t, rb0);
+        __syncthreads();
+    }
+    __syncthreads();   // the epilogue reuses the stage buffers
+}
+
 // TA: A stored k x m (op(A) = A^T);  TB: B stored n x k (op(B) = B^T).
 // ROLE only gives the trailing SYRK of gpar_potrf (ROLE = 1) its own kernel symbol, so that profilers report the
 // dominant kernel separately from the small panel-internal updates that share the code.
@@ -234,8 +309,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
 
     const bool fastk = p.fastA && p.fastB && !a_lower && ((kend - kbeg) % GEMM_BK == 0);
     const bool inner = (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n);
-    if (fastk && inner) gemm_mainloop<A_KC, B_KC, 1>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
-    else if (fastk && A_KC && B_KC) gemm_mainloop<A_KC, B_KC, (A_KC && B_KC) ? 2 : 0>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
+    if (fastk && inner) gemm_mainloop_pf2<A_KC, B_KC, 1>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
+    else if (fastk && A_KC && B_KC) gemm_mainloop_pf2<A_KC, B_KC, 2>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
     else gemm_mainloop<A_KC, B_KC, 0>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
     const long long t_main = p.stamps ? (long long)__builtin_readcyclecounter() : 0;
     const int l15 = lane & 15, lk = lane >> 4;
