@@ -11,6 +11,7 @@
 // Lane maps (probed, profiles/r01_probe_mfma_f64_16x16x4.txt): A-operand lane l = (row l & 15, k = l >> 4);
 // B-operand lane l = (column l & 15, k = l >> 4); register v of D holds row (l >> 4) + 4 v, column l & 15.
 //
+// (A BM = 64 instantiation - half a tile per workgroup - serves launches with fewer tiles than compute units; see the kernel.)
 // Work decomposition: 256 threads = 4 waves (2 x 2), workgroup tile 128 x 128, wave tile 64 x 64 =
 // 4 x 4 accumulators of 16 x 16 = 64 f64 = 128 VGPRs (arch VGPRs: no AGPR traffic); BK = 16 per stage, two LDS
 // stages (73.7 KB) so two workgroups share a CU (2 waves per SIMD) and cover each other's barrier/staging.
@@ -59,32 +60,32 @@ typedef double gpar_d4 __attribute__((ext_vector_type(4)));
 // 16-byte loads from row indices clamped to the last valid row (the duplicated rows only feed accumulators that the
 // epilogue never stores).  Without it the one-row overhang of the augmented matrix [[K, .], [y^T, c]] sent a whole row of
 // tiles per trailing update down the general path - and those tiles are the last ones dispatched.
-template <bool KC, int FAST>
+template <bool KC, int FAST, int ROWS = 128>
 __device__ __forceinline__ void gemm_gload(const double* __restrict__ g, int ld, int r0, int rmax, int k0,
-                                           int kmax, bool lower, int t, gpar_d2 (&reg)[4]) {
+                                           int kmax, bool lower, int t, gpar_d2 (&reg)[ROWS / 32]) {
     if (FAST) {
         // interior tile, aligned operand: branch-free 16-byte loads (any branch around a load makes hipcc fence it
         // with vmcnt(0), serialising the A and B requests and exposing a memory round trip per stage)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < ROWS / 32; ++q) {
             const int c = t + 256 * q;
             if (KC) {
                 const int r = c >> 3, kk = (c & 7) * 2;
                 const int row = (FAST == 2) ? min(r0 + r, rmax - 1) : r0 + r;
                 reg[q] = *reinterpret_cast<const gpar_d2*>(g + (size_t)row * ld + k0 + kk);
             } else {
-                const int kk = c >> 6, r = (c & 63) * 2;
+                const int kk = c / (ROWS / 2), r = (c % (ROWS / 2)) * 2;
                 reg[q] = *reinterpret_cast<const gpar_d2*>(g + (size_t)(k0 + kk) * ld + r0 + r);
             }
         }
     } else {
         // edge tile / unaligned operand / triangular operand: clamped (always valid) scalar loads, masked afterwards
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < ROWS / 32; ++q) {
             const int c = t + 256 * q;
             int r, kk, r1, kk1;
             if (KC) { r = r0 + (c >> 3); kk = k0 + (c & 7) * 2; r1 = r; kk1 = kk + 1; }
-            else { kk = k0 + (c >> 6); r = r0 + (c & 63) * 2; r1 = r + 1; kk1 = kk; }
+            else { kk = k0 + c / (ROWS / 2); r = r0 + (c % (ROWS / 2)) * 2; r1 = r + 1; kk1 = kk; }
             const bool ok0 = r < rmax && kk < kmax && (!lower || kk <= r);
             const bool ok1 = r1 < rmax && kk1 < kmax && (!lower || kk1 <= r1);
             const int rc = min(r, rmax - 1), kc = min(kk, kmax - 1), rc1 = min(r1, rmax - 1), kc1 = min(kk1, kmax - 1);
@@ -95,16 +96,16 @@ __device__ __forceinline__ void gemm_gload(const double* __restrict__ g, int ld,
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void gemm_sstore(double* __restrict__ s, int t, const gpar_d2 (&reg)[4]) {
+template <bool KC, int ROWS = 128>
+__device__ __forceinline__ void gemm_sstore(double* __restrict__ s, int t, const gpar_d2 (&reg)[ROWS / 32]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < ROWS / 32; ++q) {
         const int c = t + 256 * q;
         if (KC) {
             const int r = c >> 3, kk = (c & 7) * 2;
             *reinterpret_cast<gpar_d2*>(s + r * GEMM_LDKC + kk) = reg[q];
         } else {
-            const int kk = c >> 6, r = (c & 63) * 2;
+            const int kk = c / (ROWS / 2), r = (c % (ROWS / 2)) * 2;
             *reinterpret_cast<gpar_d2*>(s + kk * GEMM_LDMC + r) = reg[q];
         }
     }
@@ -112,14 +113,14 @@ __device__ __forceinline__ void gemm_sstore(double* __restrict__ s, int t, const
 
 // K loop of one 128 x 128 tile.  FAST (interior tile, aligned operands, k % 16 == 0) is branch-free so the loads
 // of stage s+1 stay in flight under the MFMAs of stage s; the other instantiation handles every edge case.
-template <bool A_KC, bool B_KC, int FAST>
-__device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, gpar_d4 (&acc)[4][4], int m0, int n0,
+template <bool A_KC, bool B_KC, int FAST, int BM>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, gpar_d4 (&acc)[BM / 32][4], int m0, int n0,
                                               int kbeg, int kend, int nk, bool a_lower, int t, int lane, int wm, int wn) {
-    gpar_d2 ra[4], rb[4];
+    gpar_d2 ra[BM / 32], rb[4];
     if (nk > 0) {
-        gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, kbeg, kend, a_lower, t, ra);
+        gemm_gload<A_KC, FAST, BM>(p.A, p.lda, m0, p.m, kbeg, kend, a_lower, t, ra);
         gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, kbeg, kend, false, t, rb);
-        gemm_sstore<A_KC>(smem, t, ra);
+        gemm_sstore<A_KC, BM>(smem, t, ra);
         gemm_sstore<B_KC>(smem + GEMM_TILE, t, rb);
     }
     __syncthreads();
@@ -135,10 +136,10 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, g
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const int kk = k4 * 4 + lk;
-            double af[4], bf[4];   // lane l: row / column l & 15 of each 16-wide block, k = 4 k4 + (l >> 4)
+            double af[BM / 32], bf[4];   // lane l: row / column l & 15 of each 16-wide block, k = 4 k4 + (l >> 4)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int r = wm * 64 + 16 * mi + l15;
+            for (int mi = 0; mi < BM / 32; ++mi) {
+                const int r = wm * (BM / 2) + 16 * mi + l15;
                 af[mi] = A_KC ? As[r * GEMM_LDKC + kk] : As[kk * GEMM_LDMC + r];
             }
 #pragma unroll
@@ -147,21 +148,21 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, g
                 bf[nj] = B_KC ? Bs[c * GEMM_LDKC + kk] : Bs[kk * GEMM_LDMC + c];
             }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < BM / 32; ++mi)
 #pragma unroll
                 for (int nj = 0; nj < 4; ++nj)
                     acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
             if (k4 == 0 && more) {
                 // the next stage's global loads go out after the first quarter of the MFMAs, not before them: their
                 // address arithmetic no longer delays the start of the MFMA phase (70.3 -> 72.3 TFLOP/s at 8192^3)
-                gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, kbeg + (kt + 1) * GEMM_BK, kend, a_lower, t, ra);
+                gemm_gload<A_KC, FAST, BM>(p.A, p.lda, m0, p.m, kbeg + (kt + 1) * GEMM_BK, kend, a_lower, t, ra);
                 gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, kbeg + (kt + 1) * GEMM_BK, kend, false, t, rb);
             }
         }
         __builtin_amdgcn_s_setprio(0);
         if (more) {
             double* An = smem + ((kt + 1) & 1) * 2 * GEMM_TILE;
-            gemm_sstore<A_KC>(An, t, ra);
+            gemm_sstore<A_KC, BM>(An, t, ra);
             gemm_sstore<B_KC>(An + GEMM_TILE, t, rb);
         }
         __syncthreads();
@@ -170,18 +171,18 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, g
 
 // One 16-deep stage of the K loop out of LDS images As / Bs; after the first quarter of its MFMAs the global loads of a
 // LATER stage (k offset `knext`) are issued into (ra, rb).
-template <bool A_KC, bool B_KC, int FAST>
+template <bool A_KC, bool B_KC, int FAST, int BM>
 __device__ __forceinline__ void gemm_stage(const GemmArgs& p, const double* __restrict__ As, const double* __restrict__ Bs,
-                                           gpar_d4 (&acc)[4][4], int m0, int n0, int knext, int kend, int t, int l15, int lk,
-                                           int wm, int wn, gpar_d2 (&ra)[4], gpar_d2 (&rb)[4]) {
+                                           gpar_d4 (&acc)[BM / 32][4], int m0, int n0, int knext, int kend, int t, int l15, int lk,
+                                           int wm, int wn, gpar_d2 (&ra)[BM / 32], gpar_d2 (&rb)[4]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
         const int kk = k4 * 4 + lk;
-        double af[4], bf[4];
+        double af[BM / 32], bf[4];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int r = wm * 64 + 16 * mi + l15;
+        for (int mi = 0; mi < BM / 32; ++mi) {
+            const int r = wm * (BM / 2) + 16 * mi + l15;
             af[mi] = A_KC ? As[r * GEMM_LDKC + kk] : As[kk * GEMM_LDMC + r];
         }
 #pragma unroll
@@ -190,12 +191,12 @@ __device__ __forceinline__ void gemm_stage(const GemmArgs& p, const double* __re
             bf[nj] = B_KC ? Bs[c * GEMM_LDKC + kk] : Bs[kk * GEMM_LDMC + c];
         }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < BM / 32; ++mi)
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj)
                 acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
         if (k4 == 0) {
-            gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, knext, kend, false, t, ra);
+            gemm_gload<A_KC, FAST, BM>(p.A, p.lda, m0, p.m, knext, kend, false, t, ra);
             gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, knext, kend, false, t, rb);
         }
     }
@@ -207,36 +208,36 @@ __device__ __forceinline__ void gemm_stage(const GemmArgs& p, const double* __re
 // HBM, so with a one-stage distance a workgroup that is alone on its CU - every launch with fewer tiles than CUs: the
 // look-ahead slices and the whole tail of a factorisation - waited for memory in every stage.  Fast modes only (the
 // prefetch index is clamped to the last stage instead of being guarded, which needs branch-free loads).
-template <bool A_KC, bool B_KC, int FAST>
-__device__ __forceinline__ void gemm_mainloop_pf2(const GemmArgs& p, double* smem, gpar_d4 (&acc)[4][4], int m0, int n0,
+template <bool A_KC, bool B_KC, int FAST, int BM>
+__device__ __forceinline__ void gemm_mainloop_pf2(const GemmArgs& p, double* smem, gpar_d4 (&acc)[BM / 32][4], int m0, int n0,
                                                   int kbeg, int kend, int nk, int t, int lane, int wm, int wn) {
     static_assert(FAST != 0, "branch-free loads only");
     if (nk <= 0) return;
-    gpar_d2 ra0[4], rb0[4], ra1[4], rb1[4];
+    gpar_d2 ra0[BM / 32], rb0[4], ra1[BM / 32], rb1[4];
     double* buf0 = smem;
     double* buf1 = smem + 2 * GEMM_TILE;
     const int klast = kbeg + (nk - 1) * GEMM_BK;
-    gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, kbeg, kend, false, t, ra0);
+    gemm_gload<A_KC, FAST, BM>(p.A, p.lda, m0, p.m, kbeg, kend, false, t, ra0);
     gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, kbeg, kend, false, t, rb0);
-    gemm_gload<A_KC, FAST>(p.A, p.lda, m0, p.m, min(kbeg + GEMM_BK, klast), kend, false, t, ra1);
+    gemm_gload<A_KC, FAST, BM>(p.A, p.lda, m0, p.m, min(kbeg + GEMM_BK, klast), kend, false, t, ra1);
     gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, min(kbeg + GEMM_BK, klast), kend, false, t, rb1);
-    gemm_sstore<A_KC>(buf0, t, ra0);
+    gemm_sstore<A_KC, BM>(buf0, t, ra0);
     gemm_sstore<B_KC>(buf0 + GEMM_TILE, t, rb0);
     __syncthreads();
     const int l15 = lane & 15, lk = lane >> 4;
     for (int kt = 0; kt < nk; kt += 2) {
         // even stage: compute buf0; (ra1, rb1) carry stage kt + 1; stage kt + 2 is requested into (ra0, rb0)
-        gemm_stage<A_KC, B_KC, FAST>(p, buf0, buf0 + GEMM_TILE, acc, m0, n0, min(kbeg + (kt + 2) * GEMM_BK, klast), kend, t, l15,
+        gemm_stage<A_KC, B_KC, FAST, BM>(p, buf0, buf0 + GEMM_TILE, acc, m0, n0, min(kbeg + (kt + 2) * GEMM_BK, klast), kend, t, l15,
                                      lk, wm, wn, ra0, rb0);
         if (kt + 1 >= nk) break;
-        gemm_sstore<A_KC>(buf1, t, ra1);
+        gemm_sstore<A_KC, BM>(buf1, t, ra1);
         gemm_sstore<B_KC>(buf1 + GEMM_TILE, t, rb1);
         __syncthreads();
         // odd stage: compute buf1; (ra0, rb0) carry stage kt + 2; stage kt + 3 is requested into (ra1, rb1)
-        gemm_stage<A_KC, B_KC, FAST>(p, buf1, buf1 + GEMM_TILE, acc, m0, n0, min(kbeg + (kt + 3) * GEMM_BK, klast), kend, t, l15,
+        gemm_stage<A_KC, B_KC, FAST, BM>(p, buf1, buf1 + GEMM_TILE, acc, m0, n0, min(kbeg + (kt + 3) * GEMM_BK, klast), kend, t, l15,
                                      lk, wm, wn, ra1, rb1);
         if (kt + 2 >= nk) break;
-        gemm_sstore<A_KC>(buf0, t, ra0);
+        gemm_sstore<A_KC, BM>(buf0, t, ra0);
         gemm_sstore<B_KC>(buf0 + GEMM_TILE, t, rb0);
         __syncthreads();
     }
@@ -246,8 +247,12 @@ __device__ __forceinline__ void gemm_mainloop_pf2(const GemmArgs& p, double* sme
 // TA: A stored k x m (op(A) = A^T);  TB: B stored n x k (op(B) = B^T).
 // ROLE only gives the trailing SYRK of gpar_potrf (ROLE = 1) its own kernel symbol, so that profilers report the
 // dominant kernel separately from the small panel-internal updates that share the code.
-template <bool TA, bool TB, int ROLE>
+// BM = 64: the workgroup computes one 64-row half of a 128 x 128 tile (blockIdx.x = 2 * tile + half; wave tile 32 x 64).
+// For launches with fewer tiles than compute units: a lone workgroup on a CU has one wave per SIMD and nothing to cover
+// its barrier / LDS latencies with (58 % MFMA issue); two half-tile workgroups per CU cover each other's.
+template <bool TA, bool TB, int ROLE, int BM = 128>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
+    constexpr int MI = BM / 32;   // 16-row blocks per wave
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr bool A_KC = !TA;
     constexpr bool B_KC = TB;
@@ -259,9 +264,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     if (p.flags & (GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_A_LOWER)) {
         // tiles differ in K length by up to n / 128 x (long ones first in the enumeration): contiguous runs per XCD would
         // hand one XCD all the long tiles (the triangular-aware inverse ran at 28 TF that way); deal them round-robin
-        idx = blockIdx.x;
+        idx = blockIdx.x / (GEMM_BM / BM);
     } else {
-        const int nb = gridDim.x, b = blockIdx.x;
+        const int nb = gridDim.x / (GEMM_BM / BM), b = blockIdx.x / (GEMM_BM / BM);
         const int xcd = b & 7, q = nb >> 3, r = nb & 7;
         idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
@@ -283,13 +288,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         tm = idx / p.tiles_n;
         tn = idx % p.tiles_n;
     }
-    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    const int m0 = tm * GEMM_BM + (BM == GEMM_BM ? 0 : (int)(blockIdx.x & 1) * BM), n0 = tn * GEMM_BN;
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w >> 1, wn = w & 1;
     const bool a_lower = (p.flags & GPAR_GEMM_A_LOWER) != 0;
     // with a triangular op(A) nothing beyond k = m0 + 127 contributes to this tile
-    int kend = a_lower ? min(p.k, m0 + GEMM_BM) : p.k;
+    int kend = a_lower ? min(p.k, m0 + BM) : p.k;
     // K_FROM_ROW: both operands vanish for k < their row (upper-triangular factors): with col <= row nothing
     // before k = m0 contributes to this tile
     int kbeg = (p.flags & GPAR_GEMM_K_FROM_ROW) ? min(m0, kend) : 0;
@@ -301,29 +306,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     }
     const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
 
-    gpar_d4 acc[4][4];   // acc[mi][nj][v]: row 16 mi + (lane >> 4) + 4 v, column 16 nj + (lane & 15) of the wave tile
+    gpar_d4 acc[MI][4];   // acc[mi][nj][v]: row 16 mi + (lane >> 4) + 4 v, column 16 nj + (lane & 15) of the wave tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = gpar_d4{0.0, 0.0, 0.0, 0.0};
 
     const bool fastk = p.fastA && p.fastB && !a_lower && ((kend - kbeg) % GEMM_BK == 0);
-    const bool inner = (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n);
-    if (fastk && inner) gemm_mainloop_pf2<A_KC, B_KC, 1>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
-    else if (fastk && A_KC && B_KC) gemm_mainloop_pf2<A_KC, B_KC, 2>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
-    else gemm_mainloop<A_KC, B_KC, 0>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
+    const bool inner = (m0 + BM <= p.m) && (n0 + GEMM_BN <= p.n);
+    if (fastk && inner) gemm_mainloop_pf2<A_KC, B_KC, 1, BM>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
+    else if (fastk && A_KC && B_KC) gemm_mainloop_pf2<A_KC, B_KC, 2, BM>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
+    else gemm_mainloop<A_KC, B_KC, 0, BM>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
     const long long t_main = p.stamps ? (long long)__builtin_readcyclecounter() : 0;
     const int l15 = lane & 15, lk = lane >> 4;
 
     // epilogue: register v of acc[mi][nj] holds C[16 mi + (lane >> 4) + 4 v][16 nj + (lane & 15)] of the wave tile
     const bool c_lower = (p.flags & GPAR_GEMM_C_LOWER) != 0;
     const int colw = n0 + wn * 64 + l15;
-    const int roww = m0 + wm * 64 + lk;
+    const int roww = m0 + wm * (BM / 2) + lk;
     const double alpha = p.alpha, beta = p.beta;
     // Loads of C are never placed behind a per-element condition (hipcc would fence each with vmcnt(0): 64 serial
     // memory round trips per tile, measured as a fixed ~20 us per tile): interior tiles use plain loads/stores, edge
     // tiles load from clamped (always valid) addresses and only the stores are predicated.
-    const bool interior = (m0 + GEMM_BM <= p.m) && (n0 + GEMM_BN <= p.n) && (!c_lower || n0 + GEMM_BN - 1 <= m0);
+    const bool interior = (m0 + BM <= p.m) && (n0 + GEMM_BN <= p.n) && (!c_lower || n0 + GEMM_BN - 1 <= m0);
     if (interior && p.fastC) {
         // Interior tile, 16-byte aligned C: transpose the accumulators through LDS (the operand stages are dead
         // after the K loop; every wave owns a private slice, so no workgroup barrier is needed) so that each lane ends
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         // instruction, instead of 8-byte accesses in 128-byte runs straight from the MFMA layout.
         double* S = smem + w * GEMM_TILE;                     // [16][GEMM_LDT] doubles, private to this wave
         const int rrow = lane >> 5, rcol = (lane & 31) * 2;   // read-back: row 2 q + rrow, columns rcol, rcol + 1
-        double* cbase = p.C + (size_t)(m0 + wm * 64 + rrow) * p.ldc + n0 + wn * 64 + rcol;
+        double* cbase = p.C + (size_t)(m0 + wm * (BM / 2) + rrow) * p.ldc + n0 + wn * 64 + rcol;
         // four quarters of 16 rows (one mi each); the C values of quarter h + 1 are requested before quarter h is processed
         gpar_d2 cv[2][8];
         if (beta != 0.0) {
@@ -339,12 +344,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
             for (int q = 0; q < 8; ++q) cv[0][q] = *reinterpret_cast<const gpar_d2*>(cbase + (size_t)(2 * q) * p.ldc);
         }
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
+        for (int h = 0; h < MI; ++h) {
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) S[(lk + 4 * v) * GEMM_LDT + 16 * nj + l15] = acc[h][nj][v];
-            if (h < 3 && beta != 0.0) {
+            if (h < MI - 1 && beta != 0.0) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     cv[(h + 1) & 1][q] = *reinterpret_cast<const gpar_d2*>(cbase + (size_t)(16 * (h + 1) + 2 * q) * p.ldc);
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         }
     } else if (interior) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             double cv[4][4];
             if (beta != 0.0) {
 #pragma unroll
@@ -386,10 +391,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         }
     } else {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             // wave-uniform: 16-row blocks entirely below the last row (all but one block of the one-row overhang of an
             // augmented matrix) or entirely above the diagonal have nothing to store
-            const int blk0 = m0 + wm * 64 + 16 * mi;
+            const int blk0 = m0 + wm * (BM / 2) + 16 * mi;
             if (blk0 >= p.m || (c_lower && n0 + wn * 64 > blk0 + 15)) continue;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -457,13 +462,21 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+    // half tiles (two workgroups per 128 x 128 tile) while a launch has fewer tiles than the chip has compute units
+    static int half_tiles = -1;
+    if (half_tiles < 0) { const char* e = getenv("GPAR_GEMM_HALF_TILES"); half_tiles = e ? atoi(e) : 256; }
+    const bool half = !ta && tb && ntiles <= half_tiles && k >= 64 && !(flags & (GPAR_GEMM_A_LOWER | GPAR_GEMM_K_FROM_ROW));
     static int lds_extra = -1;
     if (lds_extra < 0) { const char* e = getenv("GPAR_GEMM_LDS_EXTRA"); lds_extra = e ? atoi(e) : 0; }
     const int GEMM_LDS_REQ = GEMM_LDS_BYTES + lds_extra;   // experiment knob: > 6.2 KB extra forces one workgroup per CU
-    dim3 grid(ntiles), block(256);
-    if (role == 1 && !ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, GEMM_LDS_REQ, stream, p);
+    dim3 grid(half ? 2 * ntiles : ntiles), block(256);
+    if (half && role == 1) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1, 64>), grid, block, GEMM_LDS_REQ, stream, p);
+    else if (half) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0, 64>), grid, block, GEMM_LDS_REQ, stream, p);
+    else if (role == 1 && !ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, GEMM_LDS_REQ, stream, p);
