@@ -282,9 +282,10 @@ static PotrfPolicy potrf_policy(int N) {
     p.nbm = p.nbo >= 512 ? 128 : 64;
     // Look-ahead: the fused panel kernel of panel k+1 (70.8 KB LDS: fits on a CU beside one SYRK workgroup) runs on
     // the caller's stream under the trailing update of panel k on a low-priority side stream.  Pays once the
-    // trailing updates are long enough to hide it (measured: n = 8192 8.4 -> 7.8 ms, 16384 37.2 -> 33.7 ms; a wash
-    // at 6144, a loss at 4096).  The unfused fallback keeps it off (its small kernels starve behind the SYRK).
-    p.lookahead = (p.fused && N >= 7168) ? 1 : 0;
+    // trailing updates are long enough to hide it (measured with half-tile workgroups for the small launches: n = 5120
+    // 3.12 -> 2.97 ms, 6144 4.06 -> 3.81, 8192 6.75 -> 5.98; a wash at 4096, a loss at 3072).  The unfused fallback keeps
+    // it off (its small kernels starve behind the SYRK).
+    p.lookahead = (p.fused && N >= 4608) ? 1 : 0;
     p.nbo = env_int("GPAR_POTRF_NBO", p.nbo);
     p.nbm = env_int("GPAR_POTRF_NBM", p.nbm);
     p.lookahead = env_int("GPAR_POTRF_LOOKAHEAD", p.lookahead);
@@ -449,8 +450,9 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // hand-off flags of all panels zeroed once, ahead of the first panel (panel.h)
     const bool prezero = pol.fused && env_int("GPAR_POTRF_PREZERO", 1) && nf >= 128;
     if (prezero) potrf_zero_flags(A, N, lda, stream);
+    const int pair_first = env_int("GPAR_POTRF_PAIR_FIRST", 0);
     auto groupable = [&](int k) {
-        return G > 1 && pol.fused && nbo % 64 == 0 && k + G * nbo <= nf && (N - k) >= pol.pair_rows && (k % 2 == 0) && (lda % 2 == 0) &&
+        return G > 1 && (k > 0 || pair_first) && pol.fused && nbo % 64 == 0 && k + G * nbo <= nf && (N - k) >= pol.pair_rows && (k % 2 == 0) && (lda % 2 == 0) &&
                gpar_aligned16(A);
     };
     for (int k0 = 0, knext = 0; k0 < nf; k0 = knext) {
