@@ -161,7 +161,7 @@ def main():
         # UNION of the launch intervals: flops / busy time = per-launch flops / (average launch duration / concurrency).
         achieved = flops.value / (busy.value * 1e-3) * 1e-12
         out["roofline"] = {
-            "kernel": "gpar::gemm_f64_kernel<false, true, 1> (every trailing-update launch of gpar_potrf: rank-512 / rank-1024 SYRK of the rest of the matrix and the narrow look-ahead slices; v_mfma_f64_16x16x4)",
+            "kernel": "gpar::gemm_f64_kernel<false, true, 1, 128> and its half-tile form <false, true, 1, 64> for launches of at most 256 tiles (every trailing-update launch of gpar_potrf: rank-512 / rank-1024 SYRK of the rest of the matrix and the narrow look-ahead slices; v_mfma_f64_16x16x4)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MATRIX_PEAK_TFLOPS,

@@ -1,6 +1,6 @@
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 1 --warmup 0 --no-extras --no-cpu`
 into per-launch HBM traffic of the dominant kernel: the trailing SYRK update of gpar_potrf, which has its own kernel
-symbol (gemm_f64_kernel<false, true, 1>).
+symbols (gemm_f64_kernel<false, true, 1, 128> and, for launches with at most 256 tiles, its half-tile form <false, true, 1, 64>).
 
 Corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: counter values are KiB; on gfx950 FETCH_SIZE reports
 half the bytes of a wide coalesced streaming read, so the read side is doubled (exact for the 16-byte operand
@@ -10,7 +10,7 @@ streams and, since the epilogue transposes through LDS, for the 16-byte read-mod
 """
 import csv, json, sys
 
-KERNEL = "gemm_f64_kernel<false, true, 1>"  # every trailing-update launch of gpar_potrf, look-ahead slices included
+KERNEL = "gemm_f64_kernel<false, true, 1,"  # both tile forms: every trailing-update launch of gpar_potrf, look-ahead slices included
 
 
 def read(dirname, counter):
@@ -26,7 +26,7 @@ def main():
     write_b = 1024.0 * sum(write) / n
     print(json.dumps({
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 0 --no-extras --no-cpu`",
-        "kernel": "gpar::" + KERNEL + " (trailing SYRK launches of gpar_potrf)",
+        "kernel": "gpar::gemm_f64_kernel<false, true, 1, 128> + <false, true, 1, 64> (all trailing-update launches of gpar_potrf)",
         "launches": n,
         "fetch_bytes_per_launch_x2_corrected": fetch_b, "fetch_bytes_per_launch_raw": fetch_b / 2,
         "write_bytes_per_launch": write_b,

@@ -2,7 +2,7 @@
 from different streams overlap, so sum of durations / union = average number in flight)."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-key = sys.argv[2] if len(sys.argv) > 2 else "gemm_f64_kernel<false, true, 1>"
+key = sys.argv[2] if len(sys.argv) > 2 else "gemm_f64_kernel<false, true, 1,"   # both tile forms of the trailing update
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if key in r["Kernel_Name"])
 tot = sum(e - s for s, e in iv)
 busy, cs, ce = 0, iv[0][0], iv[0][1]
