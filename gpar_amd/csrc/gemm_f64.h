@@ -46,7 +46,7 @@ struct GemmArgs {
     int fastA, fastB, fastC;
     int ksplit;          // > 0: blockIdx.y selects the K range [y * ksplit, (y + 1) * ksplit) and the output slab y
     long long part_stride;   // elements between consecutive partial slabs of C (split-K)
-    long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memtime stamps, normally null
+    long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memrealtime stamps + hardware ids, normally null
 };
 
 typedef double gpar_d2 __attribute__((ext_vector_type(2)));
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
 
     // XCD-aware, bijective remap of the block index: the dispatcher places block b on XCD b % 8; give each
     // XCD a contiguous run of tiles so neighbouring tiles (shared operand panels) hit the same L2.
-    const long long t_start = p.stamps ? (long long)__builtin_readcyclecounter() : 0;
+    const long long t_start = p.stamps ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, chip-wide
     int idx;
     if (p.flags & (GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_A_LOWER)) {
         // tiles differ in K length by up to n / 128 x (long ones first in the enumeration): contiguous runs per XCD would
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     if (fastk && inner) gemm_mainloop_pf2<A_KC, B_KC, 1, BM>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
     else if (fastk && A_KC && B_KC) gemm_mainloop_pf2<A_KC, B_KC, 2, BM>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
     else gemm_mainloop<A_KC, B_KC, 0, BM>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
-    const long long t_main = p.stamps ? (long long)__builtin_readcyclecounter() : 0;
+    const long long t_main = p.stamps ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     const int l15 = lane & 15, lk = lane >> 4;
 
     // epilogue: register v of acc[mi][nj] holds C[16 mi + (lane >> 4) + 4 v][16 nj + (lane & 15)] of the wave tile
@@ -420,7 +420,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         p.stamps[blockIdx.x * 4 + 0] = t_start;
         p.stamps[blockIdx.x * 4 + 1] = t_main;
-        p.stamps[blockIdx.x * 4 + 2] = (long long)__builtin_readcyclecounter();
+        p.stamps[blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+        // where it ran: HW_ID (register 4: cu_id bits 11:8, sh_id 12, se_id 15:13) and XCC_ID (register 20, bits 3:0)
+        p.stamps[blockIdx.x * 4 + 3] = (long long)(__builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) | (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) << 16));
     }
 }
 
