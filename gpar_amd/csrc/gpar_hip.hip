@@ -150,7 +150,26 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(const double* __restr
 // attributes).  Entry points only ENQUEUE work, so serialising them costs nothing measurable and makes the library safe
 // to call from several host threads (GPARRegressor.fit trains independent layers from two threads, each on its stream).
 static std::mutex g_api_mutex;
-#define GPAR_API_GUARD std::lock_guard<std::mutex> gpar_api_guard(g_api_mutex)
+// Every entry point also makes the device of the caller's stream current for its duration (and restores the previous one):
+// the auxiliary streams and events the library creates must live on that device, whatever the calling thread's current
+// device happens to be (a fresh host thread starts on device 0).
+struct GparDeviceGuard {
+    int prev = -1, dev = -1;
+    explicit GparDeviceGuard(void* stream) {
+        hipDevice_t d;
+        if (stream && hipGetDevice(&prev) == hipSuccess && hipStreamGetDevice(static_cast<hipStream_t>(stream), &d) == hipSuccess) {
+            dev = (int)d;
+            if (dev != prev) hipSetDevice(dev);
+        }
+    }
+    ~GparDeviceGuard() {
+        if (dev >= 0 && dev != prev) hipSetDevice(prev);
+    }
+};
+#define GPAR_API_GUARD                                         \
+    std::lock_guard<std::mutex> gpar_api_guard(g_api_mutex);   \
+    GparDeviceGuard gpar_device_guard(stream)
+#define GPAR_API_GUARD_NOSTREAM std::lock_guard<std::mutex> gpar_api_guard(g_api_mutex)
 
 extern "C" {
 
@@ -351,13 +370,13 @@ int gpar_sample_stats(const double* samples, int S, long long count, long long s
 }
 
 int gpar_profile_enable(int on) {
-    GPAR_API_GUARD;
+    GPAR_API_GUARD_NOSTREAM;
     g_prof.on = on != 0;
     return 0;
 }
 
 int gpar_profile_read(int* launches, double* ms, double* busy_ms, double* flops, int reset) {
-    GPAR_API_GUARD;
+    GPAR_API_GUARD_NOSTREAM;
     profile_collect();
     if (launches) *launches = g_prof.launches;
     if (ms) *ms = g_prof.ms_done;

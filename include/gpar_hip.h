@@ -28,7 +28,9 @@
  *   - gpar_potrf may use one internal low-priority stream per caller stream (look-ahead) and joins it back before
  *     it returns control of `stream`; callers see one in-order stream.  Process-global state (those streams, an event
  *     ring, the profile hook) sits behind one mutex: entry points only enqueue, so calls from several host threads
- *     (each with its own stream) are safe and simply serialise their enqueueing.
+ *     (each with its own stream) are safe and simply serialise their enqueueing.  For the duration of a call the
+ *     device that owns `stream` is made current (and the caller's current device restored on return), so a thread need
+ *     not have called hipSetDevice; a null `stream` means the current device's default stream.
  *   - Pointers should be 16-byte aligned and leading dimensions even for the vectorised paths; other
  *     values are accepted and take a slower scalar path.
  */
