@@ -291,7 +291,7 @@ static PotrfPolicy potrf_policy(int N) {
     p.lookahead = env_int("GPAR_POTRF_LOOKAHEAD", p.lookahead);
     p.split = env_int("GPAR_POTRF_SPLIT", 0);
     p.pair_rows = env_int("GPAR_POTRF_PAIR_ROWS", 9216);   // n = 8192 measured slightly slower paired (7.19 vs 7.10 ms)
-    p.group = env_int("GPAR_POTRF_GROUP", 2);
+    p.group = env_int("GPAR_POTRF_GROUP", 3);
     if (p.nbo < 64) p.nbo = 64;
     if (p.nbm < 64) p.nbm = 64;
     return p;
