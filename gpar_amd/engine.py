@@ -175,14 +175,15 @@ class HipEngine:
         idle, the front of the next one is throughput-bound - on alternating streams the two overlap.  `rows` (the
         problem size) picks the default depth: three streams pay while a factorisation is mostly latency-bound
         (measured per 8-layer evaluation with 2 / 3 / 4 streams: n = 2048 6.0 / 4.9 / 6.3 ms, n = 4096 12.5 / 10.3 / 12.9,
-        n = 6144 22.6 / 22.2 / 25.8; from n = 8192 on two are best: 16 layers at 8192 77.4 / 81.1 / 86.6 ms, C3 at 16384
+        n = 6144 22.6 / 22.2 / 25.8; at n = 8192 it depends on the kernel - 16 layers of the C3 kernel 77.4 / 81.1 / 86.6 ms,
+        of C5's periodic + RQ kernel, whose Gram build is heavier, 82.1 / 79.5 - and the named config decides; C3 at 16384
         208 / 212).  Returns None
         when disabled (GPAR_LAYER_PIPELINE=0 or 1); any other value of the variable fixes the depth."""
         env = os.environ.get("GPAR_LAYER_PIPELINE")
         if env is not None and int(env) < 2:
             return None
         if depth is None:
-            depth = int(env) if env is not None else (3 if rows is not None and rows < 7168 else 2)
+            depth = int(env) if env is not None else (3 if rows is not None and rows < 9216 else 2)
         if depth < 2:
             return None
         return _LayerPipeline(self, _device_streams(self.device, depth))
