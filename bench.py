@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--p", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="skip the fit + predict leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--extras-timeout", type=float, default=600.0,
+                    help="seconds the fit + predict / CPU-baseline / teardown part may take before every rank exits (rank 0 prints the line first)")
     ap.add_argument("--cpu-n", type=int, default=0, help="rows of the bounded CPU sample (0: all n rows, ~17 s at C3)")
     args = ap.parse_args()
 
@@ -208,6 +210,27 @@ def main():
                                        "`avg_launch_ms` is the plain per-launch average that `rocprofv3 --stats` reports; see `isolated` "
                                        "for the kernel alone")
 
+    # The headline is measured by now.  Everything below (the fit + predict leg with its collectives, the CPU baseline, the
+    # process-group teardown) runs under a watchdog: should a peer die or a collective hang, every rank leaves after
+    # `--extras-timeout` seconds and rank 0 still prints the one JSON line, with the leg marked as timed out.
+    import threading
+
+    printed = []
+
+    def emit():
+        if rank == 0 and not printed:
+            printed.append(True)
+            print(json.dumps(out), flush=True)
+
+    def bail():
+        if not args.no_extras:
+            out.setdefault("fit_predict", {"error": f"timed out after {args.extras_timeout} s", "n_gpus": world})
+        emit()
+        os._exit(0)
+
+    watchdog = threading.Timer(args.extras_timeout, bail)
+    watchdog.daemon = True
+    watchdog.start()
     if not args.no_extras:  # every rank takes part (sharded fit / predict contain collectives)
         try:
             leg = fit_predict_leg(eng, x_np, y_np, n, m, p, world)
@@ -217,11 +240,11 @@ def main():
             out["fit_predict"] = leg
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_leg(x_np, y_np, m, p, args.cpu_n if 0 < args.cpu_n < n else n, n)
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    watchdog.cancel()
 
 
 def pmc_traffic(n, m, p):
