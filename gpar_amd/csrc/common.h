@@ -16,6 +16,16 @@ static inline int gpar_hip_status(hipError_t e) { return e == hipSuccess ? 0 : -
         if (e__ != hipSuccess) return -(int)e__;    \
     } while (0)
 
+// A HIP runtime call inside a function that returns the library's int status: a failure becomes -(hipError_t).
+#define GPAR_HIP_TRY(call)                          \
+    do {                                            \
+        hipError_t e__ = (call);                    \
+        if (e__ != hipSuccess) return -(int)e__;    \
+    } while (0)
+// A HIP runtime call whose failure cannot be reported from where it is made and does not affect results (profiling
+// events, restoring the caller's device): the status is dropped on purpose.
+#define GPAR_HIP_IGNORE(call) ((void)(call))
+
 #define GPAR_ARG_ERROR(code) (-1000 - (code))
 
 static inline int gpar_ceil_div(int a, int b) { return (a + b - 1) / b; }

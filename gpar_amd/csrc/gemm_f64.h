@@ -459,13 +459,13 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     // half tiles (two workgroups per 128 x 128 tile) while a launch has fewer tiles than the chip has compute units
@@ -527,10 +527,10 @@ static int gemm_splitk_launch(int ta, int tb, int m, int n, int k, double alpha,
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     dim3 grid(ntiles, nsl), block(256);

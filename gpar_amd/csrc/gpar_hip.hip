@@ -159,11 +159,11 @@ struct GparDeviceGuard {
         hipDevice_t d;
         if (stream && hipGetDevice(&prev) == hipSuccess && hipStreamGetDevice(static_cast<hipStream_t>(stream), &d) == hipSuccess) {
             dev = (int)d;
-            if (dev != prev) hipSetDevice(dev);
+            if (dev != prev) GPAR_HIP_IGNORE(hipSetDevice(dev));   // a failure shows up in the launch that follows
         }
     }
     ~GparDeviceGuard() {
-        if (dev >= 0 && dev != prev) hipSetDevice(prev);
+        if (dev >= 0 && dev != prev) GPAR_HIP_IGNORE(hipSetDevice(prev));
     }
 };
 #define GPAR_API_GUARD                                         \
@@ -249,7 +249,7 @@ static int gram_grad_launch(const gpar_kspec_t* ks, const double* z1, const doub
     const size_t lds = ((size_t)4 * (dz > 0 ? dz : 1) * GRAM_LD + 4 * GRAD_NACC) * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     if (lds > 160 * 1024) return GPAR_ARG_ERROR(7);

@@ -393,9 +393,8 @@ static int panel_grid_cap() {
     static int cap = -1;
     if (cap < 0) {
         int dev = 0;
-        hipGetDevice(&dev);
         hipDeviceProp_t prop;
-        cap = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 64;
+        cap = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 64;
         if (cap < 1) cap = 1;
         const char* e = getenv("GPAR_PANEL_GRID");   // experiment knob: fewer, busier panel workgroups
         if (e && atoi(e) > 0 && atoi(e) < cap) cap = atoi(e);
@@ -423,7 +422,7 @@ static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* l
     PanelArgs p{A, N, lda, k0, W / 64, logdet, info, nullptr};
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS_BYTES);
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS_BYTES));
         attr_done = true;
     }
     // zero the flag words (S + S^2 of them, 56 per scratch row in the strict upper triangle of the first diagonal
@@ -432,7 +431,7 @@ static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* l
     if (p.S > PNL_MAX_S) return GPAR_ARG_ERROR(5);
     if (!(prezeroed && potrf_flags_prezeroed(N, k0)))
         for (int r = 0; r * PNL_FLAG_SLOTS < nflags; ++r)
-            hipMemsetAsync(A + (size_t)(k0 + r) * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream);
+            GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)(k0 + r) * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream));
     const int R = (N - k0 + 63) / 64;
     int G = R < panel_grid_cap() ? R : panel_grid_cap();
     hipLaunchKernelGGL(potrf_panel_kernel, dim3(G), dim3(256), PNL_LDS_BYTES, stream, p);
@@ -491,7 +490,7 @@ static int trsm_block_fused(const double* L, int n, int ldl, double* B, int nrow
                             hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS_BYTES);
+        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS_BYTES));
         attr_done = true;
     }
     TrsmBlockArgs a{L, n, ldl, B, nrows, ldb, c0, S, upper_tri};

@@ -232,12 +232,12 @@ static ProfileState g_prof;
 static void profile_collect() {
     if (g_prof.nev == 0) return;
     std::vector<std::pair<float, float>> iv(g_prof.nev);
-    hipEventSynchronize(g_prof.ev[0][0]);
+    GPAR_HIP_IGNORE(hipEventSynchronize(g_prof.ev[0][0]));
     for (int i = 0; i < g_prof.nev; ++i) {
-        float t0 = 0.f, t1 = 0.f;
-        hipEventSynchronize(g_prof.ev[i][1]);
-        hipEventElapsedTime(&t0, g_prof.ev[0][0], g_prof.ev[i][0]);
-        hipEventElapsedTime(&t1, g_prof.ev[0][0], g_prof.ev[i][1]);
+        float t0 = 0.f, t1 = 0.f;   // a failed query leaves zeros: a measurement aid, never a result
+        GPAR_HIP_IGNORE(hipEventSynchronize(g_prof.ev[i][1]));
+        GPAR_HIP_IGNORE(hipEventElapsedTime(&t0, g_prof.ev[0][0], g_prof.ev[i][0]));
+        GPAR_HIP_IGNORE(hipEventElapsedTime(&t1, g_prof.ev[0][0], g_prof.ev[i][1]));
         g_prof.ms_done += t1 - t0;
         iv[i] = {t0, t1};
     }
@@ -393,7 +393,7 @@ static hipStream_t la_side(hipStream_t caller) {
     for (int i = 0; i < g_la.nside; ++i)
         if (g_la.caller[i] == caller) return g_la.side[i];
     int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least urgent
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;   // lo = least urgent
     hipStream_t s = nullptr;
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
     int slot = g_la.nside;
@@ -402,7 +402,7 @@ static hipStream_t la_side(hipStream_t caller) {
         // pending work finish first, and every gpar_potrf joins its side stream before it returns anyway
         slot = g_la.next_victim;
         g_la.next_victim = (g_la.next_victim + 1) % LookaheadState::MAXS;
-        hipStreamDestroy(g_la.side[slot]);
+        GPAR_HIP_IGNORE(hipStreamDestroy(g_la.side[slot]));
     } else {
         ++g_la.nside;
     }
@@ -415,15 +415,16 @@ static void prof_begin(hipStream_t s, bool& active) {
     active = g_prof.on && g_prof.nev < ProfileState::MAXEV;
     if (!active) return;
     if (!g_prof.created) {
-        for (int i = 0; i < ProfileState::MAXEV; ++i) { hipEventCreate(&g_prof.ev[i][0]); hipEventCreate(&g_prof.ev[i][1]); }
+        for (int i = 0; i < ProfileState::MAXEV; ++i)
+            if (hipEventCreate(&g_prof.ev[i][0]) != hipSuccess || hipEventCreate(&g_prof.ev[i][1]) != hipSuccess) { active = false; return; }
         g_prof.created = true;
     }
-    hipEventRecord(g_prof.ev[g_prof.nev][0], s);
+    GPAR_HIP_IGNORE(hipEventRecord(g_prof.ev[g_prof.nev][0], s));
 }
 
 static void prof_end(hipStream_t s, bool active, int rows, int cols, int kb) {
     if (!active) return;
-    hipEventRecord(g_prof.ev[g_prof.nev][1], s);
+    GPAR_HIP_IGNORE(hipEventRecord(g_prof.ev[g_prof.nev][1], s));
     g_prof.nev++;
     g_prof.launches++;
     // algorithmic flops of the lower-trapezoid rank-kb update: 2 * kb per stored element
@@ -487,7 +488,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         bool pa;
         if (!la || kend >= nf) {
             // no further panel to overlap with (or look-ahead off): one update of everything that is left
-            if (la && trail_done) { hipStreamWaitEvent(stream, trail_done, 0); trail_done = nullptr; }
+            if (la && trail_done) { GPAR_HIP_TRY(hipStreamWaitEvent(stream, trail_done, 0)); trail_done = nullptr; }
             prof_begin(stream, pa);
             rc = potrf_gemm_update(c, k0, kend, N, stream, 1);
             prof_end(stream, pa, N - kend, N - kend, kend - k0);
@@ -495,15 +496,15 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             continue;
         }
         // (1) next panel's columns, on the caller's stream; they were last written by the previous side update
-        if (trail_done) hipStreamWaitEvent(stream, trail_done, 0);
+        if (trail_done) GPAR_HIP_TRY(hipStreamWaitEvent(stream, trail_done, 0));
         hipEvent_t panel_done = la_event();
-        hipEventRecord(panel_done, stream);
+        GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
         prof_begin(stream, pa);
         rc = potrf_gemm_update(c, k0, kend, next_end, stream, 1);   // same kernel symbol: it is part of the trailing update
         prof_end(stream, pa, N - kend, next_end - kend, kend - k0);
         if (rc) return rc;
         // (2) everything to the right of the next panel, on the side stream
-        hipStreamWaitEvent(side, panel_done, 0);
+        GPAR_HIP_TRY(hipStreamWaitEvent(side, panel_done, 0));
         {
             const int rows = N - next_end, cols = N - next_end;
             if (rows > 0) {
@@ -516,9 +517,9 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             }
         }
         trail_done = la_event();
-        hipEventRecord(trail_done, side);
+        GPAR_HIP_TRY(hipEventRecord(trail_done, side));
     }
-    if (trail_done) hipStreamWaitEvent(stream, trail_done, 0);   // join
+    if (trail_done) GPAR_HIP_TRY(hipStreamWaitEvent(stream, trail_done, 0));   // join
     GPAR_LAUNCH_CHECK();
     return 0;
 }
