@@ -10,9 +10,9 @@ already resident in HBM (Gram build -> augmented Cholesky -> quadratic form, for
 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the trailing-update SYRK of the blocked Cholesky (the dominant kernel): algorithmic flops
                 (rem * (rem + 1) * kb per launch) / hipEvent-measured time, against the fp64 matrix peak;
-  cpu_baseline  the CPU oracle ("port" of the reference's torch-CPU/LAPACK path: numpy Gram + LAPACK potrf) timed
+  cpu_baseline  the reference's CPU path restated on torch-CPU fp64 operators (oracle/torch_cpu.py, kind "port"), timed
                 on this box's host cores on a bounded sample of the same workload;
-  fit_predict   wall-clock of a short `fit` + `predict` at the same size (the other half of BASELINE's metric).
+  fit_predict   wall-clock of `fit(iters=20)` + `predict(num_samples=100)` at the same size (the other half of BASELINE's metric).
 """
 import argparse
 import json
@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--extras-timeout", type=float, default=600.0,
                     help="seconds the fit + predict / CPU-baseline / teardown part may take before every rank exits (rank 0 prints the line first)")
-    ap.add_argument("--cpu-n", type=int, default=0, help="rows of the bounded CPU sample (0: all n rows, ~17 s at C3)")
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work the bounded torch-CPU baseline may spend on full-size layers")
     args = ap.parse_args()
 
     import torch
@@ -239,7 +239,7 @@ def main():
         if rank == 0:
             out["fit_predict"] = leg
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline_leg(x_np, y_np, m, p, args.cpu_n if 0 < args.cpu_n < n else n, n)
+        out["cpu_baseline"] = cpu_baseline_leg(x_np, y_np, m, p, budget_s=args.cpu_budget)
     emit()
     if world > 1:
         dist.barrier()
@@ -257,13 +257,15 @@ def pmc_traffic(n, m, p):
         return json.load(f).get("traffic_bytes_per_launch")
 
 
-def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=2, num_samples=8, n_star=1024):
-    """Short fit (fixed L-BFGS-B iteration count) + predict on the same data - the other half of BASELINE.json's
-    metric.  One rank: GPARRegressor.fit / predict.  Several ranks: layer pi is trained on rank pi mod N
-    (parallel.sharded_fit, hyper-parameters broadcast afterwards) and the posterior samples are split over the ranks
-    (parallel.sharded_sample; every rank conditions all layers, so the conditioning part does not scale)."""
+def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=20, num_samples=100, n_star=2048):
+    """`fit` with the fixed L-BFGS-B iteration count SURVEY.md 8(d) prescribes (iters=20) + `predict` (the reference's
+    default of 100 joint posterior samples, at n* = 2048 held-out inputs) on the same data - the other half of
+    BASELINE.json's metric, at the stated size.  One rank: GPARRegressor.fit / predict.  Several ranks: layer pi is trained
+    on rank pi mod N (parallel.sharded_fit, hyper-parameters broadcast afterwards), the conditioning is layer-parallel and
+    the posterior samples are split over the ranks (parallel.sharded_sample)."""
     import torch
 
+    from gpar_amd import optimise
     from gpar_amd.parallel import sharded_fit, sharded_sample
 
     def sync():
@@ -276,6 +278,7 @@ def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=2, num_samples=8,
 
     reg = c3_regressor()
     xs = np.random.default_rng(5).uniform(0, 1, (n_star, m))
+    evals_before = optimise.evaluation_count()
     sync()
     t0 = time.perf_counter()
     if world == 1:
@@ -290,50 +293,126 @@ def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=2, num_samples=8,
         mean = np.mean(sharded_sample(reg, xs, num_samples=num_samples, latent=True), axis=0)
     sync()
     t2 = time.perf_counter()
-    return {"fit_ms": 1e3 * (t1 - t0), "fit_iters": fit_iters, "predict_ms": 1e3 * (t2 - t1), "num_samples": num_samples,
-            "n_star": n_star, "predict_mean_abs": float(np.mean(np.abs(mean))), "n_gpus": world,
-            "timing": "barrier-bracketed wall-clock on rank 0"}
+    leg = {"fit_ms": 1e3 * (t1 - t0), "fit_iters": fit_iters, "fit_evaluations": optimise.evaluation_count() - evals_before,
+           "predict_ms": 1e3 * (t2 - t1), "num_samples": num_samples, "n_star": n_star,
+           "fit_predict_ms": 1e3 * (t2 - t0), "predict_mean_abs": float(np.mean(np.abs(mean))), "n_gpus": world,
+           "timing": "barrier-bracketed wall-clock on rank 0; predict = joint ancestral sampling exactly as the reference's "
+                     "predict (conditioning + num_samples posterior draws + Monte-Carlo reduction)"}
+    if world == 1 and hasattr(reg, "predict") and "marginal" in reg.predict.__code__.co_varnames:
+        sync()
+        t3 = time.perf_counter()
+        reg.predict(xs, num_samples=num_samples, latent=True, marginal=True)
+        sync()
+        leg["predict_marginal_ms"] = 1e3 * (time.perf_counter() - t3)
+    return leg
 
 
-def cpu_baseline_leg(x_np, y_np, m, p, n_sub, n_full):
-    """The CPU oracle (numpy Gram + LAPACK Cholesky; a port of the reference's torch-CPU path) on ONE layer of the
-    workload (the last, widest design matrix) - at full size by default, ~17 s on the GPU box's host - times p."""
+def _leaf_spec(spec):
+    """(leaves, rebuild): the kernel dict's coefficients and length scales as torch leaves for the autograd baseline."""
+    import torch
+
+    leaves = []
+    for term in spec["terms"]:
+        leaves.append(torch.tensor(float(term["coef"]), dtype=torch.float64))
+        for factor in term["factors"]:
+            leaves.append(torch.tensor(list(factor["scales"]), dtype=torch.float64))
+
+    def rebuild(params):
+        it = iter(params)
+        out = {"terms": []}
+        for term in spec["terms"]:
+            coef = next(it)
+            factors = [dict(factor, scales=next(it)) for factor in term["factors"]]
+            out["terms"].append({"coef": coef, "factors": factors})
+        return out
+
+    return leaves, rebuild
+
+
+def cpu_baseline_leg(x_np, y_np, m, p, n_star=2048, num_samples=100, budget_s=25.0):
+    """The reference's CPU path on this box's host cores, restated on the torch-CPU fp64 operators `lab.torch` dispatches
+    to (oracle/torch_cpu.py: unfused Gram terms with expanded squared distances, torch.linalg.cholesky,
+    solve_triangular; all host threads).  Layers of the SAME full-size workload are evaluated from the last (widest) one
+    downwards until ~budget_s seconds of CPU work are spent; the per-layer mean is multiplied by p.  One posterior draw of
+    one layer and one autograd objective + gradient evaluation are timed as well (the per-unit costs of `predict` / `fit`)."""
+    import torch
+
     from gpar_amd.engine import set_engine
     from gpar_amd.regression import _construct_gpar
+    from oracle import kernels as ok
+    from oracle import torch_cpu as tc
     from oracle.engine import OracleEngine
 
-    try:
-        from threadpoolctl import threadpool_info
-
-        threads = max([int(i.get("num_threads", 1)) for i in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    previous = set_engine(OracleEngine())
+    threads = tc.set_threads()
+    previous = set_engine(OracleEngine())  # only to read the kernel specification off the host-side model objects
     try:
         reg = c3_regressor()
         gpar = _construct_gpar(reg, reg.vs, m, p)
-        xs, ys = x_np[:n_sub], y_np[:n_sub]
-        design = np.concatenate([xs, ys[:, : p - 1]], axis=1)
-        f, noise = gpar.layers[p - 1]()
-        t0 = time.perf_counter()
-        val = float(f(design, float(noise)).logpdf(ys[:, p - 1]))
-        dt = time.perf_counter() - t0
+        layers = []
+        for pi in range(p):
+            f, noise = gpar.layers[pi]()
+            layers.append((ok.spec_to_dict(f.kernel.resolve(m + pi)), float(noise)))
     finally:
         set_engine(previous)
-    per_layer_full = dt * (n_full / n_sub) ** 3
-    how = ("no extrapolation in n" if n_sub == n_full else
-           f"extrapolated to n={n_full} with the n^3 law (pessimistic for the CPU: the Gram build is n^2)")
-    return {
-        "value": 1.0 / (per_layer_full * p),
+    n = x_np.shape[0]
+    x_all = torch.as_tensor(np.concatenate([x_np, y_np], axis=1))
+    measured, spent = [], 0.0
+    last = None
+    for pi in reversed(range(p)):
+        spec, noise = layers[pi]
+        design = x_all[:, : m + pi]
+        value, stages, L = tc.layer_logpdf(spec, design, y_np[:, pi], np.full(n, noise))
+        measured.append(dict(stages, layer=pi, logpdf=value))
+        spent += sum(stages.values())
+        if last is None:
+            last = (spec, noise, design, L)
+        if spent >= budget_s:
+            break
+    per_layer = spent / len(measured)
+    out = {
+        "value": 1.0 / (per_layer * p),
         "unit": "logpdf/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"one of the p={p} layers (the last, widest) of the same model on {n_sub} of {n_full} rows: {dt:.2f} s measured "
-                  f"(numpy fused-by-term Gram + LAPACK dpotrf via numpy/scipy, {threads} BLAS threads, host has "
-                  f"{os.cpu_count()} logical CPUs); {how}; multiplied by p={p} near-equal layers",
-        "measured_s": dt,
-        "sample_logpdf": val,
+        "backend": "torch-CPU fp64 (torch.linalg.cholesky / solve_triangular / exp / matmul: the operators the reference's "
+                   "lab.torch backend dispatches to), torch.set_num_threads(all host cores)",
+        "sample": f"{len(measured)} of the p={p} layers of the same full-size workload (n={n}; from the last, widest layer "
+                  f"downwards, {spent:.1f} s of CPU work), mean per layer x p; host has {os.cpu_count()} logical CPUs, "
+                  f"{threads} torch threads",
+        "per_layer_s": per_layer,
+        "gram_s": float(np.mean([s["gram_s"] for s in measured])),
+        "potrf_s": float(np.mean([s["potrf_s"] for s in measured])),
+        "solve_s": float(np.mean([s["solve_s"] for s in measured])),
+        "potrf_gflops": (n**3 / 3.0) / float(np.mean([s["potrf_s"] for s in measured])) * 1e-9,
+        "layers": measured,
     }
+    try:
+        cpu = open("/proc/cpuinfo").read()
+        out["cpu_model"] = next(line.split(":", 1)[1].strip() for line in cpu.splitlines() if line.startswith("model name"))
+    except Exception:
+        pass
+    # per-unit costs of predict (one posterior draw of one layer) and fit (one objective + autograd gradient of one layer)
+    spec, noise, design, L = last
+    z = torch.linalg.solve_triangular(L, torch.as_tensor(y_np[:, p - 1]).reshape(-1, 1), upper=False)
+    xs = torch.as_tensor(np.random.default_rng(5).uniform(0, 1, (n_star, design.shape[1])))
+    _, stages = tc.layer_posterior_sample(spec, design, L, z, xs, np.full(n_star, noise))
+    draw_s = sum(stages.values())
+    out["predict"] = {
+        "per_layer_per_sample_s": draw_s, "stages": stages, "n_star": n_star,
+        "estimated_predict_s": p * per_layer + p * num_samples * draw_s,
+        "note": f"reference predict = p conditionings (one factorisation each, as logpdf) + num_samples x p posterior draws "
+                f"(cross-Gram, triangular solve against the n x n factor, n* x n* Cholesky): one draw of the last layer measured, "
+                f"scaled to p={p} layers x {num_samples} samples",
+    }
+    if per_layer < 8.0:
+        leaves, rebuild = _leaf_spec(spec)
+        leaves.append(torch.tensor(noise, dtype=torch.float64))
+        del L, z
+        _, _, stages = tc.layer_objective_and_gradient(lambda ps: rebuild(ps[:-1]), leaves, design, y_np[:, p - 1], noise_index=-1)
+        out["fit"] = {"objective_and_gradient_s": stages["forward_s"] + stages["backward_s"], "stages": stages,
+                      "note": "one evaluation of one layer's training objective with torch autograd through Gram, Cholesky and "
+                              "solve (what varz.minimise_l_bfgs_b calls once per L-BFGS-B function evaluation)"}
+    return out
 
 
 if __name__ == "__main__":

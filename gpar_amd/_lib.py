@@ -17,9 +17,10 @@ K_EQ, K_RQ, K_LINEAR = 0, 1, 2
 GRAM_LOWER = 1
 GEMM_C_LOWER = 1
 GEMM_A_LOWER = 2
+WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE = 1, 2, 3, 4
 GRAD_NACC = GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 LIB_NAME = "libgpar_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -68,7 +69,7 @@ SIGNATURES = {
     "gpar_featurize": (_c_int, [ctypes.POINTER(FSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "gpar_gram": (
         _c_int,
-        [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr, _c_dbl, _ptr],
+        [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr, _c_dbl, _ptr, _ptr],
     ),
     "gpar_gram_diag": (_c_int, [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "gpar_featurize_dfreq": (_c_int, [ctypes.POINTER(FSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
@@ -94,10 +95,10 @@ SIGNATURES = {
         _c_int,
         [_c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _ptr, _c_int, _ptr, _c_int, _c_dbl, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr],
     ),
-    "gpar_logpdf_finalize": (_c_int, [_ptr, _ptr, _c_dbl, _c_int, _ptr, _ptr]),
-    "gpar_copy_strided": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _ptr]),
-    "gpar_fill": (_c_int, [_ptr, _c_int, _c_int, _c_int, _c_dbl, _ptr]),
     "gpar_dot": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
+    "gpar_gemv_t": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr]),
+    "gpar_rownorm2": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "gpar_workspace_doubles": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
     "gpar_randn": (_c_int, [_u64, _u64, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "gpar_trmv_lower": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr]),
     "gpar_sample_stats": (

@@ -30,7 +30,7 @@ static inline int gpar_hip_status(hipError_t e) { return e == hipSuccess ? 0 : -
 
 static inline int gpar_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-static inline bool gpar_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+__host__ __device__ static inline bool gpar_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // Broadcast lane `src` (compile-time constant after unrolling) of a double to the whole wave through SGPRs
 // (v_readlane_b32 x2) instead of the LDS crossbar (ds_bpermute) that __shfl lowers to.

@@ -6,43 +6,9 @@
 #include "potrf.h"
 #include "panel.h"
 #include "gram.h"
+#include "blas1.h"
 
 namespace gpar {
-
-__global__ void logpdf_finalize_kernel(const double* __restrict__ logdet, const double* __restrict__ quad,
-                                       double quad_sign, int n, double* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const double log2pi = 1.8378770664093454835606594728112;
-        out[0] = -0.5 * (logdet[0] + (double)n * log2pi + quad_sign * quad[0]);
-    }
-}
-
-__global__ __launch_bounds__(256) void copy_strided_kernel(const double* __restrict__ src, long lds, double* __restrict__ dst,
-                                                           long ldd, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[(size_t)i * ldd] = src[(size_t)i * lds];
-}
-
-__global__ __launch_bounds__(256) void fill_kernel(double* __restrict__ dst, int rows, int cols, int ldd, double value) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (r < rows && c < cols) dst[(size_t)r * ldd + c] = value;
-}
-
-// single-workgroup, fixed-order reduction: deterministic
-__global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x, long incx, const double* __restrict__ y,
-                                                   long incy, int n, double* __restrict__ out, int accumulate) {
-    __shared__ double part[1024];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) s = fma(x[(size_t)i * incx], y[(size_t)i * incy], s);
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + part[0];
-}
 
 // Philox-4x32-10 (Salmon et al. 2011).  counter = (pair index lo, hi, offset lo, hi), key = seed.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -125,9 +91,21 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(const double* __restr
     if (e >= count) return;
     const double* col = x + e;
     double sum = 0.0;
-    for (int s = 0; s < S; ++s) sum += col[(long long)s * stride];
+    bool has_nan = false;
+    for (int s = 0; s < S; ++s) {
+        const double v = col[(long long)s * stride];
+        has_nan |= (v != v);
+        sum += v;
+    }
     mean[e] = sum / (double)S;
     if (!lo && !hi) return;
+    if (has_nan) {
+        // np.percentile of a column that holds a NaN is NaN (NaN sorts last and poisons the interpolation); rank counting
+        // with < and == would silently mis-rank instead
+        if (lo) lo[e] = __builtin_nan("");
+        if (hi) hi[e] = __builtin_nan("");
+        return;
+    }
     const int k_lo1 = min(k_lo + 1, S - 1), k_hi1 = min(k_hi + 1, S - 1);
     double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
     for (int s = 0; s < S; ++s) {
@@ -189,7 +167,7 @@ int gpar_featurize(const gpar_fspec_t* fs, const double* x, int n, int ldx, doub
 }
 
 int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz,
-              double* K, int ldk, int flags, const double* diag_add, double diag_const, void* stream) {
+              double* K, int ldk, int flags, const double* diag_add, double diag_const, const double* row_scale, void* stream) {
     GPAR_API_GUARD;
     if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS)
         return GPAR_ARG_ERROR(3);
@@ -202,7 +180,7 @@ int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const 
     dim3 grid(nt2, nt1);
     if (flags & GPAR_GRAM_LOWER) grid = dim3((unsigned)((long long)nt1 * (nt1 + 1) / 2), 1);
     hipLaunchKernelGGL(gram_kernel, grid, dim3(256), lds, (hipStream_t)stream, *ks, z1, n1, ldz1, z2, n2, ldz2, dz, K, ldk,
-                       flags, diag_add, diag_const, sym);
+                       flags, diag_add, diag_const, row_scale, sym);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
@@ -307,36 +285,36 @@ int gpar_gemm_splitk(int ta, int tb, int m, int n, int k, double alpha, const do
     return gemm_splitk_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, splits, workspace, (hipStream_t)stream);
 }
 
-int gpar_logpdf_finalize(const double* logdet, const double* quad, double quad_sign, int n, double* out, void* stream) {
-    GPAR_API_GUARD;
-    hipLaunchKernelGGL(logpdf_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logdet, quad, quad_sign, n, out);
-    GPAR_LAUNCH_CHECK();
-    return 0;
-}
-
-int gpar_copy_strided(const double* src, int lds, double* dst, int ldd, int n, void* stream) {
-    GPAR_API_GUARD;
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(copy_strided_kernel, dim3(gpar_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, (long)lds, dst,
-                       (long)ldd, n);
-    GPAR_LAUNCH_CHECK();
-    return 0;
-}
-
-int gpar_fill(double* dst, int rows, int cols, int ldd, double value, void* stream) {
-    GPAR_API_GUARD;
-    if (rows <= 0 || cols <= 0) return 0;
-    hipLaunchKernelGGL(fill_kernel, dim3(gpar_ceil_div(cols, 256), rows), dim3(256), 0, (hipStream_t)stream, dst, rows, cols, ldd,
-                       value);
-    GPAR_LAUNCH_CHECK();
-    return 0;
-}
-
 int gpar_dot(const double* x, int incx, const double* y, int incy, int n, double* out, int accumulate, void* stream) {
     GPAR_API_GUARD;
     hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)incx, y, (long)incy, n, out, accumulate);
     GPAR_LAUNCH_CHECK();
     return 0;
+}
+
+int gpar_gemv_t(const double* A, int rows, int cols, int lda, const double* v, double* out, double* workspace, void* stream) {
+    GPAR_API_GUARD;
+    if (!out || (rows > 0 && cols > 0 && (!A || !v || !workspace))) return GPAR_ARG_ERROR(2);
+    return gemv_t_run(A, rows, cols, lda, v, out, workspace, (hipStream_t)stream);
+}
+
+int gpar_rownorm2(const double* A, int rows, int cols, int lda, double* out, void* stream) {
+    GPAR_API_GUARD;
+    if (rows <= 0) return 0;
+    if (!A || !out) return GPAR_ARG_ERROR(2);
+    hipLaunchKernelGGL(rownorm2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, rows, cols, lda, out);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+long long gpar_workspace_doubles(int op, int a, int b, int c) {
+    switch (op) {
+        case GPAR_WS_GEMM_SPLITK: return (long long)a * b * (c > 1 ? c : 1);           /* m, n, splits */
+        case GPAR_WS_GEMV_T: return (long long)gemv_t_chunks(a) * (b > 0 ? b : 0);      /* rows, cols */
+        case GPAR_WS_GRAM_GRAD: return (long long)(a > 0 ? a : 0) * GRAD_NACC;          /* nblocks */
+        case GPAR_WS_CHOL_INVERSE: return (long long)a * b;                             /* n, ldx: the X matrix */
+        default: return -1;
+    }
 }
 
 int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, int ldo, void* stream) {

@@ -39,7 +39,8 @@ __device__ __forceinline__ double gram_nonlin(int type, double s, double alpha) 
 __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double* __restrict__ z1, int n1, int ldz1,
                                                    const double* __restrict__ z2, int n2, int ldz2, int dz,
                                                    double* __restrict__ K, int ldk, int flags,
-                                                   const double* __restrict__ diag_add, double diag_const, int sym) {
+                                                   const double* __restrict__ diag_add, double diag_const,
+                                                   const double* __restrict__ row_scale, int sym) {
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     int bm = blockIdx.y, bn = blockIdx.x;
     if (flags & GPAR_GRAM_LOWER) {
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
             const int row = row0 + 4 * ty + i;
             if (row >= n1) continue;
             const int col = col0 + cb;
+            if (row_scale) { const double rs = row_scale[row]; total[i][0] *= rs; total[i][1] *= rs; }
             if (sym) {
                 const double dadd = (diag_add ? diag_add[row] : 0.0) + diag_const;
                 if (col == row) total[i][0] += dadd;

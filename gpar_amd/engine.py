@@ -18,6 +18,7 @@ Primitive set (all tensors float64, row-major, lower triangles authoritative):
     potrf_(A, nf=None)                (partial) Cholesky -> (logdet, info) device scalars
     trsm_rlt_(L, B) / trsm_rln_(L, B) B L^-T / B L^-1
     gemm(A, B, ta, tb, alpha, beta, out, c_lower, a_lower)
+    gemv_t(A, v) / rownorm2(A)        A^T v for a tall A / squared row norms (HBM-bound passes)
     randn(rows, cols)                 counter-based standard normals
     sample_stats(samples, qlo, qhi)   Monte-Carlo mean / percentiles over the sample axis
 """
@@ -78,8 +79,8 @@ class HipEngine:
     def features(self, ck, x):
         return hip.featurize(ck, self._mat(x))
 
-    def gram(self, ck, z1, z2=None, lower=False, diag_add=None, diag_const=0.0, out=None):
-        return hip.gram(ck, z1, z2, out=out, lower=lower, diag_add=diag_add, diag_const=diag_const)
+    def gram(self, ck, z1, z2=None, lower=False, diag_add=None, diag_const=0.0, out=None, row_scale=None):
+        return hip.gram(ck, z1, z2, out=out, lower=lower, diag_add=diag_add, diag_const=diag_const, row_scale=row_scale)
 
     def gram_diag(self, ck, z):
         return hip.gram_diag(ck, z)
@@ -98,6 +99,14 @@ class HipEngine:
 
     def chol_inverse(self, L):
         return hip.chol_inverse(L)
+
+    def gemv_t(self, A, v):
+        """A^T v for a tall matrix A and one weight per row (vector of A.shape[1] entries)."""
+        return hip.gemv_t(self._mat(A), v)
+
+    def rownorm2(self, A):
+        """Squared Euclidean norm of every row of A (vector)."""
+        return hip.rownorm2(self._mat(A))
 
     def trmv_lower(self, L, x):
         """L x for lower-triangular L and a single column x."""

@@ -9,14 +9,24 @@ This module provides those names with the same call signatures; the arithmetic i
   exact GP (Rasmussen & Williams alg. 2.1), evaluated with ONE partial Cholesky of an augmented matrix
 
         [ K + D + eps I      .  ]   factor the first n columns     [ L          . ]
-        [ y^T                0  ]   ------------------------>      [ (L^-1 y)^T   -|L^-1 y|^2 ]
+        [ r^T                0  ]   ------------------------>      [ (L^-1 r)^T   -|L^-1 r|^2 ]
 
     which yields log|K|, the quadratic form and L in a single device pipeline (include/gpar_hip.h:
-    gpar_potrf); posterior moments at new inputs are V = K_*x L^-T (TRSM), mean = V (L^-1 y),
+    gpar_potrf); posterior moments at new inputs are V = K_*x L^-T (TRSM), mean = V (L^-1 r),
     cov = K_** - V V^T (SYRK);
 
   inducing points (Titsias 2009, VFE; stheno's PseudoObs default):  L_z = chol(K_zz), B^T = K_xz L_z^-T,
-    A = I + B D^-1 B^T, bound = -1/2 [ sum_j (k_jj - |B_:j|^2)/d_j + sum_j log(2 pi d_j) + log|A| + y^T D^-1 y - |L_A^-1 B D^-1 y|^2 ].
+    A = I + B D^-1 B^T, bound = -1/2 [ sum_j (k_jj - |B_:j|^2)/d_j + sum_j log(2 pi d_j) + log|A| + r^T D^-1 r - |L_A^-1 B D^-1 r|^2 ].
+
+A process is either the prior (zero mean, kernel k) or a posterior `g | obs`, whose mean and kernel are those of the
+process the observations were made of, corrected by the observations:
+
+    dense obs   mean + V_a (L^-1 r),        k(a, b) - V_a V_b^T,                 V_a = k(a, X) L^-T
+    sparse obs  mean + k(a, Z) v,           k(a, b) - P_a P_b^T + Q_a Q_b^T,     P_a = k(a, Z) L_z^-T, Q_a = P_a L_A^-T
+
+so observations of a posterior (a posterior log-density; conditioning twice) work for every combination of dense and
+inducing-point observations by recursion over the chain (`GP._moments_into / _cross / _diag / _mean_at`); the common
+cases - observations of the prior, dense observations of a dense posterior - keep their one-factorisation fast paths.
 
 All heavy steps are engine primitives (HIP kernels); torch is used here only for O(n) vector plumbing.
 """
@@ -57,17 +67,35 @@ def _noise_vector(eng, noise, n):
     return t.contiguous()
 
 
+def _zeros(n, like):
+    return torch.zeros(n, 1, dtype=torch.float64, device=like.device)
+
+
+class _Pts:
+    """A set of inputs together with the compiled kernel and their features under it (shared by every process of one
+    conditioning chain: conditioning changes the mean and the kernel's correction terms, not the base kernel)."""
+
+    __slots__ = ("x", "ck", "z", "n")
+
+    def __init__(self, eng, kernel, x):
+        self.x = x
+        self.n = int(x.shape[0])
+        self.ck = eng.compile(kernel, x.shape[1])
+        self.z = eng.features(self.ck, x)
+
+
 class _Factor:
     """Cholesky of an n x n SPD matrix together with the solve against one right-hand side, from one partial
     factorisation of the (n + 1) x (n + 1) augmented matrix.  `fill(block)` must write the lower triangle of the
-    SPD matrix into `block` (an n x n view)."""
+    SPD matrix into `block` (an n x n view) and return the vector to subtract from `rhs` (or None)."""
 
     def __init__(self, eng, n, fill, rhs):
         self.eng, self.n = eng, n
         A = eng.new_matrix(n + 1, n + 1)
         if n > 0:
-            fill(A[:n, :n])
-            A[n, :n] = rhs.reshape(-1)
+            shift = fill(A[:n, :n])
+            rhs = rhs.reshape(-1)
+            A[n, :n] = rhs if shift is None else rhs - shift.reshape(-1)
         A[n, n] = 0.0
         if n > 0:
             logdet, info = eng.potrf_(A, nf=n)
@@ -180,7 +208,7 @@ class Measure:
 
 
 class GP:
-    """Zero-mean Gaussian process with a `gpar_amd.kernels.Kernel`; `f | obs` gives the posterior process."""
+    """Gaussian process with a `gpar_amd.kernels.Kernel`: the zero-mean prior, or (after `f | obs`) a posterior."""
 
     def __init__(self, kernel, measure=None, engine=None, _obs=None):
         if not isinstance(kernel, Kernel):
@@ -206,29 +234,92 @@ class GP:
             obs = Obs(*obs)
         if not isinstance(obs, (Obs, PseudoObs)):
             raise TypeError("can only condition on Obs / PseudoObs or a (fdd, y) tuple")
-        if self.is_posterior:
-            obs = self._obs.merged_with(obs)
-        if obs.prior_gp().kernel is not self.kernel:
+        if obs.base.kernel is not self.kernel:
             raise ValueError("observations belong to a different process")
+        if obs.base is not self:
+            if not (obs.base.is_posterior or self.is_posterior):
+                obs = obs.rebased(self)  # another handle of the same prior
+            else:
+                raise ValueError("observations must be made of the process that is being conditioned")
+        if self.is_posterior and isinstance(obs, Obs) and isinstance(self._obs, Obs) and not self._obs.base.is_posterior:
+            # dense on dense: one factorisation of the stacked observations of the prior
+            return GP(self.kernel, measure=Measure(), engine=self._engine, _obs=self._obs.merged_with(obs))
         return GP(self.kernel, measure=Measure(), engine=self._engine, _obs=obs)
 
-    def mean(self, x):
+    # ---- process primitives (recursive over the conditioning chain) ---------------------------------
+    def _pts(self, x):
         eng = self.engine
-        x = _as_matrix(eng, x)
-        if not self.is_posterior or x.shape[0] == 0:
-            return torch.zeros(x.shape[0], 1, dtype=torch.float64, device=x.device)
-        return self._obs.posterior_mean(x)
+        return _Pts(eng, self.kernel, _as_matrix(eng, x))
+
+    def _mean_at(self, p):
+        if not self.is_posterior or p.n == 0:
+            return _zeros(p.n, p.x)
+        return self._obs.mean_at(p)
+
+    def _cross(self, pa, pb, row_scale=None):
+        """k(a, b) as a new na x nb matrix (rows optionally scaled)."""
+        if not self.is_posterior:
+            return self.engine.gram(pa.ck, pa.z, pb.z, row_scale=row_scale)
+        K = self._obs.cross(pa, pb)
+        if row_scale is not None:
+            K.mul_(row_scale[:, None])
+        return K
+
+    def _diag(self, p):
+        """k(a, a) for every row of p (vector)."""
+        if not self.is_posterior:
+            return self.engine.gram_diag(p.ck, p.z)
+        return self._obs.diag(p)
+
+    def _moments_into(self, p, block, diag_add=None, jitter=0.0):
+        """Lower triangle of k(p, p) + diag(diag_add) + jitter I into `block`; returns the mean at p (n x 1)."""
+        if not self.is_posterior:
+            self.engine.gram(p.ck, p.z, lower=True, diag_add=diag_add, diag_const=jitter, out=block)
+            return _zeros(p.n, p.x)
+        return self._obs.moments_into(p, block, diag_add, jitter)
+
+    # ---- public ------------------------------------------------------------------------------------
+    def mean(self, x):
+        return self._mean_at(self._pts(x))
+
+    def marginal_moments(self, x, noise=None):
+        """(mean, variance) of f(x) (+ noise) point by point - no n* x n* covariance is formed."""
+        p = self._pts(x)
+        var = self._diag(p)
+        nv = _noise_vector(self.engine, noise, p.n)
+        if nv is not None:
+            var = var + nv
+        return self._mean_at(p), var
 
     def sample_batch(self, xs, noise=None):
         """One draw of f (+ noise) at each input set in `xs` (a list of n* x D matrices, e.g. the per-sample design
         matrices of ancestral sampling): returns an n* x len(xs) matrix.  For a dense posterior the expensive step -
         V_s = K(x_s, X) L^-T for every s - is ONE stacked triangular solve instead of len(xs) separate ones."""
-        if self.is_posterior and isinstance(self._obs, Obs):
-            return self._obs.posterior_sample_batch(self, xs, noise)
+        if self.is_posterior and self._obs.fast_dense:
+            return self._obs.posterior_sample_batch(xs, noise)
         return torch.cat([self(x_s, noise).sample() for x_s in xs], dim=1)
 
+    def marginal_sample_batch(self, xs, noise=None):
+        """As `sample_batch`, but every point is drawn from its own marginal N(mean_j, var_j + noise_j) instead of the
+        joint law of the n* points: per-point predictive statistics are unchanged, the draws of one sample are
+        independent across points.  Needs no n* x n* covariance and no factorisation of one."""
+        eng = self.engine
+        S = len(xs)
+        ns = int(xs[0].shape[0])
+        if self.is_posterior and self._obs.fast_dense:
+            mean, var = self._obs.posterior_marginals_batch(xs)
+        else:
+            moments = [self.marginal_moments(x_s) for x_s in xs]
+            mean = torch.cat([m for m, _ in moments], dim=1)
+            var = torch.stack([v for _, v in moments], dim=1)
+        nv = _noise_vector(eng, noise, ns)
+        if nv is not None:
+            var = var + nv[:, None]
+        # eps as the joint sampler's jitter; a variance rounded below zero is clamped
+        return mean + torch.sqrt(torch.clamp(var + eng.epsilon, min=0.0)) * eng.randn(ns, S)
+
     def mean_batch(self, xs):
-        if self.is_posterior and isinstance(self._obs, Obs) and len(xs) > 1:
+        if self.is_posterior and self._obs.fast_dense and len(xs) > 1:
             return self._obs.posterior_mean_batch(xs)
         return [self.mean(x_s) for x_s in xs]
 
@@ -247,27 +338,25 @@ class FDD:
         self.n = self.x.shape[0]
         self.noise = _noise_vector(self.eng, noise, self.n)
         self.noise_arg = noise  # kept for the autograd path (may carry a graph)
-        self._ck = None
-        self._z = None
+        self._pts = None
 
-    # compiled kernel + features of x (cached)
+    def pts(self):
+        """Inputs + compiled kernel + features (cached)."""
+        if self._pts is None:
+            self._pts = _Pts(self.eng, self.p.kernel, self.x)
+        return self._pts
+
     def features(self):
-        if self._z is None:
-            self._ck = self.eng.compile(self.p.kernel, self.x.shape[1])
-            self._z = self.eng.features(self._ck, self.x)
-        return self._ck, self._z
+        p = self.pts()
+        return p.ck, p.z
 
     # ---- moments ---------------------------------------------------------------------------------
     def mean(self):
-        return self.p.mean(self.x)
+        return self.p._mean_at(self.pts())
 
     def _fill_cov(self, block, jitter):
         """Write the lower triangle of cov(f(x)) + diag(noise) + jitter I into `block`; returns the mean (n x 1)."""
-        if self.p.is_posterior:
-            return self.p._obs.posterior_moments(self, block, jitter)
-        ck, z = self.features()
-        self.eng.gram(ck, z, lower=True, diag_add=self.noise, diag_const=jitter, out=block)
-        return torch.zeros(self.n, 1, dtype=torch.float64, device=self.x.device)
+        return self.p._moments_into(self.pts(), block, self.noise, jitter)
 
     def var(self):
         """Dense covariance (including noise), symmetric; for tests and small problems."""
@@ -277,8 +366,8 @@ class FDD:
         return low + torch.tril(low, -1).T
 
     def marginals(self):
-        v = self.var()
-        return self.mean().reshape(-1), torch.diagonal(v).clone()
+        mean, var = self.p.marginal_moments(self.x, self.noise)
+        return mean.reshape(-1), var
 
     # ---- logpdf / sample ---------------------------------------------------------------------------
     def _factor(self, y):
@@ -286,18 +375,7 @@ class FDD:
         y = _as_matrix(eng, y)
         if y.shape[0] != self.n:
             raise ValueError(f"{y.shape[0]} observations for {self.n} inputs")
-        holder = {}
-
-        def fill(block):
-            holder["mean"] = self._fill_cov(block, eng.epsilon)
-
-        if self.p.is_posterior:
-            # the residual needs the mean, which _fill_cov produces: fill into a scratch block first
-            scratch = eng.new_matrix(self.n, self.n)
-            mean = self._fill_cov(scratch, eng.epsilon)
-            resid = y - mean
-            return _Factor(eng, self.n, lambda block: block.copy_(scratch), resid)
-        return _Factor(eng, self.n, fill, y)
+        return _Factor(eng, self.n, lambda block: self._fill_cov(block, eng.epsilon), y)
 
     def logpdf(self, y):
         return self._factor(y).logpdf()
@@ -318,26 +396,35 @@ class FDD:
 
 
 class Obs:
-    """Exact observations `y = f(x) + noise` (stheno `Obs(fdd, y)`)."""
+    """Exact observations `y = f(x) + noise` (stheno `Obs(fdd, y)`) of the process `fdd.p` (prior or posterior)."""
 
     def __init__(self, fdd, y):
         self.fdd = fdd
         self.eng = fdd.eng
+        self.base = fdd.p
         self.y = _as_matrix(self.eng, y)
         if self.y.shape[0] != fdd.n:
             raise ValueError(f"{self.y.shape[0]} observations for {fdd.n} inputs")
         self._fac = None
 
+    @property
+    def fast_dense(self):
+        """Dense observations of the prior: the stacked / batched posterior routines below apply."""
+        return not self.base.is_posterior
+
     def prior_gp(self):
-        p = self.fdd.p
-        return p if not p.is_posterior else p._obs.prior_gp()
+        p = self.base
+        while p.is_posterior:
+            p = p._obs.base
+        return p
+
+    def rebased(self, gp):
+        return Obs(FDD(gp, self.fdd.x, self.fdd.noise_arg), self.y)
 
     # log marginal likelihood of y under the process the fdd belongs to (prior or posterior)
     def logpdf(self):
-        if self.fdd.p.is_posterior:
-            return self.fdd.logpdf(self.y)
-        if torch.is_grad_enabled():
-            params = kernel_parameters(self.fdd.p.kernel)
+        if not self.base.is_posterior and torch.is_grad_enabled():
+            params = kernel_parameters(self.base.kernel)
             noise = self.fdd.noise_arg if _needs_grad(self.fdd.noise_arg) else None
             if params or noise is not None:
                 self._params = params
@@ -350,7 +437,7 @@ class Obs:
 
     def gradients(self):
         """(1/2 diag(W) as a device vector, kernel-parameter gradients) with W = alpha alpha^T - (K + D)^-1."""
-        eng, fac, n = self.eng, self.factor(), self.fdd.n
+        eng, fac = self.eng, self.factor()
         W = eng.chol_inverse(fac.L)  # (K + D)^-1, lower triangle
         a = fac.alpha()
         eng.gemm(a, a, ta=True, alpha=1.0, beta=-1.0, out=W, c_lower=True)
@@ -364,44 +451,56 @@ class Obs:
         return self._fac
 
     def factor(self):
-        """Cholesky of K + D + eps I and L^-1 y; valid when the fdd belongs to the prior."""
+        """Cholesky of cov(f(X)) + D + eps I under the observed process and L^-1 (y - mean(X))."""
         if self._fac is None:
-            if self.fdd.p.is_posterior:
-                raise RuntimeError("internal: factor() requested for observations of a posterior process")
             self._fac = self.fdd._factor(self.y)
         return self._fac
 
     def merged_with(self, other):
-        """Observations of the prior equivalent to conditioning on `self` and then on `other` (dense only)."""
-        if not isinstance(other, Obs):
-            raise NotImplementedError("conditioning a posterior on inducing-point observations is not supported")
+        """Observations of the prior equivalent to conditioning on `self` and then on `other` (both dense)."""
         prior = self.prior_gp()
         a, b = self.fdd, other.fdd
-        if a.noise is None or b.noise is None:
-            na = a.noise if a.noise is not None else torch.zeros(a.n, dtype=torch.float64, device=a.x.device)
-            nb = b.noise if b.noise is not None else torch.zeros(b.n, dtype=torch.float64, device=b.x.device)
-        else:
-            na, nb = a.noise, b.noise
+        na = a.noise if a.noise is not None else torch.zeros(a.n, dtype=torch.float64, device=a.x.device)
+        nb = b.noise if b.noise is not None else torch.zeros(b.n, dtype=torch.float64, device=b.x.device)
         x = torch.cat([a.x, b.x], dim=0)
         return Obs(FDD(prior, x, torch.cat([na, nb])), torch.cat([self.y, other.y], dim=0))
 
-    # ---- posterior ---------------------------------------------------------------------------------
-    def _cross(self, fdd_or_x):
-        """K(x*, X) as an n* x n matrix plus the features of x*."""
-        ck, z = self.fdd.features()
-        if isinstance(fdd_or_x, FDD):
-            zs = self.eng.features(ck, fdd_or_x.x)
-        else:
-            zs = self.eng.features(ck, fdd_or_x)
-        return ck, zs, self.eng.gram(ck, zs, z)
+    # ---- the posterior's corrections (any base process) -----------------------------------------------
+    def _V(self, p):
+        """V = k_base(p, X) L^-T  (n_p x n)."""
+        V = self.base._cross(p, self.fdd.pts())
+        self.eng.trsm_rlt_(self.factor().L, V)
+        return V
 
-    def posterior_mean(self, x):
-        fac = self.factor()
+    def mean_at(self, p):
+        base_mean = self.base._mean_at(p)
         if self.fdd.n == 0:
-            return torch.zeros(x.shape[0], 1, dtype=torch.float64, device=x.device)
-        _, _, Ks = self._cross(x)
-        return self.eng.gemm(Ks, fac.alpha(), tb=True)
+            return base_mean
+        Ks = self.base._cross(p, self.fdd.pts())
+        corr = self.eng.gemm(Ks, self.factor().alpha(), tb=True)
+        return corr if not self.base.is_posterior else base_mean + corr
 
+    def cross(self, pa, pb):
+        K = self.base._cross(pa, pb)
+        if self.fdd.n:
+            self.eng.gemm(self._V(pa), self._V(pb), tb=True, alpha=-1.0, beta=1.0, out=K)
+        return K
+
+    def diag(self, p):
+        d = self.base._diag(p)
+        return d - self.eng.rownorm2(self._V(p)) if self.fdd.n else d
+
+    def moments_into(self, p, block, diag_add, jitter):
+        eng = self.eng
+        mean = self.base._moments_into(p, block, diag_add, jitter)
+        if self.fdd.n == 0:
+            return mean
+        V = self._V(p)
+        eng.gemm(V, V, tb=True, alpha=-1.0, beta=1.0, out=block, c_lower=True)
+        corr = eng.gemm(V, self.factor().zrow, tb=True)
+        return corr if not self.base.is_posterior else mean + corr
+
+    # ---- batched routines for dense observations of the prior (`fast_dense`) ----------------------------
     def posterior_mean_batch(self, xs):
         """Posterior means at several input sets with one stacked cross-Gram product."""
         eng, fac = self.eng, self.factor()
@@ -417,7 +516,41 @@ class Obs:
         means = eng.gemm(B, fac.alpha(), tb=True)
         return list(torch.split(means, sizes, dim=0))
 
-    def posterior_sample_batch(self, gp, xs, noise):
+    def _stacked_V(self, zss, ns):
+        """Rows [k ns, (k + 1) ns): V_k = K(x_k, X) L^-T for every feature set in zss - ONE triangular solve."""
+        eng, fac = self.eng, self.factor()
+        ck, z = self.fdd.features()
+        B = eng.new_matrix(len(zss) * ns, self.fdd.n)
+        for k, zs in enumerate(zss):
+            eng.gram(ck, zs, z, out=B[k * ns : (k + 1) * ns])
+        eng.trsm_rlt_(fac.L, B)
+        return B
+
+    def _chunk(self, ns):
+        """Samples per stacked right-hand side: S n* x n doubles bounded to ~16 GB of the 288 GB HBM."""
+        return max(1, int(16e9 // max(1, ns * max(self.fdd.n, 1) * 8)))
+
+    def posterior_marginals_batch(self, xs):
+        """(means, variances), each n* x S: column s holds the posterior mean / marginal variance (no noise) at xs[s]."""
+        eng, fac = self.eng, self.factor()
+        ck, z = self.fdd.features()
+        n, S = self.fdd.n, len(xs)
+        ns = int(xs[0].shape[0])
+        mean = torch.zeros(ns, S, dtype=torch.float64, device=z.device)
+        var = torch.empty(ns, S, dtype=torch.float64, device=z.device)
+        chunk = self._chunk(ns)
+        for s0 in range(0, S, chunk):
+            s1 = min(S, s0 + chunk)
+            zss = [eng.features(ck, _as_matrix(eng, xs[s])) for s in range(s0, s1)]
+            kd = torch.stack([eng.gram_diag(ck, zs) for zs in zss], dim=1)
+            if n > 0:
+                B = self._stacked_V(zss, ns)
+                mean[:, s0:s1] = eng.gemm(B, fac.zrow, tb=True).reshape(s1 - s0, ns).T
+                kd = kd - eng.rownorm2(B).reshape(s1 - s0, ns).T
+            var[:, s0:s1] = kd
+        return mean, var
+
+    def posterior_sample_batch(self, xs, noise):
         eng, fac = self.eng, self.factor()
         ck, z = self.fdd.features()
         n, S = self.fdd.n, len(xs)
@@ -427,23 +560,20 @@ class Obs:
             return out
         noise_vec = _noise_vector(eng, noise, ns)
         zr = eng.randn(ns, S)
-        # bound the stacked right-hand side (S n* x n doubles) to ~16 GB of the 288 GB HBM
-        chunk = max(1, int(16e9 // max(1, ns * max(n, 1) * 8)))
+        chunk = self._chunk(ns)
         for s0 in range(0, S, chunk):
             s1 = min(S, s0 + chunk)
             zss = [eng.features(ck, _as_matrix(eng, xs[s])) for s in range(s0, s1)]
-            B = eng.new_matrix((s1 - s0) * ns, max(n, 1))
+            B = means = None
             if n > 0:
-                for k, zs in enumerate(zss):
-                    eng.gram(ck, zs, z, out=B[k * ns : (k + 1) * ns])
-                eng.trsm_rlt_(fac.L, B)  # every V_s = K(x_s, X) L^-T in one solve
+                B = self._stacked_V(zss, ns)  # every V_s = K(x_s, X) L^-T in one solve
                 means = eng.gemm(B, fac.zrow, tb=True)
             # the per-sample blocks (Gram, SYRK downdate, an n* x n* factorisation, one matvec) are independent: a small
             # factorisation is a latency-bound chain, so they are dealt over a few streams and checked once at the end
             pipe = eng.pipeline(min(4, s1 - s0)) if s1 - s0 > 1 else None
             with eng.defer_checks(), joining(pipe):  # streams are joined BEFORE the deferred info words are read
                 for k, zs in enumerate(zss):
-                    with (pipe.stage(k, B, zr, out, zs, noise_vec, means if n > 0 else None) if pipe is not None else contextlib.nullcontext()):
+                    with (pipe.stage(k, B, zr, out, zs, noise_vec, means) if pipe is not None else contextlib.nullcontext()):
                         cov = eng.new_matrix(ns, ns)
                         eng.gram(ck, zs, lower=True, diag_add=noise_vec, diag_const=eng.epsilon, out=cov)
                         mean = 0.0
@@ -456,21 +586,12 @@ class Obs:
                         out[:, s0 + k : s0 + k + 1] = eng.trmv_lower(cov, zr[:, s0 + k : s0 + k + 1]) + mean
         return out
 
-    def posterior_moments(self, fdd, block, jitter):
-        """Lower triangle of K_** - V V^T + diag(noise*) + jitter I into `block`; returns the mean."""
-        eng = self.eng
-        fac = self.factor()
-        ck, zs, V = self._cross(fdd)
-        eng.gram(ck, zs, lower=True, diag_add=fdd.noise, diag_const=jitter, out=block)
-        if self.fdd.n == 0:
-            return torch.zeros(fdd.n, 1, dtype=torch.float64, device=block.device)
-        eng.trsm_rlt_(fac.L, V)  # V = K_*x L^-T
-        eng.gemm(V, V, tb=True, alpha=-1.0, beta=1.0, out=block, c_lower=True)
-        return eng.gemm(V, fac.zrow, tb=True)
-
 
 class PseudoObs:
-    """Inducing-point observations, VFE approximation (stheno `PseudoObs(f(x_ind), f(x, noise), y)`)."""
+    """Inducing-point observations, VFE approximation (stheno `PseudoObs(f(x_ind), f(x, noise), y)`), of the process
+    `fdd.p` (prior or posterior)."""
+
+    fast_dense = False
 
     def __init__(self, u, fdd, y):
         if isinstance(u, tuple):
@@ -478,59 +599,63 @@ class PseudoObs:
         self.u = u
         self.fdd = fdd
         self.eng = fdd.eng
+        self.base = fdd.p
         self.y = _as_matrix(self.eng, y)
-        if fdd.p.is_posterior or u.p.is_posterior:
-            raise NotImplementedError("inducing-point observations must be built on the prior")
+        if u.p is not fdd.p and (u.p.kernel is not fdd.p.kernel or u.p.is_posterior or fdd.p.is_posterior):
+            raise ValueError("inducing points and observations must belong to the same process")
         if fdd.noise is None:
             raise ValueError("inducing-point observations need observation noise")
         self._state = None
 
     def prior_gp(self):
-        return self.fdd.p
+        p = self.base
+        while p.is_posterior:
+            p = p._obs.base
+        return p
 
-    def merged_with(self, other):
-        raise NotImplementedError("conditioning a sparse posterior again is not supported")
+    def rebased(self, gp):
+        return PseudoObs(FDD(gp, self.u.x), FDD(gp, self.fdd.x, self.fdd.noise_arg), self.y)
 
     def _compute(self):
         if self._state is not None:
             return self._state
-        eng = self.eng
+        eng, base = self.eng, self.base
         n, M = self.fdd.n, self.u.n
-        ck, zx = self.fdd.features()
-        zu = eng.features(ck, self.u.x)
+        px, pz = self.fdd.pts(), self.u.pts()
         d = self.fdd.noise
-        # L_z = chol(K_zz + eps I)
-        Kzz = eng.new_matrix(M, M)
-        eng.gram(ck, zu, lower=True, diag_const=eng.epsilon, out=Kzz)
-        _, info = eng.potrf_(Kzz)
-        eng.check_info(info)
-        Lz = Kzz
-        # B^T = K_xz L_z^-T  (n x M), rows scaled by d^-1/2
-        Bt = eng.gram(ck, zx, zu)
-        eng.trsm_rlt_(Lz, Bt)
-        kdiag = eng.gram_diag(ck, zx)
-        trace_term = torch.sum((kdiag - torch.sum(Bt * Bt, dim=1)) / d)
         rs = torch.rsqrt(d)
-        # [B D^-1/2 | D^-1/2 y]: ONE product over the n data points gives A - I, c = B D^-1 y and y^T D^-1 y together
-        Bs = eng.new_matrix(n, M + 1)
-        torch.mul(Bt, rs[:, None], out=Bs[:, :M])
-        Bs[:, M] = self.y.reshape(-1) * rs
-        G = eng.gemm(Bs, Bs, ta=True, c_lower=True)  # (M + 1) x (M + 1), lower triangle
-        c = G[M : M + 1, :M].clone()
-        yDy = G[M, M].clone()
+        # L_z = chol(K_zz + eps I)
+        Lz = eng.new_matrix(M, M)
+        mean_z = base._moments_into(pz, Lz, None, eng.epsilon)
+        del mean_z  # the bound only involves the mean at the observed inputs
+        _, info = eng.potrf_(Lz)
+        eng.check_info(info)
+        # Bs = D^-1/2 K_xz L_z^-T (n x M): the row scaling rides along in the Gram kernel
+        Bs = base._cross(px, pz, row_scale=rs)
+        eng.trsm_rlt_(Lz, Bs)
+        kdiag = base._diag(px)
+        resid = self.y if not base.is_posterior else self.y - base._mean_at(px)
+        ys = resid.reshape(-1) * rs
+        # A - I = Bs^T Bs: ONE product over the n data points (K = n is cut into slices so that the whole chip works);
+        # c = Bs^T ys is a matrix-vector pass; the trace term needs no pass of its own:
+        #   sum_a (k_aa - |B_:a|^2) / d_a = sum_a k_aa / d_a - tr(A - I)
+        G = eng.gemm(Bs, Bs, ta=True, c_lower=True)
+        c = eng.gemv_t(Bs, ys).reshape(1, M)
+        yDy = torch.sum(ys * ys)
+        trace_term = torch.sum(kdiag / d) - torch.sum(torch.diagonal(G))
 
         def fill(block):
-            block.copy_(G[:M, :M])
+            block.copy_(G)
             block.diagonal().add_(1.0)
 
         facA = _Factor(eng, M, fill, c)
         elbo = -0.5 * (trace_term + torch.sum(torch.log(d)) + n * _LOG_2PI + facA.logdet[0] + yDy - facA.quad)
-        # v = L_z^-T A^-1 c, so that mean(x*) = K_*z v
+        # v = L_z^-T A^-1 c, so that the mean correction at x* is K_*z v
         v = facA.alpha().clone()  # (A^-1 c)^T, 1 x M
         eng.trsm_rln_(Lz, v)
         deferring = getattr(eng, "_deferred", None) is not None
-        self._state = {"ck": ck, "zu": zu, "Lz": Lz, "La": facA.L, "v": v, "elbo": elbo.detach() if deferring else elbo.detach().cpu(),
-                       "Bt": Bt, "facA": facA, "kdiag": kdiag}
+        self._state = {"Lz": Lz, "La": facA.L, "v": v, "elbo": elbo.detach() if deferring else elbo.detach().cpu(),
+                       "Bs": Bs, "G": G, "facA": facA, "kdiag": kdiag, "ys": ys}
         return self._state
 
     def _value(self):
@@ -538,8 +663,8 @@ class PseudoObs:
 
     def logpdf(self):
         """The VFE bound; differentiable with respect to kernel parameters and noise when they carry a graph."""
-        if torch.is_grad_enabled():
-            params = kernel_parameters(self.fdd.p.kernel)
+        if not self.base.is_posterior and torch.is_grad_enabled():
+            params = kernel_parameters(self.base.kernel)
             noise = self.fdd.noise_arg if _needs_grad(self.fdd.noise_arg) else None
             if params or noise is not None:
                 self._params = params
@@ -560,29 +685,30 @@ class PseudoObs:
             W_fu = [alpha beta^T + D^-1 B^T (I - A^-1)] L_z^-1,   beta = B alpha,
             W_uu = -1/2 L_z^-T (beta beta^T + A - 2 I + A^-1) L_z^-1,
             (S^-1)_aa = 1/d_a - |L_A^-1 B_:a|^2 / d_a^2.
-        The three weighted sums over kernel derivatives are one fused device pass each (`kernel_grads_vfe`)."""
+        The forward pass keeps Bs = D^-1/2 B^T, so B^T = D^1/2 Bs throughout.  The three weighted sums over kernel
+        derivatives are one fused device pass each (`kernel_grads_vfe`)."""
         eng = self.eng
         st = self._compute()
         n, M = self.fdd.n, self.u.n
         d = self.fdd.noise
-        Bt, facA, Lz = st["Bt"], st["facA"], st["Lz"]
+        rs = torch.rsqrt(d)
+        Bs, facA, Lz, G = st["Bs"], st["facA"], st["Lz"], st["G"]
         a = facA.alpha()  # (A^-1 B D^-1 y)^T, 1 x M
-        alpha = (self.y.reshape(-1) - eng.gemm(Bt, a, tb=True).reshape(-1)) / d  # S^-1 y
-        beta = eng.gemm(alpha.reshape(1, n), Bt)  # 1 x M
+        alpha = (st["ys"] - eng.gemm(Bs, a, tb=True).reshape(-1)) * rs  # S^-1 y
+        beta = eng.gemv_t(Bs, alpha / rs).reshape(1, M)  # (B alpha)^T
         Ainv = eng.chol_inverse(facA.L)  # lower triangle of A^-1
         Ainv_full = torch.tril(Ainv) + torch.tril(Ainv, -1).T
         # W_fu
         T = eng.new_matrix(n, M)
-        T.copy_(Bt)
-        eng.gemm(Bt, Ainv_full, alpha=-1.0, beta=1.0, out=T)  # B^T (I - A^-1)
-        T.div_(d[:, None])
-        T.add_(alpha[:, None] * beta.reshape(1, M))
+        T.copy_(Bs)
+        eng.gemm(Bs, Ainv_full, alpha=-1.0, beta=1.0, out=T)  # Bs (I - A^-1)
+        T.mul_(rs[:, None])  # D^-1 B^T (I - A^-1)
+        T.add_(alpha[:, None] * beta)
         eng.trsm_rln_(Lz, T)  # ... L_z^-1
         # W_uu
         S = eng.new_matrix(M, M)
-        S.copy_(beta.reshape(M, 1) * beta.reshape(1, M) + Ainv_full)
-        A_minus_I = eng.gemm(Bt / torch.sqrt(d)[:, None], Bt / torch.sqrt(d)[:, None], ta=True)  # B D^-1 B^T
-        S.add_(A_minus_I)
+        S.copy_(beta.reshape(M, 1) * beta + Ainv_full)
+        S.add_(torch.tril(G) + torch.tril(G, -1).T)  # B D^-1 B^T = A - I
         S.diagonal().sub_(1.0)
         eng.trsm_rln_(Lz, S)  # S L_z^-1
         St = eng.new_matrix(M, M)
@@ -590,35 +716,60 @@ class PseudoObs:
         eng.trsm_rln_(Lz, St)  # L_z^-T S L_z^-1 (symmetric)
         Wuu = eng.new_matrix(M, M)
         Wuu.copy_(-0.25 * (St + St.T))
-        # per-point terms
+        # per-point terms: |L_A^-1 B_:a|^2 / d_a^2 = |Es_a|^2 / d_a with Es = Bs L_A^-T, and q_aa / d_a^2 = |Bs_a|^2 / d_a
         E = eng.new_matrix(n, M)
-        E.copy_(Bt)
-        eng.trsm_rlt_(facA.L, E)  # rows: (L_A^-1 B_:a)^T
-        e = torch.sum(E * E, dim=1)
-        q = torch.sum(Bt * Bt, dim=1)
-        noise_grad = 0.5 * (alpha * alpha - 1.0 / d + e / (d * d) + (st["kdiag"] - q) / (d * d))
-        grads = eng.kernel_grads_vfe(st["ck"], self.fdd.x, self.u.x, T, Wuu, -0.5 / d)
+        E.copy_(Bs)
+        eng.trsm_rlt_(facA.L, E)
+        noise_grad = 0.5 * (alpha * alpha - 1.0 / d + (eng.rownorm2(E) - eng.rownorm2(Bs)) / d + st["kdiag"] / (d * d))
+        ck = self.fdd.pts().ck
+        grads = eng.kernel_grads_vfe(ck, self.fdd.x, self.u.x, T, Wuu, -0.5 / d)
         return noise_grad, grads
 
-    def posterior_mean(self, x):
-        st = self._compute()
-        zs = self.eng.features(st["ck"], x)
-        Ksz = self.eng.gram(st["ck"], zs, st["zu"])
-        return self.eng.gemm(Ksz, st["v"], tb=True)
+    # ---- the posterior's corrections (any base process) -----------------------------------------------
+    def _P(self, p):
+        """(k_base(p, Z), P = k_base(p, Z) L_z^-T) as two n_p x M matrices."""
+        Kz = self.base._cross(p, self.u.pts())
+        P = Kz.clone()
+        self.eng.trsm_rlt_(self._compute()["Lz"], P)
+        return Kz, P
 
-    def posterior_moments(self, fdd, block, jitter):
-        eng = self.eng
+    def mean_at(self, p):
         st = self._compute()
-        ck = st["ck"]
-        zs = eng.features(ck, fdd.x)
-        eng.gram(ck, zs, lower=True, diag_add=fdd.noise, diag_const=jitter, out=block)
-        P = eng.gram(ck, zs, st["zu"])
-        mean = eng.gemm(P, st["v"], tb=True)
-        eng.trsm_rlt_(st["Lz"], P)  # P = K_*z L_z^-T
+        Kz = self.base._cross(p, self.u.pts())
+        corr = self.eng.gemm(Kz, st["v"], tb=True)
+        return corr if not self.base.is_posterior else self.base._mean_at(p) + corr
+
+    # kept for callers that use the stheno-like name
+    def posterior_mean(self, x):
+        return self.mean_at(self.base._pts(x))
+
+    def cross(self, pa, pb):
+        eng, st = self.eng, self._compute()
+        K = self.base._cross(pa, pb)
+        _, Pa = self._P(pa)
+        _, Pb = self._P(pb)
+        eng.gemm(Pa, Pb, tb=True, alpha=-1.0, beta=1.0, out=K)
+        eng.trsm_rlt_(st["La"], Pa)
+        eng.trsm_rlt_(st["La"], Pb)
+        eng.gemm(Pa, Pb, tb=True, alpha=1.0, beta=1.0, out=K)
+        return K
+
+    def diag(self, p):
+        eng, st = self.eng, self._compute()
+        _, P = self._P(p)
+        out = self.base._diag(p) - eng.rownorm2(P)
+        eng.trsm_rlt_(st["La"], P)
+        return out + eng.rownorm2(P)
+
+    def moments_into(self, p, block, diag_add, jitter):
+        eng, st = self.eng, self._compute()
+        mean = self.base._moments_into(p, block, diag_add, jitter)
+        Kz, P = self._P(p)
+        corr = eng.gemm(Kz, st["v"], tb=True)
         eng.gemm(P, P, tb=True, alpha=-1.0, beta=1.0, out=block, c_lower=True)
         eng.trsm_rlt_(st["La"], P)  # Q = P L_A^-T
         eng.gemm(P, P, tb=True, alpha=1.0, beta=1.0, out=block, c_lower=True)
-        return mean
+        return corr if not self.base.is_posterior else mean + corr
 
 
 SparseObs = PseudoObs

@@ -21,10 +21,9 @@ __all__ = [
     "trsm_rlt_",
     "trsm_rln_",
     "gemm",
-    "logpdf_finalize",
-    "copy_strided_",
-    "fill_",
     "dot",
+    "gemv_t",
+    "rownorm2",
     "randn",
     "sample_stats",
     "trmv_lower",
@@ -79,8 +78,9 @@ def featurize(ck, x):
     return z
 
 
-def gram(ck, z1, z2=None, out=None, lower=False, diag_add=None, diag_const=0.0):
-    """K = k(z1, z2) (z2 None: symmetric, optionally lower-only, + diag_add + diag_const on the diagonal)."""
+def gram(ck, z1, z2=None, out=None, lower=False, diag_add=None, diag_const=0.0, row_scale=None):
+    """K = k(z1, z2) (z2 None: symmetric, optionally lower-only, + diag_add + diag_const on the diagonal); with `row_scale`
+    (n1 weights) row a is multiplied by row_scale[a]."""
     lib = _lib.load()
     sym = z2 is None
     if sym:
@@ -99,10 +99,16 @@ def gram(ck, z1, z2=None, out=None, lower=False, diag_add=None, diag_const=0.0):
         _check_mat(diag_add, "diag_add")
         diag_add = diag_add.contiguous()
         dptr = diag_add.data_ptr()
+    rptr = None
+    if row_scale is not None:
+        if row_scale.dim() != 1 or row_scale.numel() != n1 or row_scale.dtype != torch.float64:
+            raise ValueError("row_scale must be a vector of n1 fp64 weights")
+        row_scale = row_scale.contiguous()
+        rptr = row_scale.data_ptr()
     _lib.check(
         lib.gpar_gram(
             ctypes.byref(ck.kspec), z1.data_ptr(), n1, _ld(z1), z2.data_ptr(), n2, _ld(z2), ck.dz,
-            out.data_ptr(), _ld(out), flags, dptr, float(diag_const), stream_ptr(z1.device),
+            out.data_ptr(), _ld(out), flags, dptr, float(diag_const), rptr, stream_ptr(z1.device),
         ),
         "gpar_gram",
     )
@@ -178,11 +184,14 @@ def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False,
             raise ValueError("beta != 0 needs an `out`")
     _check_mat(out, "out")
     flags = (_lib.GEMM_C_LOWER if c_lower else 0) | (_lib.GEMM_A_LOWER if a_lower else 0)
-    # few output tiles but a very long K: cut K into slices so the whole chip works (deterministic two-pass sum)
-    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    # few output tiles but a very long K: cut K into slices so that the launch fills the chip's 512 workgroup slots (two
+    # 73.7 KB workgroups per CU) in one round; deterministic two-pass sum.  (The workspace comes from torch's stream-aware
+    # caching allocator: no hipMalloc after the first call of a given size.)
+    tm, tn = (m + 127) // 128, (n + 127) // 128
+    tiles = (min(tm, tn) * (min(tm, tn) + 1) // 2 + (tm - min(tm, tn)) * min(tm, tn)) if c_lower else tm * tn
     if not a_lower and k >= 8192 and tiles <= 128:
         splits = max(2, min(64, 512 // max(tiles, 1), k // 1024))
-        work = torch.empty(splits * m * n, dtype=torch.float64, device=A.device)
+        work = torch.empty(lib.gpar_workspace_doubles(_lib.WS_GEMM_SPLITK, m, n, splits), dtype=torch.float64, device=A.device)
         _lib.check(
             lib.gpar_gemm_splitk(
                 int(ta), int(tb), m, n, k, float(alpha), A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), float(beta),
@@ -201,33 +210,6 @@ def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False,
     return out
 
 
-def logpdf_finalize(logdet, quad, quad_sign, n):
-    lib = _lib.load()
-    out = torch.empty(1, dtype=torch.float64, device=logdet.device)
-    _lib.check(
-        lib.gpar_logpdf_finalize(logdet.data_ptr(), quad.data_ptr(), float(quad_sign), int(n), out.data_ptr(), stream_ptr(logdet.device)),
-        "gpar_logpdf_finalize",
-    )
-    return out
-
-
-def copy_strided_(src, src_inc, dst, dst_inc, n):
-    lib = _lib.load()
-    _lib.check(
-        lib.gpar_copy_strided(src.data_ptr(), int(src_inc), dst.data_ptr(), int(dst_inc), int(n), stream_ptr(dst.device)),
-        "gpar_copy_strided",
-    )
-    return dst
-
-
-def fill_(dst, value):
-    lib = _lib.load()
-    _check_mat(dst, "dst")
-    rows, cols = (1, dst.shape[0]) if dst.dim() == 1 else dst.shape
-    _lib.check(lib.gpar_fill(dst.data_ptr(), rows, cols, _ld(dst), float(value), stream_ptr(dst.device)), "gpar_fill")
-    return dst
-
-
 def dot(x, incx, y, incy, n, out=None, accumulate=False):
     lib = _lib.load()
     if out is None:
@@ -236,6 +218,30 @@ def dot(x, incx, y, incy, n, out=None, accumulate=False):
         lib.gpar_dot(x.data_ptr(), int(incx), y.data_ptr(), int(incy), int(n), out.data_ptr(), int(accumulate), stream_ptr(x.device)),
         "gpar_dot",
     )
+    return out
+
+
+def gemv_t(A, v):
+    """A^T v for a tall matrix A (rows x cols) and a vector v (rows): new vector of `cols` entries."""
+    lib = _lib.load()
+    _check_mat(A, "A")
+    rows, cols = A.shape
+    v = v.reshape(-1).contiguous()
+    if v.numel() != rows or v.dtype != torch.float64:
+        raise ValueError("v must hold one fp64 weight per row of A")
+    out = torch.empty(cols, dtype=torch.float64, device=A.device)
+    work = torch.empty(max(1, lib.gpar_workspace_doubles(_lib.WS_GEMV_T, rows, cols, 0)), dtype=torch.float64, device=A.device)
+    _lib.check(lib.gpar_gemv_t(A.data_ptr(), rows, cols, _ld(A), v.data_ptr(), out.data_ptr(), work.data_ptr(), stream_ptr(A.device)),
+               "gpar_gemv_t")
+    return out
+
+
+def rownorm2(A):
+    """Squared Euclidean norms of the rows of A: new vector."""
+    lib = _lib.load()
+    _check_mat(A, "A")
+    out = torch.empty(A.shape[0], dtype=torch.float64, device=A.device)
+    _lib.check(lib.gpar_rownorm2(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), out.data_ptr(), stream_ptr(A.device)), "gpar_rownorm2")
     return out
 
 

@@ -13,9 +13,15 @@ import torch
 
 from .engine import NotPositiveDefiniteError
 
-__all__ = ["minimise_l_bfgs_b"]
+__all__ = ["minimise_l_bfgs_b", "evaluation_count"]
 
 log = logging.getLogger(__name__)
+
+_evaluations = 0  # objective + gradient evaluations made by this process (read by bench.py to report work done)
+
+
+def evaluation_count():
+    return _evaluations
 
 
 def minimise_l_bfgs_b(f, vs, names=None, iters=1000, f_calls=10000, trace=False):
@@ -40,6 +46,8 @@ def minimise_l_bfgs_b(f, vs, names=None, iters=1000, f_calls=10000, trace=False)
     x0 = vs.get_vector(names)
 
     def fg(x):
+        global _evaluations
+        _evaluations += 1  # (several host threads may train layers at once: a statistic, not a synchronised counter)
         vs.set_vector(x, names)
         previous = [t.requires_grad for t in latents]
         for t in latents:

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GPAR_ABI_VERSION 1
+#define GPAR_ABI_VERSION 2
 
 /* ---- kernel specification -------------------------------------------------------------------
  * A GPAR layer kernel (gpar/regression.py:92-180) is a sum of products of elementary kernels applied
@@ -107,10 +107,13 @@ size_t gpar_sizeof_kspec(void);
  * reached from gpar/regression.py:110,127-129,138,146,166,178] */
 int gpar_featurize(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* z, int ldz, void* stream);
 
-/* K[a][b] = k(z1[a], z2[b]) (+ diag_add[a] + diag_const if a == b and z1 == z2).
+/* K[a][b] = row_scale[a] * k(z1[a], z2[b]) (+ diag_add[a] + diag_const if a == b and z1 == z2).
+ * row_scale may be NULL (= 1): the inducing-point path builds D^-1/2 K_xz directly (gpar/model.py:286-287), so that the
+ * scaled cross-Gram never needs a pass of its own.
  * [mlkernels K(x, y); f(x, noise / w) adds diag(noise / w): gpar/model.py:287-289; lab's B.epsilon jitter] */
 int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2,
-              int dz, double* K, int ldk, int flags, const double* diag_add, double diag_const, void* stream);
+              int dz, double* K, int ldk, int flags, const double* diag_add, double diag_const, const double* row_scale,
+              void* stream);
 
 /* out[a] = k(z[a], z[a])   [kernel diagonal; VFE trace term, posterior marginal variances] */
 int gpar_gram_diag(const gpar_kspec_t* ks, const double* z, int n, int ldz, int dz, double* out, void* stream);
@@ -178,15 +181,26 @@ int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A
 int gpar_gemm_splitk(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
                      int ldb, double beta, double* C, int ldc, int flags, int splits, double* workspace, void* stream);
 
-/* Small device-side utilities used by the fused paths (all asynchronous). */
-/* out[0] = -0.5 * (logdet[0] + n*log(2*pi) + quad_sign * quad[0])   [Normal.logpdf] */
-int gpar_logpdf_finalize(const double* logdet, const double* quad, double quad_sign, int n, double* out, void* stream);
-/* dst[i*ldd] = src[i*lds], i < n  (strided vector copy: y into the augmented row, diagonals out) */
-int gpar_copy_strided(const double* src, int lds, double* dst, int ldd, int n, void* stream);
-/* dst[r][c] = value for r < rows, c < cols */
-int gpar_fill(double* dst, int rows, int cols, int ldd, double value, void* stream);
+/* Small device-side reductions used by the fused paths (all asynchronous, all deterministic). */
 /* out[0] (+)= sum_i x[i*incx]*y[i*incy] */
 int gpar_dot(const double* x, int incx, const double* y, int incy, int n, double* out, int accumulate, void* stream);
+/* out[j] = sum_i A[i][j] * v[i], j < cols, for a tall rows x cols matrix (two passes: per-128-row partial sums into
+ * `workspace` - gpar_workspace_doubles(GPAR_WS_GEMV_T, rows, cols, 0) doubles - then an in-order sum).
+ * [c = B D^-1 y of the inducing-point bound; stheno PseudoObs, gpar/model.py:286-287] */
+int gpar_gemv_t(const double* A, int rows, int cols, int lda, const double* v, double* out, double* workspace, void* stream);
+/* out[i] = sum_j A[i][j]^2, i < rows.  [marginal posterior variances k(x*, x*) - |V_i|^2, V = K_*x L^-T] */
+int gpar_rownorm2(const double* A, int rows, int cols, int lda, double* out, void* stream);
+
+/* Workspace sizes in doubles (the caller allocates every workspace; -1 for an unknown `op`):
+ *   GPAR_WS_GEMM_SPLITK  (m, n, splits)   gpar_gemm_splitk
+ *   GPAR_WS_GEMV_T       (rows, cols, -)  gpar_gemv_t
+ *   GPAR_WS_GRAM_GRAD    (nblocks, -, -)  gpar_gram_grad / gpar_gram_grad_cross
+ *   GPAR_WS_CHOL_INVERSE (n, ldx, -)      the X matrix of gpar_chol_inverse */
+#define GPAR_WS_GEMM_SPLITK 1
+#define GPAR_WS_GEMV_T 2
+#define GPAR_WS_GRAM_GRAD 3
+#define GPAR_WS_CHOL_INVERSE 4
+long long gpar_workspace_doubles(int op, int a, int b, int c);
 /* Standard normals from Philox-4x32-10 + Box-Muller: out[r][c], element index = r*cols + c in the stream
  * identified by (seed, offset).   [B.randn in Normal.sample] */
 int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, int ldo, void* stream);
@@ -201,7 +215,7 @@ int gpar_trmv_lower(const double* L, int n, int ldl, const double* x, int incx, 
  * receive the order-statistic interpolations  v[k] + g (v[k+1] - v[k])  (numpy's "linear" method, evaluated with
  * numpy's _lerp so the result is bit-identical to np.percentile for the same (k, g)); the caller derives
  * (k_lo, g_lo), (k_hi, g_hi) from the percentiles exactly as numpy does.  Selection is by rank counting, O(S^2)
- * per element, S <= 65536. */
+ * per element, S <= 65536.  An element with a NaN among its samples gets NaN bounds (and a NaN mean), as numpy gives. */
 int gpar_sample_stats(const double* samples, int S, long long count, long long stride, int k_lo, double g_lo, int k_hi,
                       double g_hi, double* mean, double* lo, double* hi, void* stream);
 

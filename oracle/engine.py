@@ -63,9 +63,11 @@ class OracleEngine:
     def features(self, ck, x):
         return x  # the oracle evaluates kernels on the raw design matrix
 
-    def gram(self, ck, z1, z2=None, lower=False, diag_add=None, diag_const=0.0, out=None):
+    def gram(self, ck, z1, z2=None, lower=False, diag_add=None, diag_const=0.0, out=None, row_scale=None):
         K = ok.gram(ck.spec, _np(z1), None if z2 is None else _np(z2),
                     noise_diag=None if diag_add is None else _np(diag_add), jitter=diag_const)
+        if row_scale is not None:
+            K = K * _np(row_scale).reshape(-1, 1)
         if out is None:
             return torch.from_numpy(K)
         o = out.numpy()
@@ -175,6 +177,13 @@ class OracleEngine:
         else:
             o[...] = prod + (beta * o if beta != 0.0 else 0.0)
         return out
+
+    def gemv_t(self, A, v):
+        return torch.from_numpy(_np(A).T @ _np(v).reshape(-1))
+
+    def rownorm2(self, A):
+        a = _np(A)
+        return torch.from_numpy(np.sum(a * a, axis=1))
 
     # ---- randomness ------------------------------------------------------------------------------
     def seed(self, seed):

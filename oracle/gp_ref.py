@@ -64,3 +64,52 @@ def vfe_posterior(spec, x, y, noise, z, xs, eps=1e-12):
     mean = Ksz @ np.linalg.solve(Sigma, Kxz.T @ (y / d))
     cov = ok.gram(spec, xs) - Ksz @ np.linalg.solve(Kzz, Ksz.T) + Ksz @ np.linalg.solve(Sigma, Ksz.T)
     return mean, cov
+
+
+class Process:
+    """A Gaussian process given by explicit callables `mean(x) -> (n,)` and `k(a, b) -> (na, nb)`; conditioning returns
+    a new Process by the dense closed forms above (no factorisations are shared with the product).  Used to pin
+    observations OF A POSTERIOR - `PseudoObs` / `Obs` built on `f | obs`, conditioning twice - for every combination
+    of exact and inducing-point observations (what stheno supports through its measure algebra; the reference reaches
+    it in `GPARRegressor.logpdf(..., posterior=True)`, /root/reference/gpar/regression.py:493-499)."""
+
+    def __init__(self, mean, k):
+        self.mean, self.k = mean, k
+
+    @classmethod
+    def prior(cls, spec):
+        return cls(lambda x: np.zeros(np.asarray(x).shape[0]), lambda a, b: ok.gram(spec, np.asarray(a, float), np.asarray(b, float)))
+
+    def logpdf(self, x, y, noise, eps=1e-12):
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        S = self.k(x, x) + np.diag(np.broadcast_to(noise, y.shape) + eps)
+        return _mvn_logpdf(S, y - self.mean(x))
+
+    def condition(self, x, y, noise, eps=1e-12):
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        S = self.k(x, x) + np.diag(np.broadcast_to(noise, y.shape) + eps)
+        a = np.linalg.solve(S, y - self.mean(x))
+        mean = lambda xs: self.mean(xs) + self.k(xs, x) @ a
+        k = lambda p, q: self.k(p, q) - self.k(p, x) @ np.linalg.solve(S, self.k(x, q))
+        return Process(mean, k)
+
+    def vfe_bound(self, x, y, noise, z, eps=1e-12):
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        d = np.broadcast_to(noise, y.shape).astype(np.float64)
+        Kzz = self.k(z, z) + eps * np.eye(np.asarray(z).shape[0])
+        Kxz = self.k(x, z)
+        Q = Kxz @ np.linalg.solve(Kzz, Kxz.T)
+        kdiag = np.diag(self.k(x, x))
+        return _mvn_logpdf(Q + np.diag(d), y - self.mean(x)) - 0.5 * np.sum((kdiag - np.diag(Q)) / d)
+
+    def condition_sparse(self, x, y, noise, z, eps=1e-12):
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        d = np.broadcast_to(noise, y.shape).astype(np.float64)
+        Kzz = self.k(z, z) + eps * np.eye(np.asarray(z).shape[0])
+        Kxz = self.k(x, z)
+        Sigma = Kzz + Kxz.T @ (Kxz / d[:, None])
+        b = np.linalg.solve(Sigma, Kxz.T @ ((y - self.mean(x)) / d))
+        mean = lambda xs: self.mean(xs) + self.k(xs, z) @ b
+        k = lambda p, q: (self.k(p, q) - self.k(p, z) @ np.linalg.solve(Kzz, self.k(z, q))
+                          + self.k(p, z) @ np.linalg.solve(Sigma, self.k(z, q)))
+        return Process(mean, k)

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "gpar_hip.h")
 def _declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|size_t)\s+(gpar_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|size_t|long long)\s+(gpar_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_the_expected_surface():
