@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--extras-timeout", type=float, default=600.0,
                     help="seconds the fit + predict / CPU-baseline / teardown part may take before every rank exits (rank 0 prints the line first)")
-    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work the bounded torch-CPU baseline may spend on full-size layers")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work the bounded torch-CPU baseline may spend on full-size layers")
     args = ap.parse_args()
 
     import torch
@@ -329,7 +329,7 @@ def _leaf_spec(spec):
     return leaves, rebuild
 
 
-def cpu_baseline_leg(x_np, y_np, m, p, n_star=2048, num_samples=100, budget_s=25.0):
+def cpu_baseline_leg(x_np, y_np, m, p, n_star=2048, num_samples=100, budget_s=30.0):
     """The reference's CPU path on this box's host cores, restated on the torch-CPU fp64 operators `lab.torch` dispatches
     to (oracle/torch_cpu.py: unfused Gram terms with expanded squared distances, torch.linalg.cholesky,
     solve_triangular; all host threads).  Layers of the SAME full-size workload are evaluated from the last (widest) one
@@ -366,7 +366,7 @@ def cpu_baseline_leg(x_np, y_np, m, p, n_star=2048, num_samples=100, budget_s=25
         spent += sum(stages.values())
         if last is None:
             last = (spec, noise, design, L)
-        if spent >= budget_s:
+        if spent + spent / len(measured) > budget_s:  # the next layer would overrun the budget
             break
     per_layer = spent / len(measured)
     out = {

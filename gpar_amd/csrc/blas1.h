@@ -13,7 +13,7 @@ namespace gpar {
 typedef double b1_d2 __attribute__((ext_vector_type(2)));
 
 constexpr int GEMVT_COLS = 512;    // columns per workgroup (256 threads x 2 adjacent columns: 16-byte loads, 4 KB per row)
-constexpr int GEMVT_ROWS = 128;    // rows per workgroup
+constexpr int GEMVT_ROWS = 512;    // rows per workgroup: n = 65536, M = 1024 -> 2 x 128 workgroups, 128 partial rows to sum
 
 // partial[chunk][j] = sum over the chunk's rows of A[i][j] v[i]; rows are consumed in order, 8 at a time.
 __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* __restrict__ A, int rows, int cols, int lda,
@@ -43,13 +43,26 @@ __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* __res
     }
 }
 
+// out[j] = sum over chunks, in a FIXED order: 64 columns per workgroup (lane = column, coalesced), the chunk range cut into
+// four contiguous quarters (one per wave, eight loads in flight), the four quarter sums added in order.
 __global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const double* __restrict__ partial, int nchunks, int cols,
                                                             double* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cols) return;
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int jc = min(j, cols - 1);
+    const int per = (nchunks + 3) / 4, c0 = min(w * per, nchunks), c1 = min(c0 + per, nchunks);
     double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * cols + j];
-    out[j] = s;
+    for (int c = c0; c < c1; c += 8) {
+        double x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = partial[(size_t)min(c + q, c1 - 1) * cols + jc];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += (c + q < c1) ? x[q] : 0.0;
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && j < cols) out[j] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 static inline int gemv_t_chunks(int rows) { return gpar_ceil_div(rows, GEMVT_ROWS); }
@@ -64,7 +77,7 @@ static int gemv_t_run(const double* A, int rows, int cols, int lda, const double
     const int nchunks = gemv_t_chunks(rows);
     hipLaunchKernelGGL(gemv_t_partial_kernel, dim3(gpar_ceil_div(cols, GEMVT_COLS), nchunks), dim3(256), 0, stream, A, rows,
                        cols, lda, v, workspace);
-    hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3(gpar_ceil_div(cols, 256)), dim3(256), 0, stream, (const double*)workspace,
+    hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3(gpar_ceil_div(cols, 64)), dim3(256), 0, stream, (const double*)workspace,
                        nchunks, cols, out);
     GPAR_LAUNCH_CHECK();
     return 0;

@@ -228,20 +228,46 @@ def test_trmv_lower(env, n):
     np.testing.assert_allclose(got, L @ x[:, 1:2], rtol=1e-12, atol=1e-12 * np.sqrt(n))
 
 
-def test_small_utilities(env):
+def test_reductions(env):
+    """gpar_dot, gpar_gemv_t (A^T v for a tall A), gpar_rownorm2: ragged sizes, padded and unpadded storage."""
     torch, hip, dev, to_dev = env
     rng = np.random.default_rng(5)
     x, y = rng.standard_normal(5000), rng.standard_normal(5000)
     d = hip.dot(to_dev(x), 1, to_dev(y), 1, 5000)
     assert np.isclose(d.item(), x @ y, rtol=1e-12)
-    A = to_dev(rng.standard_normal((40, 40)))
-    v = to_dev(np.zeros(40))
-    hip.copy_strided_(A, A.stride(0) + 1, v, 1, 40)
-    assert np.array_equal(v.cpu().numpy(), np.diag(A.cpu().numpy()))
-    hip.fill_(A, 2.5)
-    assert np.all(A.cpu().numpy() == 2.5)
-    out = hip.logpdf_finalize(to_dev(np.array([3.0])), to_dev(np.array([-4.0])), -1.0, 10)
-    assert np.isclose(out.item(), -0.5 * (3.0 + 10 * np.log(2 * np.pi) + 4.0))
+    for rows, cols, pad in [(1, 1, True), (7, 3, True), (129, 513, True), (1000, 37, False), (2049, 1024, True), (300, 1025, False), (5000, 130, True)]:
+        A = rng.standard_normal((rows, cols))
+        v = rng.standard_normal(rows)
+        scale = np.abs(A).T @ np.abs(v)
+        got = hip.gemv_t(to_dev(A, pad), to_dev(v)).cpu().numpy()
+        assert np.all(np.abs(got - A.T @ v) <= 1e-13 * scale + 1e-300), (rows, cols)
+        again = hip.gemv_t(to_dev(A, pad), to_dev(v)).cpu().numpy()
+        assert np.array_equal(got, again)  # fixed reduction order
+        got = hip.rownorm2(to_dev(A, pad)).cpu().numpy()
+        np.testing.assert_allclose(got, np.sum(A * A, axis=1), rtol=1e-13)
+    from gpar_amd import _lib
+
+    lib = _lib.load()
+    assert lib.gpar_workspace_doubles(_lib.WS_GEMM_SPLITK, 10, 20, 3) == 600
+    assert lib.gpar_workspace_doubles(_lib.WS_GEMV_T, 513, 7, 0) == 2 * 7
+    assert lib.gpar_workspace_doubles(_lib.WS_GRAM_GRAD, 5, 0, 0) == 5 * _lib.GRAD_NACC
+    assert lib.gpar_workspace_doubles(99, 1, 1, 1) == -1
+
+
+def test_sample_stats_propagates_nan_like_numpy(env):
+    """A NaN among an element's samples: np.percentile gives NaN bounds (rank counting mis-ranked instead)."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((20, 6, 2))
+    x[3, 2, 1] = np.nan
+    x[7, 4, 0] = np.inf
+    d = torch.tensor(x, dtype=torch.float64, device=dev)
+    mean, lo, hi = hip.sample_stats(d, 2.5, 97.5)
+    with np.errstate(invalid="ignore"):
+        np.testing.assert_array_equal(mean.cpu().numpy(), np.mean(x, axis=0))
+        np.testing.assert_array_equal(lo.cpu().numpy(), np.percentile(x, 2.5, axis=0))
+        np.testing.assert_array_equal(hi.cpu().numpy(), np.percentile(x, 97.5, axis=0))
+    assert np.isnan(lo.cpu().numpy()[2, 1]) and np.isnan(hi.cpu().numpy()[2, 1])
 
 
 def _kernels(m, p_cols):
@@ -289,6 +315,10 @@ def test_gram_matches_oracle(env, m, p_cols, n1, n2):
         got = hip.gram(ck, z1, z2).cpu().numpy()
         ref = ok.gram(spec, x1, x2)
         assert np.allclose(got, ref, rtol=1e-13, atol=1e-14), name
+        # rows scaled in the same pass (the D^-1/2 K_xz of the inducing-point path)
+        rs = rng.uniform(0.5, 3.0, n1)
+        got = hip.gram(ck, z1, z2, row_scale=to_dev(rs)).cpu().numpy()
+        assert np.allclose(got, ref * rs[:, None], rtol=1e-13, atol=1e-14), name
         # symmetric, lower-only, with noise diagonal + jitter
         noise = rng.uniform(0.01, 0.1, n1)
         K = to_dev(np.full((n1, n1), np.nan))
