@@ -105,6 +105,7 @@ CONFIGS = {
     "C1-paper-synthetic": (dict(scale=0.1, linear=True, linear_scale=10.0, nonlinear=True, nonlinear_scale=0.1, noise=0.1, impute=True, replace=False, normalise_y=False), 25, 1, 3, 0.0),
     "C2-shape": (dict(scale=0.5, linear=True, nonlinear=False, noise=0.1), 384, 2, 4, 0.0),
     "C3-shape-markov2": (dict(scale=0.5, linear=True, nonlinear=True, markov=2, noise=0.1), 300, 4, 8, 0.0),
+    "C4-shape-inducing": (dict(scale=0.5, linear=True, nonlinear=True, noise=0.1, x_ind=np.random.default_rng(8).uniform(0, 1, (64, 8))), 500, 8, 4, 0.0),
     "C5-shape-per-rq": (dict(scale=0.5, per=True, rq=True, linear=True, nonlinear=True, noise=0.1), 200, 3, 5, 0.0),
     "missing-impute": (dict(scale=0.5, linear=True, nonlinear=True, noise=0.1, impute=True), 257, 2, 3, 0.2),
     "replace": (dict(scale=0.5, linear=True, nonlinear=True, noise=0.1, impute=True, replace=True), 190, 2, 3, 0.1),
