@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <utility>
+#include <vector>
 
 #include "../../include/gpar_hip.h"
 
@@ -27,6 +29,20 @@ static inline int gpar_hip_status(hipError_t e) { return e == hipSuccess ? 0 : -
 #define GPAR_HIP_IGNORE(call) ((void)(call))
 
 #define GPAR_ARG_ERROR(code) (-1000 - (code))
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device) - a
+// process may drive several GPUs (callers hold the library mutex).
+static inline hipError_t gpar_set_max_lds(const void* fn, int bytes) {
+    static std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    for (const auto& d : done)
+        if (d.first == fn && d.second == dev) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.emplace_back(fn, dev);
+    return e;
+}
 
 static inline int gpar_ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -457,17 +457,11 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     p.ksplit = 0;
     p.part_stride = 0;
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
-    static bool attr_done = false;
-    if (!attr_done) {
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    for (const void* fn : {reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>),
+                           reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>),
+                           reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0, 64>),
+                           reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1, 64>)})
+        GPAR_HIP_TRY(gpar_set_max_lds(fn, 160 * 1024));
     // half tiles (two workgroups per 128 x 128 tile) while a launch has fewer tiles than the chip has compute units
     static int half_tiles = -1;
     if (half_tiles < 0) { const char* e = getenv("GPAR_GEMM_HALF_TILES"); half_tiles = e ? atoi(e) : 256; }
@@ -525,14 +519,9 @@ static int gemm_splitk_launch(int ta, int tb, int m, int n, int k, double alpha,
     p.part_stride = (long long)m * n;
     const int nsl = gpar_ceil_div(k, len);
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
-    static bool attr_done = false;
-    if (!attr_done) {
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    for (const void* fn : {reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>),
+                           reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>)})
+        GPAR_HIP_TRY(gpar_set_max_lds(fn, 160 * 1024));
     dim3 grid(ntiles, nsl), block(256);
     if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, GEMM_LDS_BYTES, stream, p);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, GEMM_LDS_BYTES, stream, p);

@@ -5,6 +5,7 @@
 #include "gemm_f64.h"
 #include "potrf.h"
 #include "panel.h"
+#include "panel2.h"
 #include "gram.h"
 #include "blas1.h"
 
@@ -225,11 +226,7 @@ static int gram_grad_launch(const gpar_kspec_t* ks, const double* z1, const doub
         }
     }
     const size_t lds = ((size_t)4 * (dz > 0 ? dz : 1) * GRAM_LD + 4 * GRAD_NACC) * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&gram_grad_kernel), 160 * 1024));
     if (lds > 160 * 1024) return GPAR_ARG_ERROR(7);
     hipLaunchKernelGGL(gram_grad_kernel, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, *ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2,
                        dz, W, ldw, mode, workspace);

@@ -204,7 +204,9 @@ __device__ __forceinline__ void pnl_diag(double* __restrict__ T, int col0, const
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
         } else if (jb > 0) {
+#ifndef GPAR_EXPERIMENT_NO_DIAG_HELPERS
             pnl_rank8(T, T, jb - 1, i, 8 * jb + 8 + (w - 1), 3);
+#endif
         }
         __syncthreads();
     }
@@ -390,16 +392,17 @@ __global__ __launch_bounds__(256, 2) void potrf_panel_kernel(PanelArgs p) {
 
 // Number of workgroups that can be co-resident (1 per CU at this LDS size): queried once.
 static int panel_grid_cap() {
-    static int cap = -1;
-    if (cap < 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cap = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 64;
-        if (cap < 1) cap = 1;
+    static int caps[64];   // per device; 0 = not queried yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 64;
+    if (caps[dev] == 0) {
+        int cus = 0;
+        int cap = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 64;
         const char* e = getenv("GPAR_PANEL_GRID");   // experiment knob: fewer, busier panel workgroups
         if (e && atoi(e) > 0 && atoi(e) < cap) cap = atoi(e);
+        caps[dev] = cap;
     }
-    return cap;
+    return caps[dev];
 }
 
 // The flag words of every 64-aligned diagonal block, zeroed in ONE launch at the start of a factorisation: nothing in
@@ -420,11 +423,7 @@ static void potrf_zero_flags(double* A, int N, int lda, hipStream_t stream) {
 static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream,
                              bool prezeroed = false) {
     PanelArgs p{A, N, lda, k0, W / 64, logdet, info, nullptr};
-    static bool attr_done = false;
-    if (!attr_done) {
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS_BYTES));
-        attr_done = true;
-    }
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_panel_kernel), PNL_LDS_BYTES));
     // zero the flag words (S + S^2 of them, 56 per scratch row in the strict upper triangle of the first diagonal
     // block: rows 0..7 have columns 8..63 strictly above the diagonal, which bounds S at 16)
     const int nflags = p.S + p.S * p.S;
@@ -488,11 +487,7 @@ __global__ __launch_bounds__(256) void trsm_block_kernel(TrsmBlockArgs a) {
 
 static int trsm_block_fused(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
                             hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        GPAR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PNL_LDS_BYTES));
-        attr_done = true;
-    }
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&trsm_block_kernel), PNL_LDS_BYTES));
     TrsmBlockArgs a{L, n, ldl, B, nrows, ldb, c0, S, upper_tri};
     hipLaunchKernelGGL(trsm_block_kernel, dim3(gpar_ceil_div(nrows, 64)), dim3(256), PNL_LDS_BYTES, stream, a);
     GPAR_LAUNCH_CHECK();

@@ -1,0 +1,476 @@
+// Panel factorisation and fused triangular-solve blocks, second generation: LEFT-LOOKING row-block tasks on the matrix cores.
+//
+// A W-column panel (W = 64 S) is a 64 S x 64 S diagonal block (S row blocks: the "team") followed by row blocks that only
+// need  X = A21 L11^-T  ("bulk" rows).  One workgroup per 64-row block, block index = row block, so that every wait is
+// on a LOWER-indexed workgroup (the dispatcher launches blocks in index order: whatever is resident can always finish,
+// the grid may be larger than the chip, and several of these kernels can be in flight from different streams).
+//
+// Row block rb, for every column block c (64 columns) it has to solve:
+//     acc  = sum_{u<c} X[rb][u] L[c][u]^T         one K = 64 chunk per u on v_mfma_f64_16x16x4, operands through LDS, the
+//                                                 next chunk's two tiles in flight in registers; C never leaves registers
+//     T    = A[rb][c] - acc
+//     X    = T L[c][c]^-T                         "strip": again on the matrix cores (see p2_strip)
+// and a team row block (rb < S) keeps  D = sum_u X[rb][u] X[rb][u]^T  in registers, factors  A[rb][rb] - D  (pnl_diag) and
+// publishes L[rb][rb].  The first version of the fused panel kernel (panel.h) updated A[rb][c] right-looking, one
+// read-modify-write of a 64 x 64 tile in global memory per K = 64, and solved strips by substitution on the vector ALUs
+// (19.5 k cycles per 64 x 64 strip, one wave doing the serial part): both the hand-off chain (60-65 k cycles per 64
+// columns) and the bulk work per row block (~480 k cycles per 512-column panel) ran at ~10 % of the matrix-core rate.
+//
+// Data layout in registers ("T layout"): wave w owns rows 16 w .. 16 w + 15 of the row block and all 64 columns of the
+// column block, as four TRANSPOSED 16 x 16 tiles: register v of tile mi in lane l holds element
+//     (column 16 mi + (l >> 4) + 4 v,  row 16 w + (l & 15)).
+// This is the D layout of v_mfma_f64_16x16x4 for the product  L[c][u] X^T  (M = columns, N = rows) - and, because D's
+// register v holds rows 4 v .. 4 v + 3 of the tile, register k4 of a tile IS the B operand of K-step k4 of the next
+// product: the strip's chain  X_jb^T = W_jb T_jb,  T_jb' -= L[jb'][jb] X_jb^T  runs from accumulators to operands with
+// no shuffle, no LDS round trip and no barrier (each wave solves its own 16 rows).
+//
+// Strip arithmetic: the 64 x 64 triangle L[c][c] is used in 16 x 16 blocks; off-diagonal blocks enter as plain products
+// (substitution), the four diagonal 16 x 16 blocks through their explicit inverses W_jb (four waves, one block each, 136
+// fused multiply-adds per lane: in the factorisation once per diagonal tile by its owner, which publishes them in four
+// strictly upper 16 x 16 blocks of the tile - scratch by the ABI's convention; in a triangular solve once per strip).  Those blocks are diagonal blocks of a Cholesky factor
+// of K + noise: their condition number is the square root of that of a 16 x 16 principal block of the Schur complement.
+#pragma once
+#include "common.h"
+#include "panel.h"
+
+namespace gpar {
+
+constexpr int P2_LDS_BYTES = 2 * PNL_TILE * 8 + 1024;   // operand tile (L) + row-block tile (X / A) + progress cache, reciprocals
+
+// ---- tile movement: 64 x 64 doubles, 256 threads, 8 x 16 bytes per thread, coalesced ---------------------------------
+// (The thread index is passed through an empty volatile asm in each of these: otherwise the compiler hoists the eight
+// 64-bit row addresses of every tile kind out of the column loop - loop invariants - and, out of registers, spills them;
+// the reloads then sit in front of the stores on the hand-off chain.  Recomputing them is a dozen integer instructions.)
+__device__ __forceinline__ int p2_opaque(int t) {
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+__device__ __forceinline__ void p2_gload(const double* __restrict__ M, int ld, int nrows, int r0, int c0, int t, pan_d2 (&v)[8]) {
+    t = p2_opaque(t);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = t + 256 * q;
+        const int r = c >> 5, cc = (c & 31) * 2;
+        const int rr = min(r0 + r, nrows - 1);   // clamped, never behind a branch
+        v[q] = *reinterpret_cast<const pan_d2*>(M + (size_t)rr * ld + c0 + cc);
+    }
+}
+
+__device__ __forceinline__ void p2_sstore(double* __restrict__ dst, int t, const pan_d2 (&v)[8]) {
+    t = p2_opaque(t);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = t + 256 * q;
+        const int r = c >> 5, cc = (c & 31) * 2;
+        *reinterpret_cast<pan_d2*>(dst + r * PNL_LD + cc) = v[q];
+    }
+}
+
+// LDS tile -> global, rows beyond nrows skipped; `through`: write-through (sc1) stores for tiles other workgroups read.
+__device__ __forceinline__ void p2_gstore(double* __restrict__ M, int ld, int nrows, int r0, int c0, const double* __restrict__ src,
+                                          int t, bool through) {
+    t = p2_opaque(t);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = t + 256 * q;
+        const int r = c >> 5, cc = (c & 31) * 2;
+        if (r0 + r < nrows) {
+            const pan_d2 v = *reinterpret_cast<const pan_d2*>(src + r * PNL_LD + cc);
+            double* dst = M + (size_t)(r0 + r) * ld + c0 + cc;
+            if (through) {
+                // one 16-byte write-through store (an 8-byte sc1 store costs a fabric write of its own: 2.7x per byte)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+            } else {
+                *reinterpret_cast<pan_d2*>(dst) = v;
+            }
+        }
+    }
+}
+
+// ---- one K = 64 chunk:  acc[mi] (column tile mi x this wave's 16 rows) += L[.][k] X[.][k]^T --------------------------
+// The operand fragments of K-step k4 + 1 are requested from LDS before the four products of step k4 are issued (two
+// register sets, the loop fully unrolled): with one wave per SIMD nothing else covers the LDS latency, and reads issued
+// right before the products that need them left the matrix core idle a third of the time (110 instead of 64 cycles per
+// v_mfma_f64_16x16x4: tools/time_panel2.hip).
+__device__ __forceinline__ void p2_frag(const double* __restrict__ Ls, const double* __restrict__ Xs, int w, int l15, int kk,
+                                        double (&a)[4], double& b) {
+    b = Xs[(16 * w + l15) * PNL_LD + kk];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) a[mi] = Ls[(16 * mi + l15) * PNL_LD + kk];
+}
+
+__device__ __forceinline__ void p2_chunk(const double* __restrict__ Ls, const double* __restrict__ Xs, pan_d4 (&acc)[4], int w,
+                                         int l15, int lk) {
+    double a0[4], a1[4], b0, b1;
+    p2_frag(Ls, Xs, w, l15, lk, a0, b0);
+    // (scheduling barriers: left alone, the compiler sinks every read to just before its product)
+#pragma unroll
+    for (int k4 = 0; k4 < 16; k4 += 2) {
+        p2_frag(Ls, Xs, w, l15, 4 * (k4 + 1) + lk, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[mi], b0, acc[mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k4 + 2 < 16) p2_frag(Ls, Xs, w, l15, 4 * (k4 + 2) + lk, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[mi], b1, acc[mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Position of W_jb (inverse of the jb-th diagonal 16 x 16 block) inside the strictly upper 16 x 16 blocks of the LDS tile.
+__device__ __forceinline__ int p2_wblock(int jb) {
+    // jb: 0 -> block (0, 2), 1 -> (0, 3), 2 -> (1, 2), 3 -> (1, 3): columns >= 32, clear of the progress words that the
+    // panel's first diagonal block keeps in its row 0 (columns 8 .. 23)
+    return 16 * (jb >> 1) * PNL_LD + 16 * (2 + (jb & 1));
+}
+
+// Wave w inverts the w-th diagonal 16 x 16 block  [La 0; Lba Lb]  of the lower-triangular tile Cs into the 16 x 16 block
+// W at p2_wblock(w):  W = [Wa 0; -Wb Lba Wa, Wb].
+//   (1) the two 8 x 8 inverses by substitution on 16 lanes (lane = 8 h + j solves L_h x = e_j; all 36 coefficients of its
+//       triangle requested up front, reciprocal pivots by v_rcp_f64 + two Newton steps);
+//   (2) the coupling block on the matrix cores: P = Lba Wa, then -Wb P - four v_mfma_f64_16x16x4 with zero padding, the
+//       result going from the accumulators of the first product straight into the B operand of the second.
+// A 16-step substitution on the vector ALUs needs 120 wave-uniform LDS reads per wave (every one a full LDS instruction):
+// 2 us with four waves at it, on the critical chain of every 64 columns; this form takes a quarter of that.
+__device__ __forceinline__ void p2_inverse_blocks(double* __restrict__ Cs, int w, int lane) {
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int base = 16 * w;
+    double* W = Cs + p2_wblock(w);
+    {
+        const int h = l15 >> 3, j = l15 & 7, b8 = base + 8 * h;
+        double c[8][8];   // c[i][k], k < i: strictly lower coefficients; c[i][i]: pivots
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int k = 0; k <= i; ++k) c[i][k] = Cs[(b8 + i) * PNL_LD + b8 + k];
+        double x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double d = c[k][k];
+            double r = __builtin_amdgcn_rcp(d);
+            r = fma(fma(-d, r, 1.0), r, r);
+            r = fma(fma(-d, r, 1.0), r, r);
+            const double xk = x[k] * r;
+            x[k] = xk;
+#pragma unroll
+            for (int i = k + 1; i < 8; ++i) x[i] = fma(-c[i][k], xk, x[i]);
+        }
+        // diagonal 8 x 8 blocks of W (zeros above their diagonals included) and the zero upper-right 8 x 8 block
+#pragma unroll
+        for (int i = 0; i < 8; ++i) W[(8 * h + i) * PNL_LD + 8 * h + j] = x[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) W[i * PNL_LD + 8 + (l15 & 7)] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // P = Lba Wa: rows 8 .. 15 (registers 2, 3 of the D layout), columns 0 .. 7
+    pan_d4 P = pan_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k4 = 0; k4 < 2; ++k4) {
+        const int k = 4 * k4 + lk;
+        const double av = Cs[(base + l15) * PNL_LD + base + k];   // L16[m][k], used for m >= 8 only
+        const double bv = W[k * PNL_LD + l15];                    // Wa[k][n], n < 8
+        P = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 >= 8 ? av : 0.0, l15 < 8 ? bv : 0.0, P, 0, 0, 0);
+    }
+    pan_d4 Q = pan_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k4 = 0; k4 < 2; ++k4) {
+        const double av = W[l15 * PNL_LD + 8 + 4 * k4 + lk];      // Wb[m - 8][k - 8] = W[m][8 + ...], m >= 8
+        Q = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 >= 8 ? av : 0.0, P[2 + k4], Q, 0, 0, 0);
+    }
+    if (l15 < 8) {
+        W[(8 + lk) * PNL_LD + l15] = -Q[2];
+        W[(12 + lk) * PNL_LD + l15] = -Q[3];
+    }
+}
+
+// T (this wave's 16 rows x 64 columns, T layout) <- X^T with X L^T = T, L the lower-triangular tile in Cs whose diagonal
+// 16 x 16 blocks have their inverses at p2_wblock().
+__device__ __forceinline__ void p2_strip(const double* __restrict__ Cs, pan_d4 (&T)[4], int l15, int lk) {
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        const double* W = Cs + p2_wblock(jb);
+        pan_d4 x = pan_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(W[l15 * PNL_LD + 4 * k4 + lk], T[jb][k4], x, 0, 0, 0);
+        T[jb] = x;
+#pragma unroll
+        for (int j2 = jb + 1; j2 < 4; ++j2) {
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+                T[j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Cs[(16 * j2 + l15) * PNL_LD + 16 * jb + 4 * k4 + lk], x[k4], T[j2], 0, 0, 0);
+        }
+    }
+}
+
+// Tiles (mi, ni), mi >= ni, of a 64 x 64 lower triangle dealt over the four waves: slot q of wave w.
+//   w0: (0,0) (1,0) (2,0)    w1: (1,1) (2,1) (3,0)    w2: (2,2) (3,1)    w3: (3,3) (3,2)
+__device__ __forceinline__ int p2_dtile_m(int w, int q) { return q == 0 ? w : (w == 0 ? q : (w == 1 ? q + 1 : 3)); }
+__device__ __forceinline__ int p2_dtile_n(int w, int q) { return q == 0 ? w : (w == 0 ? 0 : (w == 1 ? (q == 1 ? 1 : 0) : (w == 2 ? 1 : 2))); }
+
+// ---- progress words: prog[t] = number of column blocks team row t has completed and published (u strips, then the
+// diagonal block: t + 1 means L[t][t] is out).  They live where the first generation kept its flags (pnl_flag).
+__device__ __forceinline__ void p2_publish(const PanelArgs& p, int trow, unsigned long long value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(pnl_flag(p, trow), value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Returns once prog[trow] >= need.  `seen` (LDS) caches the last value read per team row, so a satisfied wait costs one
+// LDS read and one barrier.  All threads call it; the barrier(s) inside also separate the LDS phases around it.
+__device__ __forceinline__ void p2_wait(const PanelArgs& p, unsigned long long* __restrict__ seen, int trow, unsigned long long need) {
+    const bool ok = seen[trow] >= need;
+    __syncthreads();   // everybody has read the cached value before anybody may overwrite it
+    if (ok) return;
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        unsigned long long v;
+        while ((v = __hip_atomic_load(pnl_flag(p, trow), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > PNL_SPIN_LIMIT) {
+                if (p.info) atomicCAS(p.info, 0, -77);
+                v = need;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        seen[trow] = v;
+    }
+    __syncthreads();
+}
+
+// One row block of the panel / of a triangular-solve block.
+//   L (ldl, lrows rows): the triangular factor's tiles, read at rows lr0 + 64 c, columns lc0 + 64 u;
+//   B (ldb, brows rows): the right-hand sides / the panel's own rows, read and overwritten at rows r0, columns bc0 + 64 c.
+// FLAGS: L is being produced by the team workgroups of the same launch (wait on progress words); TEAM: this row block is
+// one of them (row block index trow): publishes its strips, accumulates its diagonal block and factors it.
+template <bool FLAGS, bool TEAM>
+__device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* __restrict__ L, int ldl, int lrows, int lr0, int lc0,
+                                             double* __restrict__ B, int ldb, int brows, int r0, int bc0, int ncol, int ufirst,
+                                             int trow, double* __restrict__ psm) {
+    double* Cs = psm;
+    double* Xs = psm + PNL_TILE;
+    unsigned long long* seen = reinterpret_cast<unsigned long long*>(psm + 2 * PNL_TILE);   // 16 words
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    if (FLAGS) {
+        if (t < 16) seen[t] = 0ull;
+        __syncthreads();
+    }
+    // TEAM: the ten 16 x 16 tiles on and below the diagonal of this row block's diagonal tile, dealt 3 / 3 / 2 / 2 over the
+    // waves; slot q of wave w holds tile (mi, ni) = (p2_dtile_m, p2_dtile_n)
+    pan_d4 dacc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dacc[q] = pan_d4{0.0, 0.0, 0.0, 0.0};
+
+    // dev aid (tools/time_panel2.hip): 100 MHz wall-clock stamps of the first 16 row blocks, normally off
+#define P2_STAMP(col, k)                                                                                              \
+    do {                                                                                                              \
+        if (FLAGS && p.stamps && t == 0 && blockIdx.x < 16)                                                           \
+            p.stamps[((size_t)blockIdx.x * 17 + (col)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime();      \
+    } while (0)
+    for (int c = ufirst; c < ncol; ++c) {
+        P2_STAMP(c, 0);
+        pan_d4 acc[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi] = pan_d4{0.0, 0.0, 0.0, 0.0};
+        pan_d2 xa[8];   // the row block's own tile of column block u (operand of chunk u), finally of column block c itself
+        p2_gload(B, ldb, brows, r0, bc0 + 64 * ufirst, t, xa);
+        if (c > ufirst) {
+            if (FLAGS) p2_wait(p, seen, c, (unsigned long long)c);   // every L[c][u], u < c, is out
+            pan_d2 la[8];
+            p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * ufirst, t, la);
+            for (int u = ufirst; u < c; ++u) {
+                __syncthreads();   // the previous chunk's operand reads are done
+                p2_sstore(Cs, t, la);
+                p2_sstore(Xs, t, xa);
+                __syncthreads();
+                // next chunk's tiles in flight under this chunk's products; after the last chunk the row block's tile of
+                // column block c (what is to be solved) arrives the same way (the L index is clamped: a harmless repeat)
+                p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * min(u + 1, c - 1), t, la);
+                p2_gload(B, ldb, brows, r0, bc0 + 64 * (u + 1), t, xa);
+                __builtin_amdgcn_sched_barrier(0);   // the requests go out before the products, not in the middle of them
+                p2_chunk(Cs, Xs, acc, w, l15, lk);
+            }
+        }
+        __syncthreads();
+        P2_STAMP(c, 1);   // chunks done
+        p2_sstore(Xs, t, xa);
+        __syncthreads();
+        pan_d4 T[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) T[mi][v] = Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] - acc[mi][v];
+        // the triangle to solve against
+        if (FLAGS) p2_wait(p, seen, c, (unsigned long long)c + 1);
+        else __syncthreads();
+        P2_STAMP(c, 2);   // triangle available
+        {
+            pan_d2 lt[8];
+            p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * c, t, lt);
+            p2_sstore(Cs, t, lt);
+        }
+        __syncthreads();
+        if (!FLAGS) {   // a team workgroup publishes the inverses with its diagonal tile (they arrived with the load above)
+            p2_inverse_blocks(Cs, w, lane);
+            __syncthreads();
+        }
+        P2_STAMP(c, 3);   // triangle in LDS
+        p2_strip(Cs, T, l15, lk);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] = T[mi][v];
+        __syncthreads();
+        P2_STAMP(c, 4);   // strip done
+        p2_gstore(B, ldb, brows, r0, bc0 + 64 * c, Xs, t, TEAM);
+        if (TEAM) {
+            // D += X X^T for the tiles on and below the diagonal of this row block's diagonal tile
+            const double* xa0 = Xs + (16 * p2_dtile_m(w, 0) + l15) * PNL_LD + lk;
+            const double* xa1 = Xs + (16 * p2_dtile_m(w, 1) + l15) * PNL_LD + lk;
+            const double* xa2 = Xs + (16 * p2_dtile_m(w, 2) + l15) * PNL_LD + lk;
+            const double* xb0 = Xs + (16 * p2_dtile_n(w, 0) + l15) * PNL_LD + lk;
+            const double* xb1 = Xs + (16 * p2_dtile_n(w, 1) + l15) * PNL_LD + lk;
+            const double* xb2 = Xs + (16 * p2_dtile_n(w, 2) + l15) * PNL_LD + lk;
+            double fa[2][3], fb[2][3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { fa[0][q] = (q == 0 ? xa0 : q == 1 ? xa1 : xa2)[0]; fb[0][q] = (q == 0 ? xb0 : q == 1 ? xb1 : xb2)[0]; }
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4) {
+                const int cur = k4 & 1, nxt = cur ^ 1;
+                if (k4 + 1 < 16) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        fa[nxt][q] = (q == 0 ? xa0 : q == 1 ? xa1 : xa2)[4 * (k4 + 1)];
+                        fb[nxt][q] = (q == 0 ? xb0 : q == 1 ? xb1 : xb2)[4 * (k4 + 1)];
+                    }
+                }
+                dacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][0], fb[cur][0], dacc[0], 0, 0, 0);
+                dacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][1], fb[cur][1], dacc[1], 0, 0, 0);
+                if (w < 2) dacc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][2], fb[cur][2], dacc[2], 0, 0, 0);
+            }
+            P2_STAMP(c, 5);   // diagonal-tile accumulation done
+            // The diagonal tile is requested now, behind the write-through stores of X: memory operations return in order, so it
+            // arrives with their acknowledgement, which the publication has to wait for anyway (requested before the stores it
+            // would hold 32 registers through the accumulation; requested after the publication it costs a round trip).
+            const bool last = c == ncol - 1;
+            pan_d2 dt[8];
+            if (last) p2_gload(B, ldb, brows, r0, bc0 + 64 * trow, t, dt);
+            p2_publish(p, trow, (unsigned long long)c + 1);
+            if (last) p2_sstore(Cs, t, dt);   // parked in Cs: the triangle is dead, every wave is past the barrier above
+            P2_STAMP(c, 6);   // published
+        }
+    }
+    if (TEAM) {
+        __syncthreads();
+        P2_STAMP(trow, 0);
+        if (ncol == 0) {   // (otherwise the tile was requested under the last accumulation and is in Cs)
+            pan_d2 dt[8];
+            p2_gload(B, ldb, brows, r0, bc0 + 64 * trow, t, dt);
+            p2_sstore(Cs, t, dt);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (q < 2 || w < 2) {
+                const int mi = p2_dtile_m(w, q), ni = p2_dtile_n(w, q);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Cs[(16 * mi + lk + 4 * v) * PNL_LD + 16 * ni + l15] -= dacc[q][v];
+            }
+        __syncthreads();
+        P2_STAMP(trow, 1);   // diagonal tile assembled
+        pnl_diag(Cs, r0, p, t);
+        __syncthreads();
+        P2_STAMP(trow, 2);   // factored
+        p2_inverse_blocks(Cs, w, lane);   // into four strictly upper 16 x 16 blocks of the tile (scratch by the ABI's convention)
+        __syncthreads();
+        {   // the lower triangle in 16-byte write-through stores (the pair that holds the diagonal element of an even row also
+            // writes its right-hand neighbour: scratch - the progress words sit in row 0 from column 8 on, the inverses from
+            // column 32 on in rows 0 .. 31)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = t + 256 * q;
+                const int r = e >> 5, cc = (e & 31) * 2;
+                if (cc <= r && r0 + r < brows) {
+                    const pan_d2 v = *reinterpret_cast<const pan_d2*>(Cs + r * PNL_LD + cc);
+                    double* dst = B + (size_t)(r0 + r) * ldb + bc0 + 64 * trow + cc;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+                }
+            }
+        }
+        {   // the four inverse blocks: 1024 doubles, two 16-byte write-through stores per thread
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = t + 256 * q;                  // 512 pairs
+                const int jb = e >> 7, i = (e >> 3) & 15, jj = (e & 7) * 2;
+                const int off = p2_wblock(jb) + i * PNL_LD + jj;
+                const pan_d2 v = *reinterpret_cast<const pan_d2*>(Cs + off);
+                double* dst = B + (size_t)(r0 + (off / PNL_LD)) * ldb + bc0 + 64 * trow + (off % PNL_LD);
+                if (r0 + (off / PNL_LD) < brows) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+            }
+        }
+        P2_STAMP(trow, 3);   // inverses + stores issued
+        p2_publish(p, trow, (unsigned long long)trow + 1);
+        P2_STAMP(trow, 4);   // published
+    }
+#undef P2_STAMP
+}
+
+// launch bounds (256, 2): at most 256 unified registers, so that a wave fits beside a trailing-update wave (see panel.h)
+__global__ __launch_bounds__(256, 2) void potrf_panel2_kernel(PanelArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    const int rb = blockIdx.x;
+    const int r0 = p.k0 + 64 * rb;
+    if (rb < p.S) {
+        __builtin_amdgcn_s_setprio(3);   // the chain: never lose an issue arbitration to bulk work on the same compute unit
+        p2_row_block<true, true>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, rb, 0, rb, psm);
+    } else {
+        p2_row_block<true, false>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, p.S, 0, 0, psm);
+    }
+}
+
+static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream,
+                              bool prezeroed = false) {
+    PanelArgs p{A, N, lda, k0, W / 64, logdet, info, nullptr};
+    if (p.S > PNL_MAX_S) return GPAR_ARG_ERROR(5);
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_panel2_kernel), P2_LDS_BYTES));
+    if (!(prezeroed && potrf_flags_prezeroed(N, k0)))
+        GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)k0 * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream));
+    const int R = (N - k0 + 63) / 64;
+    hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R), dim3(256), P2_LDS_BYTES, stream, p);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused block of the forward triangular solve  X L^T = B  (gpar_trsm_rlt): one workgroup per 64-row block of B carries
+// it through the S column blocks [c0, c0 + 64 S) - the same left-looking row-block task, without hand-offs.
+__global__ __launch_bounds__(256, 2) void trsm_block2_kernel(TrsmBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    const int r0 = 64 * blockIdx.x;
+    // upper_tri: row r has nothing left of column r, so column blocks that end before r0 are still zero - and stay zero
+    int ufirst = 0;
+    if (a.upper_tri) {
+        while (ufirst < a.S && a.c0 + 64 * ufirst + 63 < r0) ++ufirst;
+    }
+    const PanelArgs none{nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
+    p2_row_block<false, false>(none, a.L, a.ldl, a.n, a.c0, a.c0, a.B, a.ldb, a.nrows, r0, a.c0, a.S, ufirst, 0, psm);
+}
+
+static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
+                             hipStream_t stream) {
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&trsm_block2_kernel), P2_LDS_BYTES));
+    TrsmBlockArgs a{L, n, ldl, B, nrows, ldb, c0, S, upper_tri};
+    hipLaunchKernelGGL(trsm_block2_kernel, dim3(gpar_ceil_div(nrows, 64)), dim3(256), P2_LDS_BYTES, stream, a);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace gpar

@@ -358,6 +358,20 @@ static int trsm_block_fused(const double* L, int n, int ldl, double* B, int nrow
 // defined in panel.h (one persistent launch per panel)
 static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed);
 static void potrf_zero_flags(double* A, int N, int lda, hipStream_t stream);
+// second generation (panel2.h): left-looking row-block tasks, strips on the matrix cores.  GPAR_PANEL_V=1 selects the first.
+static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed);
+static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
+                             hipStream_t stream);
+static int env_int(const char* name, int dflt);
+static inline int potrf_panel_any(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed) {
+    return env_int("GPAR_PANEL_V", 2) >= 2 ? potrf_panel_fused2(A, N, lda, k0, W, logdet, info, stream, prezeroed)
+                                           : potrf_panel_fused(A, N, lda, k0, W, logdet, info, stream, prezeroed);
+}
+static inline int trsm_block_any(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
+                                 hipStream_t stream) {
+    return env_int("GPAR_PANEL_V", 2) >= 2 ? trsm_block_fused2(L, n, ldl, B, nrows, ldb, c0, S, upper_tri, stream)
+                                           : trsm_block_fused(L, n, ldl, B, nrows, ldb, c0, S, upper_tri, stream);
+}
 
 struct LookaheadState {
     // one low-priority side stream per caller stream (callers that pipeline independent layers over two or three
@@ -471,12 +485,12 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
                     rc = potrf_gemm_update(c, k0, ks, ks + nbo, stream, 1);
                     prof_end(stream, pb, N - ks, nbo, ks - k0);
                 }
-                if (!rc) rc = potrf_panel_fused(A, N, lda, ks, nbo, logdet, info, stream, prezero);
+                if (!rc) rc = potrf_panel_any(A, N, lda, ks, nbo, logdet, info, stream, prezero);
             }
         } else {
             const int w = kend - k0;
             const bool fused_ok = pol.fused && w % 64 == 0 && w <= 1024 && N - k0 >= 64 && (k0 % 2 == 0) && (lda % 2 == 0) && gpar_aligned16(A);
-            rc = fused_ok ? potrf_panel_fused(A, N, lda, k0, w, logdet, info, stream, prezero)
+            rc = fused_ok ? potrf_panel_any(A, N, lda, k0, w, logdet, info, stream, prezero)
                           : (pol.split ? potrf_panel_split(c, k0, kend, nbo, stream) : potrf_panel(c, k0, kend, nbo, stream));
         }
         knext = kend;
@@ -549,9 +563,9 @@ static int trsm_rlt_run2(const double* L, int n, int ldl, double* B, int nrows, 
             c1 = c0 + 2 * NB;
             const int rows_a = upper_tri ? (nrows < cm ? nrows : cm) : nrows;
             const int rows = upper_tri ? (nrows < c1 ? nrows : c1) : nrows;   // rows beyond rows_a are still zero in block A
-            int rc = trsm_block_fused(L, n, ldl, B, rows_a, ldb, c0, NB / 64, upper_tri, stream);
+            int rc = trsm_block_any(L, n, ldl, B, rows_a, ldb, c0, NB / 64, upper_tri, stream);
             if (!rc) rc = gemm_launch(0, 1, rows_a, NB, NB, -1.0, B + c0, ldb, L + (size_t)cm * ldl + c0, ldl, 1.0, B + cm, ldb, 0, stream);
-            if (!rc) rc = trsm_block_fused(L, n, ldl, B, rows, ldb, cm, NB / 64, upper_tri, stream);
+            if (!rc) rc = trsm_block_any(L, n, ldl, B, rows, ldb, cm, NB / 64, upper_tri, stream);
             if (!rc) rc = gemm_launch(0, 1, rows, n - c1, 2 * NB, -1.0, B + c0, ldb, L + (size_t)c1 * ldl + c0, ldl, 1.0, B + c1, ldb, 0, stream);
             if (rc) return rc;
             continue;
@@ -561,7 +575,7 @@ static int trsm_rlt_run2(const double* L, int n, int ldl, double* B, int nrows, 
         if (fusable && (c1 - c0) > 64 && (c1 - c0) % 64 != 0) c1 = c0 + (c1 - c0) / 64 * 64;
         const int rows = upper_tri ? (nrows < c1 ? nrows : c1) : nrows;
         if (fusable && (c1 - c0) % 64 == 0 && (c1 - c0) > 64) {
-            int rc = trsm_block_fused(L, n, ldl, B, rows, ldb, c0, (c1 - c0) / 64, upper_tri, stream);
+            int rc = trsm_block_any(L, n, ldl, B, rows, ldb, c0, (c1 - c0) / 64, upper_tri, stream);
             if (rc) return rc;
         } else {
             for (int c = c0; c < c1; c += POTRF_NBI) {

@@ -1,0 +1,56 @@
+// Dev aid: wall-clock (100 MHz) stamps along the hand-off chain of the second-generation panel kernel (panel2.h).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/time_panel2.hip -o tools/time_panel2 && tools/time_panel2 [N]
+#include "../gpar_amd/csrc/panel2.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace gpar;
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 4096, lda = N, S = 8;
+    double* A;
+    long long* st;
+    const size_t nst = 16 * 17 * 8;
+    hipMalloc(&A, sizeof(double) * (size_t)N * lda);
+    hipMalloc(&st, 8 * nst);
+    std::vector<double> h((size_t)N * 512, 0.0);
+    for (int r = 0; r < N; ++r)
+        for (int c = 0; c < 512 && c <= r; ++c) h[(size_t)r * 512 + c] = (r == c) ? 600.0 : 0.5 / (1 + (r - c) % 7);
+    PanelArgs p{A, N, lda, 0, S, nullptr, nullptr, st};
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int R = (N + 63) / 64;
+    for (int rep = 0; rep < 3; ++rep) {
+        for (int r = 0; r < N; ++r) hipMemcpyAsync(A + (size_t)r * lda, h.data() + (size_t)r * 512, 512 * 8, hipMemcpyHostToDevice, 0);
+        hipMemsetAsync(A + 8, 0, 56 * 8, 0);
+        hipMemsetAsync(st, 0, 8 * nst, 0);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R), dim3(256), P2_LDS_BYTES, 0, p);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("panel2 kernel, N = %d (R = %d row blocks): %.1f us\n", N, R, ms * 1e3);
+    }
+    std::vector<long long> s(nst);
+    hipMemcpy(s.data(), st, 8 * nst, hipMemcpyDeviceToHost);
+    auto at = [&](int rb, int c, int k) { return s[((size_t)rb * 17 + c) * 8 + k]; };
+    const long long t0 = at(0, 0, 0);
+    auto us = [&](long long v) { return v ? (v - t0) * 0.01 : -1.0; };
+    printf("team row t: per column c < t: start, chunks done, triangle available, in LDS, strip done, D accumulated, published [us since row 0 started]\n");
+    for (int t = 0; t < S; ++t) {
+        for (int c = 0; c < t; ++c)
+            printf("  t=%d c=%d: %7.2f %7.2f %7.2f %7.2f %7.2f %7.2f %7.2f\n", t, c, us(at(t, c, 0)), us(at(t, c, 1)), us(at(t, c, 2)),
+                   us(at(t, c, 3)), us(at(t, c, 4)), us(at(t, c, 5)), us(at(t, c, 6)));
+        printf("  t=%d diag: start %7.2f assembled %7.2f factored %7.2f inverses+stores %7.2f published %7.2f\n", t, us(at(t, t, 0)),
+               us(at(t, t, 1)), us(at(t, t, 2)), us(at(t, t, 3)), us(at(t, t, 4)));
+    }
+    printf("bulk row blocks 8..15: per column c: start, chunks done, triangle available, in LDS, strip done\n");
+    for (int rb = 8; rb < 16 && rb < R; rb += 7)
+        for (int c = 0; c < S; ++c)
+            printf("  rb=%d c=%d: %7.2f %7.2f %7.2f %7.2f %7.2f\n", rb, c, us(at(rb, c, 0)), us(at(rb, c, 1)), us(at(rb, c, 2)), us(at(rb, c, 3)),
+                   us(at(rb, c, 4)));
+    return 0;
+}
