@@ -17,6 +17,7 @@ K_EQ, K_RQ, K_LINEAR = 0, 1, 2
 GRAM_LOWER = 1
 GEMM_C_LOWER = 1
 GEMM_A_LOWER = 2
+POTRF_NO_LOOKAHEAD = 1
 WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE = 1, 2, 3, 4
 GRAD_NACC = GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS
 
@@ -84,6 +85,7 @@ SIGNATURES = {
          _ptr, _ptr],
     ),
     "gpar_potrf": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    "gpar_potrf_ex": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr]),
     "gpar_trsm_rlt": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),
     "gpar_trsm_rln": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),
     "gpar_chol_inverse": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr]),

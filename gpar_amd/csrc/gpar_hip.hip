@@ -255,6 +255,12 @@ int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, voi
     return potrf_run(A, N, nf, lda, logdet, info, (hipStream_t)stream);
 }
 
+int gpar_potrf_ex(double* A, int N, int nf, int lda, double* logdet, int* info, int flags, void* stream) {
+    GPAR_API_GUARD;
+    if (N <= 0 || nf <= 0) return 0;
+    return potrf_run(A, N, nf, lda, logdet, info, (hipStream_t)stream, flags);
+}
+
 int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream) {
     GPAR_API_GUARD;
     return trsm_rlt_run(L, n, ldl, B, nrows, ldb, (hipStream_t)stream);

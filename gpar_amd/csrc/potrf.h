@@ -448,9 +448,12 @@ static void prof_end(hipStream_t s, bool active, int rows, int cols, int kb) {
 // Top level: panels of `nbo` columns; the trailing update of panel k is split into the next panel's columns
 // (look-ahead part, stays on the caller's stream ahead of the next panel factorisation) and the rest (on a
 // low-priority side stream), so the serial diag/strip chain of panel k+1 runs under the big SYRK of panel k.
-static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* info, hipStream_t stream) {
+static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* info, hipStream_t stream, int flags = 0) {
     if (nf > N) return GPAR_ARG_ERROR(1);
-    const PotrfPolicy pol = potrf_policy(N);
+    PotrfPolicy pol = potrf_policy(N);
+    // the caller runs several factorisations at once (three or more layer streams): each one's look-ahead side stream would
+    // add a queue to an already over-subscribed chip (C5, three streams at n = 8192: 78 -> 72 ms per evaluation without)
+    if ((flags & GPAR_POTRF_NO_LOOKAHEAD) && !getenv("GPAR_POTRF_LOOKAHEAD")) pol.lookahead = 0;
     PotrfCtx c{A, N, lda, logdet, info, pol.nbm};
     const int nbo = pol.nbo;
     hipStream_t side = (pol.lookahead && nf > nbo && la_init()) ? la_side(stream) : nullptr;

@@ -86,7 +86,8 @@ class HipEngine:
         return hip.gram_diag(ck, z)
 
     def potrf_(self, A, nf=None):
-        return hip.potrf_(A, nf=nf)
+        # inside a layer pipeline of three or more streams the factorisations overlap one another: no look-ahead stream each
+        return hip.potrf_(A, nf=nf, lookahead=getattr(self._tls, "pipe_depth", 0) < 3)
 
     def trsm_rlt_(self, L, B):
         return hip.trsm_rlt_(L, B)
@@ -182,7 +183,9 @@ class HipEngine:
         """Streams for layers that do not depend on one another (complete data, no `replace`, no inducing points):
         the tail of a blocked factorisation is a latency-bound chain of small panels that leaves most of the chip
         idle, the front of the next one is throughput-bound - on alternating streams the two overlap.  `rows` (the
-        problem size) picks the default depth: three streams pay while a factorisation is mostly latency-bound
+        problem size) picks the default depth: four streams below 9216 rows (with GPU_MAX_HW_QUEUES = 8, see the package
+        __init__: C2 5.35 -> 4.85 ms, C5 75 -> 70.5 ms against three), two above; round-1 measurements, taken with the
+        runtime's default of four hardware queues, when a fourth stream silently shared a queue: three streams paid while a factorisation is mostly latency-bound
         (measured per 8-layer evaluation with 2 / 3 / 4 streams: n = 2048 6.0 / 4.9 / 6.3 ms, n = 4096 12.5 / 10.3 / 12.9,
         n = 6144 22.6 / 22.2 / 25.8; at n = 8192 it depends on the kernel - 16 layers of the C3 kernel 77.4 / 81.1 / 86.6 ms,
         of C5's periodic + RQ kernel, whose Gram build is heavier, 82.1 / 79.5 - and the named config decides; C3 at 16384
@@ -192,7 +195,7 @@ class HipEngine:
         if env is not None and int(env) < 2:
             return None
         if depth is None:
-            depth = int(env) if env is not None else (3 if rows is not None and rows < 9216 else 2)
+            depth = int(env) if env is not None else (4 if rows is not None and rows < 9216 else 2)
         if depth < 2:
             return None
         return _LayerPipeline(self, _device_streams(self.device, depth))
@@ -268,6 +271,7 @@ class _LayerPipeline:
     that stage's stream (torch's caching allocator is stream-aware) and may be used by the caller after `join()`."""
 
     def __init__(self, engine, streams):
+        self.engine = engine
         self.main = torch.cuda.current_stream(engine.device)
         self.streams = streams
         self.keep = []
@@ -280,8 +284,14 @@ class _LayerPipeline:
         self.keep.extend(inputs)
         if s not in self.used:
             self.used.append(s)
-        with torch.cuda.stream(s):
-            yield
+        tls = self.engine._tls
+        outer = getattr(tls, "pipe_depth", 0)
+        tls.pipe_depth = len(self.streams)
+        try:
+            with torch.cuda.stream(s):
+                yield
+        finally:
+            tls.pipe_depth = outer
 
     def keep_alive(self, *tensors):
         self.keep.extend(tensors)

@@ -96,7 +96,8 @@ class _Factor:
             shift = fill(A[:n, :n])
             rhs = rhs.reshape(-1)
             A[n, :n] = rhs if shift is None else rhs - shift.reshape(-1)
-        A[n, n] = 0.0
+        A[n, n].zero_()  # (NOT `A[n, n] = 0.0`: a Python scalar assigned by index goes through a CPU tensor, a synchronous
+        #                   host-to-device copy queued behind everything on the stream - one hidden host sync per layer)
         if n > 0:
             logdet, info = eng.potrf_(A, nf=n)
             eng.check_info(info)
@@ -576,14 +577,15 @@ class Obs:
                     with (pipe.stage(k, B, zr, out, zs, noise_vec, means) if pipe is not None else contextlib.nullcontext()):
                         cov = eng.new_matrix(ns, ns)
                         eng.gram(ck, zs, lower=True, diag_add=noise_vec, diag_const=eng.epsilon, out=cov)
-                        mean = 0.0
+                        mean = None
                         if n > 0:
                             V = B[k * ns : (k + 1) * ns]
                             eng.gemm(V, V, tb=True, alpha=-1.0, beta=1.0, out=cov, c_lower=True)
                             mean = means[k * ns : (k + 1) * ns]
                         _, info = eng.potrf_(cov)
                         eng.check_info(info)
-                        out[:, s0 + k : s0 + k + 1] = eng.trmv_lower(cov, zr[:, s0 + k : s0 + k + 1]) + mean
+                        draw = eng.trmv_lower(cov, zr[:, s0 + k : s0 + k + 1])
+                        out[:, s0 + k : s0 + k + 1] = draw if mean is None else draw + mean
         return out
 
 

@@ -126,9 +126,10 @@ def gram_diag(ck, z):
     return out
 
 
-def potrf_(A, nf=None, logdet=None, info=None):
+def potrf_(A, nf=None, logdet=None, info=None, lookahead=True):
     """In-place (partial) Cholesky of the lower triangle of the square matrix A; returns (logdet, info) device
-    scalars (logdet accumulates, info is sticky: pass fresh zeros)."""
+    scalars (logdet accumulates, info is sticky: pass fresh zeros).  `lookahead=False`: the caller has several
+    factorisations in flight itself (see gpar_potrf_ex)."""
     lib = _lib.load()
     _check_mat(A, "A")
     N = A.shape[0]
@@ -139,8 +140,9 @@ def potrf_(A, nf=None, logdet=None, info=None):
         logdet = torch.zeros(1, dtype=torch.float64, device=A.device)
     if info is None:
         info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    flags = 0 if lookahead else _lib.POTRF_NO_LOOKAHEAD
     _lib.check(
-        lib.gpar_potrf(A.data_ptr(), N, nf, _ld(A), logdet.data_ptr(), info.data_ptr(), stream_ptr(A.device)), "gpar_potrf"
+        lib.gpar_potrf_ex(A.data_ptr(), N, nf, _ld(A), logdet.data_ptr(), info.data_ptr(), flags, stream_ptr(A.device)), "gpar_potrf_ex"
     )
     return logdet, info
 

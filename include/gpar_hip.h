@@ -156,6 +156,10 @@ int gpar_gram_grad_cross(const gpar_kspec_t* ks, const double* z1, const double*
  * workgroups; every spin is bounded and a timeout is reported as info = -77).
  * [matrix.cholesky -> torch.linalg.cholesky (LAPACK dpotrf)] */
 int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, void* stream);
+/* The same with hints.  GPAR_POTRF_NO_LOOKAHEAD: the caller keeps three or more factorisations in flight on streams of its
+ * own (independent layers, gpar/model.py:221-243 run concurrently), so the internal side stream is not used. */
+#define GPAR_POTRF_NO_LOOKAHEAD 1
+int gpar_potrf_ex(double* A, int N, int nf, int lda, double* logdet, int* info, int flags, void* stream);
 
 /* B <- B L^-T  (right side, lower, transposed: forward substitution on the rows of B; B is nrows x n).
  * [solve_triangular inside matrix.iqf_diag / PosteriorKernel, reached from gpar/model.py:226,264,298] */
