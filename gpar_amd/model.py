@@ -259,12 +259,17 @@ class GPAR:
             return torch.zeros(x.shape[0], 0, dtype=torch.float64, device=x.device)
         return torch.cat(columns, dim=1)
 
-    def sample_many(self, x, w, num_samples, latent=False):
+    def sample_many(self, x, w, num_samples, latent=False, marginal=False):
         """`num_samples` independent ancestral samples (the loop of reference regression.py:559-563), computed layer by
         layer for all samples at once.  While every sample still sees the same design matrix (always at layer 0;
         at every layer when `replace` feeds posterior means forward) one factorisation serves all draws; once the
-        inputs differ per sample, the per-sample cross-covariances are stacked into one triangular solve."""
-        if num_samples == 1:
+        inputs differ per sample, the per-sample cross-covariances are stacked into one triangular solve.
+
+        `marginal` (not in the reference; off by default): within a layer every point is drawn from its own marginal
+        N(mean_j, var_j) instead of the joint law over the n* points.  Per-point predictive statistics (what `predict`
+        reports: means and marginal percentiles) have the same distribution; the joint law of one sample across points
+        does not, so `sample` keeps the joint sampler.  No n* x n* covariance is built or factored."""
+        if num_samples == 1 and not marginal:
             return [self.sample(x, w, latent=latent)]
         eng = get_engine()
         x = eng.tensor(x)
@@ -278,7 +283,14 @@ class GPAR:
         for i, (is_last, model) in enumerate(last(self.layers)):
             f, noise = model()
             obs_noise = None if latent else self._noise_over(noise, w[:, i])
-            draws = f(x, obs_noise).sample(num=S) if shared else f.sample_batch(xs, obs_noise)
+            if marginal:
+                if shared:
+                    mean, var = f.marginal_moments(x, obs_noise)
+                    draws = mean + torch.sqrt(torch.clamp(var + eng.epsilon, min=0.0))[:, None] * eng.randn(ns, S)
+                else:
+                    draws = f.marginal_sample_batch(xs, obs_noise)
+            else:
+                draws = f(x, obs_noise).sample(num=S) if shared else f.sample_batch(xs, obs_noise)
             columns.append(draws)
             if is_last:
                 break

@@ -277,7 +277,7 @@ class GPARRegressor:
             value = value.detach().cpu().numpy()
         return value
 
-    def _sample_device(self, x, w, p, posterior, num_samples, latent, conditioned=None):
+    def _sample_device(self, x, w, p, posterior, num_samples, latent, conditioned=None, marginal=False):
         """The samples of `sample` as engine tensors (n* x p each), output transforms undone."""
         x = _uprank(_to_torch(x))
         if posterior and not self.is_conditioned:
@@ -295,7 +295,8 @@ class GPARRegressor:
             gpar = gpar | (self.x, self.y, self.w)
         else:
             gpar = _construct_gpar(self, self.vs, x.shape[1], p)
-        return [self._untransform_y(self._unnormalise_y(s)).detach() for s in gpar.sample_many(x, w, num_samples, latent=latent)]
+        return [self._untransform_y(self._unnormalise_y(s)).detach()
+                for s in gpar.sample_many(x, w, num_samples, latent=latent, marginal=marginal)]
 
     def sample(self, x, w=None, p=None, posterior=False, num_samples=1, latent=False, _conditioned=None):
         """Draw samples from the prior or the posterior at inputs x; a single ndarray for num_samples=1, otherwise
@@ -304,11 +305,16 @@ class GPARRegressor:
         samples = [s.cpu().numpy() for s in self._sample_device(x, w, p, posterior, num_samples, latent, _conditioned)]
         return samples[0] if num_samples == 1 else samples
 
-    def predict(self, x, w=None, num_samples=100, latent=False, credible_bounds=False):
+    def predict(self, x, w=None, num_samples=100, latent=False, credible_bounds=False, marginal=False):
         """Monte-Carlo predictive mean (and central 95% marginal bounds) from posterior samples
         (reference regression.py:566-597).  The reduction over the sample axis runs on the device
-        (`gpar_sample_stats`: sequential mean, numpy-"linear" percentiles); only the n* x p results cross PCIe."""
-        samples = self._sample_device(x, w, None, True, num_samples, latent)
+        (`gpar_sample_stats`: sequential mean, numpy-"linear" percentiles); only the n* x p results cross PCIe.
+
+        `marginal=True` (an addition, off by default; reference todo.tasks:5): the statistics returned here only involve
+        per-point marginals, so within each layer the points may be drawn from their marginals N(mean_j, var_j)
+        instead of jointly - same distribution of every returned number, no n* x n* covariance, SYRK downdate or
+        factorisation per sample (`GPAR.sample_many`)."""
+        samples = self._sample_device(x, w, None, True, num_samples, latent, marginal=marginal)
         if num_samples == 1:
             # the reference hands np.mean a single (n*, p) array here, so axis 0 is the input axis; keep that
             samples = samples[0].cpu().numpy()

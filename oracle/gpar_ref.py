@@ -3,7 +3,7 @@
 Restates the orchestration of /root/reference/gpar/model.py:178-243 (`GPAR.logpdf`), :279-322 (`_obs`,
 `_update_inputs`), :325-362 (`per_output`) and the per-layer kernel of /root/reference/gpar/regression.py:92-180
 directly from a `{name: value}` dictionary of hyper-parameters (the dictionary `GPARRegressor.get_variables()`
-returns), without importing anything from the product.  Dense (no inducing points) path only.
+returns), without importing anything from the product.  Dense and inducing-point (VFE) paths.
 """
 import numpy as np
 
@@ -54,12 +54,19 @@ def layer_spec(hypers, m, pi, config):
     return {"terms": terms}, float(g(f"{pi}/noise"))
 
 
-def gpar_logpdf(x, y, w, hypers, config, impute=False, replace=False, eps=1e-12):
-    """Sum over layers of log N(y_i; 0, K_i([x, y_<i]) + noise_i / w_i) with the reference's missing-data rules."""
+def gpar_logpdf(x, y, w, hypers, config, impute=False, replace=False, eps=1e-12, x_ind=None):
+    """Sum over layers of log N(y_i; 0, K_i([x, y_<i]) + noise_i / w_i) - with `x_ind`, of the VFE bounds - with the
+    reference's missing-data rules (model.py:178-243, 279-322): rows kept per layer (`per_output`), observations filtered
+    (`_obs`), the next input column = observed values, imputed / replaced by posterior means (`_update_inputs`), and the
+    inducing inputs extended by the posterior mean at the inducing inputs."""
     x = np.asarray(x, dtype=np.float64)
     x = x[:, None] if x.ndim == 1 else x
     y = np.asarray(y, dtype=np.float64)
     w = np.ones_like(y) if w is None else np.asarray(w, dtype=np.float64)
+    sparse = x_ind is not None
+    if sparse:
+        x_ind = np.asarray(x_ind, dtype=np.float64)
+        x_ind = x_ind[:, None] if x_ind.ndim == 1 else x_ind
     m, p = x.shape[1], y.shape[1]
     available = ~np.isnan(y)
     total = 0.0
@@ -71,14 +78,25 @@ def gpar_logpdf(x, y, w, hypers, config, impute=False, replace=False, eps=1e-12)
         y, w, available = y[mask], w[mask], available[mask]
         spec, noise = layer_spec(hypers, m, i, config)
         have = ~np.isnan(yi)
-        total += gp_ref.logpdf(spec, x[have], yi[have], noise / wi[have], eps=eps)
+        if sparse:
+            total += gp_ref.vfe_bound(spec, x[have], yi[have], noise / wi[have], x_ind, eps=eps)
+        else:
+            total += gp_ref.logpdf(spec, x[have], yi[have], noise / wi[have], eps=eps)
         if i < p - 1:
+
+            def estimate(points):
+                if sparse:
+                    return gp_ref.vfe_posterior(spec, x[have], yi[have], noise / wi[have], x_ind, points, eps=eps)[0]
+                return gp_ref.posterior(spec, x[have], yi[have], noise / wi[have], points, eps=eps)[0]
+
             col = yi.copy()
             if (impute and (~have).any()) or (replace and have.any()):
-                mean, _ = gp_ref.posterior(spec, x[have], yi[have], noise / wi[have], x, eps=eps)
+                mean = estimate(x)
                 if impute:
                     col[~have] = mean[~have]
                 if replace:
                     col[have] = mean[have]
+            if sparse:
+                x_ind = np.concatenate([x_ind, estimate(x_ind)[:, None]], axis=1)
             x = np.concatenate([x, col[:, None]], axis=1)
     return total

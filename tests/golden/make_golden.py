@@ -62,6 +62,40 @@ CASES = [
     ("replace", dict(n=15, m=1, p=3, config=dict(linear=True, nonlinear=True), impute=True, replace=True, missing=0.15, weights=False)),
 ]
 
+# Shapes of the reference's example workloads (synthetic stand-ins: the datasets are downloaded at run time there):
+#   air_temp.py:18,27-46   inducing points on an even grid, replace + impute, B.epsilon = 1e-6, D-GPAR-L-NL
+#   eeg.py:21-30           a block of the last outputs missing on the last rows, nonlinear only, noise 0.01
+#   exchange.py:21-32      RQ kernels, linear + nonlinear, three outputs with missing blocks in the middle
+WORKLOADS = [
+    ("air-temp-shape", dict(n=30, p=3, x_ind=9, epsilon=1e-6, impute=True, replace=True, pattern="scattered",
+                            config=dict(linear=True, nonlinear=True))),
+    ("eeg-shape", dict(n=28, p=4, x_ind=None, epsilon=1e-12, impute=True, replace=False, pattern="tail-block",
+                       config=dict(linear=False, nonlinear=True))),
+    ("exchange-shape", dict(n=26, p=3, x_ind=None, epsilon=1e-12, impute=True, replace=False, pattern="middle-blocks",
+                            config=dict(linear=True, nonlinear=True, rq=True))),
+]
+
+
+def workload_case(name, c, rng):
+    n, p = c["n"], c["p"]
+    x = np.sort(rng.uniform(0.0, 1.0, n))
+    base = np.stack([np.sin(5 * x + k) + 0.3 * k * x for k in range(p)], axis=1)
+    y = base + 0.1 * rng.standard_normal((n, p))
+    if c["pattern"] == "scattered":
+        y[rng.random((n, p)) < 0.2] = np.nan
+        y[0] = base[0]
+    elif c["pattern"] == "tail-block":
+        y[n - 8 :, p - 2 :] = np.nan  # the last two outputs are unobserved on the last rows (eeg.py holds out F1 / F2 / FZ)
+    else:
+        y[8:14, 0] = np.nan
+        y[12:20, 2] = np.nan
+    hypers = hypers_for(1, p, c["config"], rng)
+    x_ind = None if c["x_ind"] is None else np.linspace(0.0, 1.0, c["x_ind"])
+    value = gpar_ref.gpar_logpdf(x, y, None, hypers, c["config"], impute=c["impute"], replace=c["replace"], eps=c["epsilon"], x_ind=x_ind)
+    return {"name": name, "config": c["config"], "impute": c["impute"], "replace": c["replace"], "epsilon": c["epsilon"],
+            "x_ind": None if x_ind is None else x_ind.tolist(), "x": x[:, None].tolist(),
+            "y": [[None if np.isnan(v) else v for v in row] for row in y.tolist()], "w": None, "hypers": hypers, "logpdf": value}
+
 
 def main():
     rng = np.random.default_rng(20260928)
@@ -109,6 +143,10 @@ def main():
         out["vfe"].append({"name": name, "config": config, "hypers": hypers, "x": x.tolist(), "y": y.tolist(), "noise": noise.tolist(),
                            "z": z.tolist(), "xs": xs.tolist(), "bound": gp_ref.vfe_bound(spec, x, y, noise, z),
                            "mean": mean.tolist(), "cov": cov.tolist()})
+    # appended after everything else so that the earlier vectors keep their values (one shared random stream)
+    wl_rng = np.random.default_rng(20260929)
+    for name, c in WORKLOADS:
+        out["gpar_logpdf"].append(workload_case(name, c, wl_rng))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpar_cases.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

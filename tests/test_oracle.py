@@ -244,8 +244,11 @@ def test_golden_vectors_reproduce_and_host_code_agrees(case, oracle_engine):
 
     x, y = np.array(case["x"]), _nan_array(case["y"])
     w = None if case["w"] is None else np.array(case["w"])
-    fresh = gpar_ref.gpar_logpdf(x, y, w, case["hypers"], case["config"], impute=case["impute"], replace=case["replace"])
+    eps, x_ind = case.get("epsilon", 1e-12), case.get("x_ind")
+    fresh = gpar_ref.gpar_logpdf(x, y, w, case["hypers"], case["config"], impute=case["impute"], replace=case["replace"],
+                                 eps=eps, x_ind=None if x_ind is None else np.array(x_ind))
     assert abs(fresh - case["logpdf"]) <= 1e-11 * abs(case["logpdf"])
+    oracle_engine.epsilon = eps  # lab's B.epsilon (examples/paper/air_temp.py:18 sets 1e-6)
     reg = regressor_from_case(case)
     got = float(reg.logpdf(x, y, w))
     assert abs(got - case["logpdf"]) <= 1e-9 * abs(case["logpdf"]), (got, case["logpdf"])
@@ -257,8 +260,9 @@ def regressor_from_case(case):
     get-or-create semantics)."""
     from gpar_amd.regression import GPARRegressor
 
-    reg = GPARRegressor(replace=case["replace"], impute=case["impute"], normalise_y=False, **{
-        k: v for k, v in case["config"].items()})
+    x_ind = case.get("x_ind")
+    reg = GPARRegressor(replace=case["replace"], impute=case["impute"], normalise_y=False,
+                        x_ind=None if x_ind is None else np.array(x_ind), **{k: v for k, v in case["config"].items()})
     for name, value in case["hypers"].items():
         value = np.asarray(value, dtype=np.float64)
         if name.endswith("/input/lin/const"):

@@ -52,8 +52,11 @@ def _on(kind, fn, seed=77):
 def test_golden_gpar_logpdf(case, hip):
     x, y = np.array(case["x"]), _nan_array(case["y"])
     w = None if case["w"] is None else np.array(case["w"])
+    hip.epsilon = case.get("epsilon", 1e-12)  # lab's B.epsilon; the air_temp workload sets 1e-6
     got = float(regressor_from_case(case).logpdf(x, y, w))
-    assert abs(got - case["logpdf"]) <= 1e-10 * abs(case["logpdf"]), (got, case["logpdf"])
+    # inducing-point chains feed posterior means through K_zz^-1 (jitter-conditioned): 1e-8, as the other VFE goldens
+    tol = 1e-10 if case.get("x_ind") is None else 1e-8
+    assert abs(got - case["logpdf"]) <= tol * abs(case["logpdf"]), (got, case["logpdf"])
 
 
 @pytest.mark.parametrize("case", _golden()["single_gp"], ids=lambda c: c["name"])

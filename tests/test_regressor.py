@@ -339,3 +339,45 @@ def test_paper_synthetic_experiment_gpar_beats_independent_gps(engine):
     gpar, igp = out["gpar"]["rmse"], out["independent"]["rmse"]
     assert gpar[1] < 0.75 * igp[1] and gpar[2] < 0.75 * igp[2], (gpar, igp)
     assert out["gpar"]["logpdf"] > out["independent"]["logpdf"]
+
+
+@pytest.mark.parametrize("kw", [dict(replace=False), dict(replace=True), dict(replace=False, x_ind=np.linspace(0, 1, 9))])
+def test_marginal_predict_matches_joint_predict(engine, kw):
+    """`predict(..., marginal=True)`: per-point statistics of draws from the per-layer marginals agree with those of the
+    joint sampler within Monte-Carlo error; the signature keeps the reference's arguments and defaults in front."""
+    rng = np.random.default_rng(7)
+    x = np.linspace(0, 1, 40)
+    y = np.stack([np.sin(6 * x), np.cos(5 * x) + 0.3 * np.sin(6 * x) ** 2], axis=1) + 0.05 * rng.standard_normal((40, 2))
+    xs = np.linspace(0.05, 0.95, 25)
+    reg = GPARRegressor(scale=0.2, linear=True, nonlinear=True, noise=0.05, normalise_y=False, **kw)
+    reg.condition(x, y)
+    S = 400
+    engine.seed(11)
+    mean_j, lo_j, hi_j = reg.predict(xs, num_samples=S, credible_bounds=True)
+    engine.seed(12)
+    mean_m, lo_m, hi_m = reg.predict(xs, num_samples=S, credible_bounds=True, marginal=True)
+    width = np.maximum(hi_j - lo_j, 1e-3)
+    assert np.all(np.abs(mean_m - mean_j) < 0.35 * width)          # ~ 4 sigma / sqrt(S) of a 95 % interval's width
+    assert np.all(np.abs((hi_m - lo_m) - (hi_j - lo_j)) < 0.45 * width)
+    import inspect
+
+    params = list(inspect.signature(GPARRegressor.predict).parameters)
+    assert params[:6] == ["self", "x", "w", "num_samples", "latent", "credible_bounds"] and params[6] == "marginal"
+
+
+@pytest.mark.parametrize("name,size", [("air_temp", dict(n=90, n_ind=16)), ("eeg", dict(n=64, p=5)), ("exchange", dict(n=70, p=4))])
+def test_paper_workload_stand_ins(engine, name, size):
+    """The reference's other example workloads (examples/paper/air_temp.py:27-46, eeg.py:21-33, exchange.py:21-35) on
+    synthetic data of their shape: sparse + replace + impute with epsilon 1e-6; block-missing outputs; RQ kernels.  Fit and
+    predict must run end to end and GPAR must predict the held-out blocks better than independent GPs."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "paper_workloads.py")
+    spec = importlib.util.spec_from_file_location("paper_workloads", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run(name, iters=15, num_samples=30, **size)
+    assert out["gpar"]["finite"] and out["independent"]["finite"]
+    g, i = np.nanmean(out["gpar"]["smse"]), np.nanmean(out["independent"]["smse"])
+    assert g < i, (name, out)
