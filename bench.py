@@ -113,8 +113,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    timing = {}
+
     def step():
-        return sharded_logpdf(gpar, x, y, w)
+        return sharded_logpdf(gpar, x, y, w, timing=timing)
 
     value = None
     for _ in range(args.warmup):
@@ -122,6 +124,7 @@ def main():
     lib.gpar_profile_read(None, None, None, None, 1)
     lib.gpar_profile_enable(1)
     barrier()
+    timing.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         value = step()
@@ -132,10 +135,15 @@ def main():
 
     launches, ms, busy, flops = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     lib.gpar_profile_read(ctypes.byref(launches), ctypes.byref(ms), ctypes.byref(busy), ctypes.byref(flops), 1)
+    busy_ms = [1e3 * timing.get("busy_s", 0.0) / max(args.steps, 1)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor(busy_ms, dtype=torch.float64, device=eng.device)
+        everyone = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        busy_ms = [float(b.item()) for b in everyone]
 
     out = {
         "metric": "logpdf_per_s",
@@ -155,7 +163,10 @@ def main():
                         f"noise=0.1, inputs resident in HBM",
             "parallelism": f"layer-parallel x{world} (layer i on rank i mod {world}; 8-byte all-reduce only)",
             "logpdf": float(value),
+            "layers_per_rank": [len(range(r, p, world)) for r in range(world)],
         },
+        # wall-clock each rank spent on its own layers per step, up to the collective: the slowest one bounds the step
+        "per_rank_busy_ms": busy_ms,
     }
     if launches.value > 0 and busy.value > 0:
         # Independent layers are pipelined over two streams, so two trailing updates (of different layers) are often in

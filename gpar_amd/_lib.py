@@ -18,6 +18,7 @@ GRAM_LOWER = 1
 GEMM_C_LOWER = 1
 GEMM_A_LOWER = 2
 POTRF_NO_LOOKAHEAD = 1
+POTRF_UNFUSED = 2
 WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE = 1, 2, 3, 4
 GRAD_NACC = GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS
 
@@ -100,6 +101,8 @@ SIGNATURES = {
     "gpar_dot": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "gpar_gemv_t": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr]),
     "gpar_rownorm2": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "gpar_pack_lower": (_c_int, [_ptr, _c_int, _c_int, _ptr, _ptr]),
+    "gpar_unpack_lower": (_c_int, [_ptr, _c_int, _ptr, _c_int, _ptr]),
     "gpar_workspace_doubles": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
     "gpar_randn": (_c_int, [_u64, _u64, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "gpar_trmv_lower": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr]),

@@ -117,6 +117,22 @@ __global__ __launch_bounds__(256) void rownorm2_kernel(const double* __restrict_
     if (lane == 0) out[row] = s;
 }
 
+// Lower triangle (diagonal included) of a row-major n x n matrix <-> packed storage, row r at offset r (r + 1) / 2: what one
+// rank sends another when a Cholesky factor travels (half the bytes of the padded square buffer).  One workgroup per row.
+__global__ __launch_bounds__(256) void pack_lower_kernel(const double* __restrict__ A, int n, int lda, double* __restrict__ out) {
+    const int r = blockIdx.x;
+    const double* src = A + (size_t)r * lda;
+    double* dst = out + (size_t)r * (r + 1) / 2;
+    for (int c = threadIdx.x; c <= r; c += 256) dst[c] = src[c];
+}
+
+__global__ __launch_bounds__(256) void unpack_lower_kernel(const double* __restrict__ in, int n, double* __restrict__ A, int lda) {
+    const int r = blockIdx.x;
+    const double* src = in + (size_t)r * (r + 1) / 2;
+    double* dst = A + (size_t)r * lda;
+    for (int c = threadIdx.x; c <= r; c += 256) dst[c] = src[c];
+}
+
 // single-workgroup, fixed-order reduction: deterministic
 __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x, long incx, const double* __restrict__ y,
                                                    long incy, int n, double* __restrict__ out, int accumulate) {

@@ -310,6 +310,24 @@ int gpar_rownorm2(const double* A, int rows, int cols, int lda, double* out, voi
     return 0;
 }
 
+int gpar_pack_lower(const double* A, int n, int lda, double* out, void* stream) {
+    GPAR_API_GUARD;
+    if (n <= 0) return 0;
+    if (!A || !out) return GPAR_ARG_ERROR(2);
+    hipLaunchKernelGGL(pack_lower_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, A, n, lda, out);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_unpack_lower(const double* in, int n, double* A, int lda, void* stream) {
+    GPAR_API_GUARD;
+    if (n <= 0) return 0;
+    if (!A || !in) return GPAR_ARG_ERROR(2);
+    hipLaunchKernelGGL(unpack_lower_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, in, n, A, lda);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
 long long gpar_workspace_doubles(int op, int a, int b, int c) {
     switch (op) {
         case GPAR_WS_GEMM_SPLITK: return (long long)a * b * (c > 1 ? c : 1);           /* m, n, splits */

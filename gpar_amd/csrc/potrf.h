@@ -454,6 +454,12 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // the caller runs several factorisations at once (three or more layer streams): each one's look-ahead side stream would
     // add a queue to an already over-subscribed chip (C5, three streams at n = 8192: 78 -> 72 ms per evaluation without)
     if ((flags & GPAR_POTRF_NO_LOOKAHEAD) && !getenv("GPAR_POTRF_LOOKAHEAD")) pol.lookahead = 0;
+    if (flags & GPAR_POTRF_UNFUSED) {   // the caller's retry after a hand-off timeout: separate leaf kernels, nothing spins
+        pol.fused = 0;
+        pol.lookahead = 0;
+        pol.nbo = N >= 12288 ? 512 : (N >= 6144 ? 256 : (N >= 1536 ? 128 : 64));
+        pol.nbm = pol.nbo >= 512 ? 128 : 64;
+    }
     PotrfCtx c{A, N, lda, logdet, info, pol.nbm};
     const int nbo = pol.nbo;
     hipStream_t side = (pol.lookahead && nf > nbo && la_init()) ? la_side(stream) : nullptr;

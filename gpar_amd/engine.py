@@ -31,7 +31,7 @@ import torch
 from . import _lib, hip
 from .kernels import compile_kernel
 
-__all__ = ["HipEngine", "get_engine", "set_engine", "NotPositiveDefiniteError", "joining"]
+__all__ = ["HipEngine", "get_engine", "set_engine", "NotPositiveDefiniteError", "HandOffTimeoutError", "joining"]
 
 
 class NotPositiveDefiniteError(ArithmeticError):
@@ -40,6 +40,17 @@ class NotPositiveDefiniteError(ArithmeticError):
     def __init__(self, info):
         super().__init__(f"matrix is not positive definite: pivot {info} is not positive")
         self.info = info
+
+
+class HandOffTimeoutError(ArithmeticError):
+    """A workgroup of the persistent panel kernel gave up waiting for a tile from another one (device-side info < 0): the
+    factorisation's results are invalid.  Waits only ever target workgroups dispatched earlier, so this needs an
+    external cause (a hung or pre-empted GPU); callers retry once on the unfused path (`HipEngine.safe_mode`), and the
+    optimiser treats it as a failed evaluation."""
+
+    def __init__(self, code):
+        super().__init__(f"gpar_potrf: device-side hand-off timed out (code {code})")
+        self.code = code
 
 
 class HipEngine:
@@ -53,6 +64,10 @@ class HipEngine:
             )
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.epsilon = float(epsilon)  # lab's B.epsilon: diagonal jitter added before every Cholesky
+        # lab's B.cholesky_retry_factor: a failed Cholesky is retried with the jitter multiplied by 10 while the factor stays
+        # <= this value (default 1: no retry, as in lab).  Retrying needs the verdict of each attempt, i.e. a host sync per
+        # factorisation: layers are then neither pipelined nor checked in one go.
+        self.cholesky_retry_factor = 1.0
         self._seed = int(seed)
         self._calls = 0
         self._tls = threading.local()  # per host thread: pending device-side info words of an open defer_checks() block
@@ -87,7 +102,19 @@ class HipEngine:
 
     def potrf_(self, A, nf=None):
         # inside a layer pipeline of three or more streams the factorisations overlap one another: no look-ahead stream each
-        return hip.potrf_(A, nf=nf, lookahead=getattr(self._tls, "pipe_depth", 0) < 3)
+        safe = getattr(self._tls, "safe", False)
+        return hip.potrf_(A, nf=nf, lookahead=not safe and getattr(self._tls, "pipe_depth", 0) < 3, fused=not safe)
+
+    @contextlib.contextmanager
+    def safe_mode(self):
+        """Factorisations inside use the unfused panel path (separate leaf kernels, nothing waits inside a launch), without
+        look-ahead and without layer pipelining: the retry path after a HandOffTimeoutError."""
+        outer = getattr(self._tls, "safe", False)
+        self._tls.safe = True
+        try:
+            yield
+        finally:
+            self._tls.safe = outer
 
     def trsm_rlt_(self, L, B):
         return hip.trsm_rlt_(L, B)
@@ -108,6 +135,13 @@ class HipEngine:
     def rownorm2(self, A):
         """Squared Euclidean norm of every row of A (vector)."""
         return hip.rownorm2(self._mat(A))
+
+    def pack_lower(self, A, out=None):
+        """Lower triangle of A as n (n + 1) / 2 contiguous doubles (the exchange format of factors between ranks)."""
+        return hip.pack_lower(A, out)
+
+    def unpack_lower_(self, packed, A):
+        return hip.unpack_lower_(packed, A)
 
     def trmv_lower(self, L, x):
         """L x for lower-triangular L and a single column x."""
@@ -192,7 +226,7 @@ class HipEngine:
         208 / 212).  Returns None
         when disabled (GPAR_LAYER_PIPELINE=0 or 1); any other value of the variable fixes the depth."""
         env = os.environ.get("GPAR_LAYER_PIPELINE")
-        if env is not None and int(env) < 2:
+        if (env is not None and int(env) < 2) or getattr(self._tls, "safe", False) or self.cholesky_retry_factor > 1:
             return None
         if depth is None:
             depth = int(env) if env is not None else (4 if rows is not None and rows < 9216 else 2)
@@ -237,7 +271,7 @@ class HipEngine:
     def _raise_for(info):
         code = int(info.item())
         if code < 0:
-            raise RuntimeError(f"gpar_potrf: device-side hand-off timed out (code {code}); is another kernel holding the CUs?")
+            raise HandOffTimeoutError(code)
         if code != 0:
             raise NotPositiveDefiniteError(code)
 

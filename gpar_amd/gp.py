@@ -92,17 +92,20 @@ class _Factor:
     def __init__(self, eng, n, fill, rhs):
         self.eng, self.n = eng, n
         A = eng.new_matrix(n + 1, n + 1)
-        if n > 0:
-            shift = fill(A[:n, :n])
-            rhs = rhs.reshape(-1)
-            A[n, :n] = rhs if shift is None else rhs - shift.reshape(-1)
-        A[n, n].zero_()  # (NOT `A[n, n] = 0.0`: a Python scalar assigned by index goes through a CPU tensor, a synchronous
-        #                   host-to-device copy queued behind everything on the stream - one hidden host sync per layer)
-        if n > 0:
+        logdet = torch.zeros(1, dtype=torch.float64, device=A.device)
+        scale = 1.0
+        while n > 0:
+            shift = fill(A[:n, :n], scale)
+            row = rhs.reshape(-1)
+            A[n, :n] = row if shift is None else row - shift.reshape(-1)
+            A[n, n].zero_()  # (NOT `A[n, n] = 0.0`: a Python scalar assigned by index goes through a CPU tensor, a
+            #                   synchronous host-to-device copy queued behind everything on the stream - a hidden host sync)
             logdet, info = eng.potrf_(A, nf=n)
-            eng.check_info(info)
-        else:
-            logdet = torch.zeros(1, dtype=torch.float64, device=A.device)
+            if not _retrying(eng, info, scale):
+                break
+            scale *= 10.0  # lab's Cholesky retry: jitter x 10 (B.cholesky_retry_factor)
+        if n == 0:
+            A[n, n].zero_()
         self.A = A
         self.L = A[:n, :n]
         self.zrow = A[n : n + 1, :n]  # (L^-1 rhs)^T, 1 x n
@@ -137,6 +140,24 @@ class _Factor:
                 self.eng.trsm_rln_(self.L, a)
             self._alpha = a
         return self._alpha
+
+
+def _retrying(eng, info, scale):
+    """Record / check the verdict of a factorisation.  True: it failed and lab's retry rule (engine.cholesky_retry_factor)
+    allows another attempt with ten times the jitter."""
+    from .engine import NotPositiveDefiniteError
+
+    limit = getattr(eng, "cholesky_retry_factor", 1.0)
+    if limit <= 1.0:
+        eng.check_info(info)  # possibly deferred: no host sync
+        return False
+    try:
+        eng._raise_for(info)  # synchronises: a retry needs the verdict now
+    except NotPositiveDefiniteError:
+        if scale * 10.0 > limit:
+            raise
+        return True
+    return False
 
 
 def _needs_grad(v):
@@ -376,7 +397,7 @@ class FDD:
         y = _as_matrix(eng, y)
         if y.shape[0] != self.n:
             raise ValueError(f"{y.shape[0]} observations for {self.n} inputs")
-        return _Factor(eng, self.n, lambda block: self._fill_cov(block, eng.epsilon), y)
+        return _Factor(eng, self.n, lambda block, scale: self._fill_cov(block, eng.epsilon * scale), y)
 
     def logpdf(self, y):
         return self._factor(y).logpdf()
@@ -388,9 +409,13 @@ class FDD:
         if n == 0:
             return torch.zeros(0, num, dtype=torch.float64, device=self.x.device)
         S = eng.new_matrix(n, n)
-        mean = self._fill_cov(S, eng.epsilon)
-        _, info = eng.potrf_(S)
-        eng.check_info(info)
+        scale = 1.0
+        while True:
+            mean = self._fill_cov(S, eng.epsilon * scale)
+            _, info = eng.potrf_(S)
+            if not _retrying(eng, info, scale):
+                break
+            scale *= 10.0
         zr = eng.randn(n, num)
         out = eng.trmv_lower(S, zr) if num == 1 else eng.gemm(S, zr, a_lower=True)
         return out + mean
@@ -646,7 +671,7 @@ class PseudoObs:
         yDy = torch.sum(ys * ys)
         trace_term = torch.sum(kdiag / d) - torch.sum(torch.diagonal(G))
 
-        def fill(block):
+        def fill(block, scale):
             block.copy_(G)
             block.diagonal().add_(1.0)
 

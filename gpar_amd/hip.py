@@ -24,6 +24,8 @@ __all__ = [
     "dot",
     "gemv_t",
     "rownorm2",
+    "pack_lower",
+    "unpack_lower_",
     "randn",
     "sample_stats",
     "trmv_lower",
@@ -126,7 +128,7 @@ def gram_diag(ck, z):
     return out
 
 
-def potrf_(A, nf=None, logdet=None, info=None, lookahead=True):
+def potrf_(A, nf=None, logdet=None, info=None, lookahead=True, fused=True):
     """In-place (partial) Cholesky of the lower triangle of the square matrix A; returns (logdet, info) device
     scalars (logdet accumulates, info is sticky: pass fresh zeros).  `lookahead=False`: the caller has several
     factorisations in flight itself (see gpar_potrf_ex)."""
@@ -140,7 +142,7 @@ def potrf_(A, nf=None, logdet=None, info=None, lookahead=True):
         logdet = torch.zeros(1, dtype=torch.float64, device=A.device)
     if info is None:
         info = torch.zeros(1, dtype=torch.int32, device=A.device)
-    flags = 0 if lookahead else _lib.POTRF_NO_LOOKAHEAD
+    flags = (0 if lookahead else _lib.POTRF_NO_LOOKAHEAD) | (0 if fused else _lib.POTRF_UNFUSED)
     _lib.check(
         lib.gpar_potrf_ex(A.data_ptr(), N, nf, _ld(A), logdet.data_ptr(), info.data_ptr(), flags, stream_ptr(A.device)), "gpar_potrf_ex"
     )
@@ -245,6 +247,28 @@ def rownorm2(A):
     out = torch.empty(A.shape[0], dtype=torch.float64, device=A.device)
     _lib.check(lib.gpar_rownorm2(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), out.data_ptr(), stream_ptr(A.device)), "gpar_rownorm2")
     return out
+
+
+def pack_lower(A, out=None):
+    """Lower triangle (diagonal included) of the square matrix A as a contiguous vector of n (n + 1) / 2 doubles."""
+    lib = _lib.load()
+    _check_mat(A, "A")
+    n = A.shape[0]
+    if out is None:
+        out = torch.empty(n * (n + 1) // 2, dtype=torch.float64, device=A.device)
+    _lib.check(lib.gpar_pack_lower(A.data_ptr(), n, _ld(A), out.data_ptr(), stream_ptr(A.device)), "gpar_pack_lower")
+    return out
+
+
+def unpack_lower_(packed, A):
+    """Inverse of pack_lower into the lower triangle of A (the strict upper triangle is left alone)."""
+    lib = _lib.load()
+    _check_mat(A, "A")
+    n = A.shape[0]
+    if packed.numel() < n * (n + 1) // 2 or not packed.is_contiguous():
+        raise ValueError("packed buffer too small or not contiguous")
+    _lib.check(lib.gpar_unpack_lower(packed.data_ptr(), n, A.data_ptr(), _ld(A), stream_ptr(A.device)), "gpar_unpack_lower")
+    return A
 
 
 def randn(seed, offset, rows, cols, device):

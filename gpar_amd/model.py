@@ -71,6 +71,22 @@ def last(xs, select=None):
         yield True, current
 
 
+def _retry_unfused(evaluate):
+    """evaluate(); should a hand-off inside a persistent panel kernel have timed out (device-side info < 0: results
+    invalid), once more with the engine in safe mode - separate leaf kernels, no look-ahead, no layer pipelining.  An
+    objective under autograd is not retried here: the optimiser treats the error as a failed evaluation."""
+    from .engine import HandOffTimeoutError
+
+    try:
+        return evaluate()
+    except HandOffTimeoutError:
+        eng = get_engine()
+        if torch.is_grad_enabled() or not hasattr(eng, "safe_mode"):
+            raise
+        with eng.safe_mode():
+            return evaluate()
+
+
 def _differentiable(f, noise):
     """Does the layer's log-likelihood take part in an autograd graph (the objective of `fit`)?"""
     from .gp import kernel_parameters
@@ -148,6 +164,9 @@ class GPAR:
     # ---- conditioning ----------------------------------------------------------------------------
     def __or__(self, x_y_w):
         """Posterior GPAR given data (x, y, w)."""
+        return _retry_unfused(lambda: self._condition(x_y_w))
+
+    def _condition(self, x_y_w):
         x, y, w = self._prep(*x_y_w)
         x_ind = self._prep_ind(self.x_ind)
         post = self.copy()
@@ -181,6 +200,9 @@ class GPAR:
         `outputs` restricts the layers visited, `x_ind` resumes a computation and `return_inputs` returns the
         design matrix (and inducing inputs) reached after the last visited layer instead of the value — the
         three together let `fit` precompute the inputs of a layer once (reference: model.py:178-243)."""
+        return _retry_unfused(lambda: self._logpdf(x, y, w, only_last_layer, sample_missing, return_inputs, x_ind, outputs))
+
+    def _logpdf(self, x, y, w, only_last_layer, sample_missing, return_inputs, x_ind, outputs):
         x, y, w = self._prep(x, y, w)
         x_ind = self._prep_ind(self.x_ind if x_ind is None else x_ind)
         total = torch.zeros((), dtype=torch.float64)

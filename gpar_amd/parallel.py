@@ -21,7 +21,7 @@ import torch.distributed as dist
 from .engine import get_engine
 from .model import last, per_output
 
-__all__ = ["world", "sharded_logpdf", "sharded_fit", "sharded_sample"]
+__all__ = ["world", "sharded_logpdf", "sharded_fit", "sharded_condition", "sharded_sample"]
 
 
 def world(group=None):
@@ -38,8 +38,13 @@ def _needs_estimate(gpar, yi, complete):
     return bool(torch.isnan(yi[:, 0]).any())
 
 
-def sharded_logpdf(gpar, x, y, w, group=None):
-    """`GPAR.logpdf(x, y, w)` with the layers divided over the ranks of `group`; every rank returns the total."""
+def sharded_logpdf(gpar, x, y, w, group=None, timing=None):
+    """`GPAR.logpdf(x, y, w)` with the layers divided over the ranks of `group`; every rank returns the total.
+    `timing` (a dict, optional) accumulates under "busy_s" the wall-clock this rank spent on its own layers, i.e. up to
+    the collective (what makes a multi-GPU run interpretable: the slowest rank's busy time bounds the step)."""
+    import time
+
+    t_start = time.perf_counter()
     rank, size = world(group)
     eng = get_engine()
     x, y, w = gpar._prep(x, y, w)
@@ -49,6 +54,8 @@ def sharded_logpdf(gpar, x, y, w, group=None):
         local, x, x_ind = _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local)
     if local.is_cuda:
         local = local.cpu()
+    if timing is not None:
+        timing["busy_s"] = timing.get("busy_s", 0.0) + (time.perf_counter() - t_start)
     if size > 1:
         buf = local.detach().to(device=eng.device, dtype=torch.float64).reshape(1).clone()
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
@@ -164,8 +171,8 @@ def sharded_fit(reg, x, y, w=None, group=None, **kw_args):
 def sharded_condition(reg, group=None):
     """The conditioned GPAR of `reg` (as `gpar | (x, y, w)`), with the p training-data factorisations divided over the
     ranks when no layer feeds another: layer i is factored by rank i mod G (a rank's layers pipelined over its streams)
-    and its (n + 1) x (n + 1) factor buffer - L and the row L^-1 y - is broadcast from its owner; every rank ends up
-    holding every factor, which is what sample-parallel prediction needs.  In the dependent regimes (imputation,
+    and the factor buffers - L and the row L^-1 y - are all-gathered in packed lower-triangular form, G layers per
+    collective; every rank ends up holding every factor, which is what sample-parallel prediction needs.  In the dependent regimes (imputation,
     `replace`, inducing points) every rank conditions locally, as the chain is sequential anyway."""
     from .model import construct_model
     from .regression import _construct_gpar
@@ -198,14 +205,38 @@ def sharded_condition(reg, group=None):
             post.layers.append(construct_model(f | obs, noise))
             if not is_last:
                 x = torch.cat([x, yi], dim=1)
-    # the exchange step: one broadcast per layer from its owner (2.15 GB at n = 16384; the streams were joined above, so
-    # the collective is ordered after the factorisations)
-    for i, fac in enumerate(factors):
-        # the matrix is a view into a row-padded buffer: collectives want the contiguous storage behind it
-        buf = fac.A._base if fac.A._base is not None else fac.A
-        assert buf.is_contiguous()
-        dist.broadcast(buf, src=_global_rank(i % size, group), group=group)
+    # The exchange step: layer i's factor (L and the row L^-1 y: the lower triangle of the (n + 1) x (n + 1) buffer) lives on
+    # rank i mod G.  Round k all-gathers layers k G .. k G + G - 1 in PACKED form - (n + 1)(n + 2) / 2 doubles each, half the
+    # bytes of the padded square buffers and one collective over all xGMI links per round instead of one broadcast (one
+    # root's links) per layer.  The streams were joined above, so the collective is ordered after the factorisations.
+    _exchange_factors(eng, factors, rank, size, group)
     return post
+
+
+def _exchange_factors(eng, factors, rank, size, group):
+    count = len(factors)
+    for first in range(0, count, size):
+        mine = first + rank
+        sizes = [f.n + 1 for f in factors[first : first + size]]
+        if len(set(sizes)) != 1:
+            # ragged layers (cannot happen in the independent regime this is used for): one broadcast per layer
+            for i in range(first, min(first + size, count)):
+                buf = factors[i].A._base if factors[i].A._base is not None else factors[i].A
+                dist.broadcast(buf, src=_global_rank(i % size, group), group=group)
+            continue
+        N = sizes[0]
+        length = N * (N + 1) // 2
+        send = torch.empty(length, dtype=torch.float64, device=eng.device)
+        if mine < count:
+            eng.pack_lower(factors[mine].A, send)
+        else:
+            send.zero_()  # this rank has no layer in the last, incomplete round
+        recv = [torch.empty(length, dtype=torch.float64, device=eng.device) for _ in range(size)]
+        dist.all_gather(recv, send, group=group)
+        for r in range(size):
+            i = first + r
+            if i < count and r != rank:
+                eng.unpack_lower_(recv[r], factors[i].A)
 
 
 def sharded_sample(reg, x, w=None, num_samples=100, latent=False, group=None):

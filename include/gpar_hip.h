@@ -159,6 +159,9 @@ int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, voi
 /* The same with hints.  GPAR_POTRF_NO_LOOKAHEAD: the caller keeps three or more factorisations in flight on streams of its
  * own (independent layers, gpar/model.py:221-243 run concurrently), so the internal side stream is not used. */
 #define GPAR_POTRF_NO_LOOKAHEAD 1
+/* GPAR_POTRF_UNFUSED: panels by separate diagonal / strip / update kernels (no persistent kernel, no in-launch hand-offs):
+ * the caller's retry path should a hand-off ever time out (info = -77). */
+#define GPAR_POTRF_UNFUSED 2
 int gpar_potrf_ex(double* A, int N, int nf, int lda, double* logdet, int* info, int flags, void* stream);
 
 /* B <- B L^-T  (right side, lower, transposed: forward substitution on the rows of B; B is nrows x n).
@@ -194,6 +197,12 @@ int gpar_dot(const double* x, int incx, const double* y, int incy, int n, double
 int gpar_gemv_t(const double* A, int rows, int cols, int lda, const double* v, double* out, double* workspace, void* stream);
 /* out[i] = sum_j A[i][j]^2, i < rows.  [marginal posterior variances k(x*, x*) - |V_i|^2, V = K_*x L^-T] */
 int gpar_rownorm2(const double* A, int rows, int cols, int lda, double* out, void* stream);
+
+/* Lower triangle (diagonal included) of the row-major n x n matrix A <-> packed storage of n (n + 1) / 2 doubles (row r at
+ * offset r (r + 1) / 2).  [the exchange format of Cholesky factors between the GPUs of a node: layer-parallel conditioning
+ * all-gathers packed factors, half the bytes of the padded square buffers] */
+int gpar_pack_lower(const double* A, int n, int lda, double* out, void* stream);
+int gpar_unpack_lower(const double* in, int n, double* A, int lda, void* stream);
 
 /* Workspace sizes in doubles (the caller allocates every workspace; -1 for an unknown `op`):
  *   GPAR_WS_GEMM_SPLITK  (m, n, splits)   gpar_gemm_splitk

@@ -27,10 +27,11 @@ class _Compiled:
         self.spec = ok.spec_to_dict(self.kernel)
 
 
-class OracleNotPositiveDefinite(ArithmeticError):
-    def __init__(self, info):
-        super().__init__(f"matrix is not positive definite: pivot {info} is not positive")
-        self.info = info
+from gpar_amd.engine import NotPositiveDefiniteError as _ProductNotPD  # the exception type the host code catches
+
+
+class OracleNotPositiveDefinite(_ProductNotPD):
+    pass
 
 
 def _np(t):
@@ -43,6 +44,7 @@ class OracleEngine:
     def __init__(self, seed=0, epsilon=1e-12):
         self.device = torch.device("cpu")
         self.epsilon = float(epsilon)
+        self.cholesky_retry_factor = 1.0
         self._seed = int(seed)
         self._calls = 0
 
@@ -181,6 +183,21 @@ class OracleEngine:
     def gemv_t(self, A, v):
         return torch.from_numpy(_np(A).T @ _np(v).reshape(-1))
 
+    def pack_lower(self, A, out=None):
+        a = _np(A)
+        il = np.tril_indices(a.shape[0])
+        packed = torch.from_numpy(np.ascontiguousarray(a[il]))
+        if out is not None:
+            out[: packed.numel()] = packed
+            return out
+        return packed
+
+    def unpack_lower_(self, packed, A):
+        a = A.numpy()
+        il = np.tril_indices(a.shape[0])
+        a[il] = _np(packed)[: len(il[0])]
+        return A
+
     def rownorm2(self, A):
         a = _np(A)
         return torch.from_numpy(np.sum(a * a, axis=1))
@@ -221,3 +238,5 @@ class OracleEngine:
         code = int(info.item())
         if code != 0:
             raise OracleNotPositiveDefinite(code)
+
+    _raise_for = check_info

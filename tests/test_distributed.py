@@ -107,3 +107,75 @@ def test_layer_parallel_matches_serial_world_size_2():
         assert received == [i for i in range(3) if i % size != rank], (rank, received)  # the others' layers came over the wire
     # both ranks hold the same totals
     assert results[0]["independent"][1] == results[1]["independent"][1]
+
+
+def _worker_c3(rank, size, port, results):
+    """BASELINE C3's partitioning at toy size: p = 8 layers, markov = 2, four ranks -> two layers per rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        from gpar_amd.engine import get_engine, set_engine
+        from gpar_amd.parallel import sharded_condition, sharded_fit, sharded_logpdf, sharded_sample
+        from gpar_amd.regression import GPARRegressor, _construct_gpar
+        from oracle.engine import OracleEngine
+
+        set_engine(OracleEngine(seed=3))
+        rng = np.random.default_rng(4)
+        n, m, p = 24, 4, 8
+        x = rng.uniform(0, 1, (n, m))
+        cols = []
+        for i in range(p):
+            f = np.sin(3 * x @ rng.uniform(0.5, 1.5, m) + i)
+            if cols:
+                f = f + 0.5 * np.cos(cols[-1])
+            cols.append(f + 0.05 * rng.standard_normal(n))
+        y = np.stack(cols, axis=1)
+        kw = dict(scale=0.5, linear=True, nonlinear=True, markov=2, noise=0.1, normalise_y=False)
+        reg = GPARRegressor(**kw)
+        gpar = _construct_gpar(reg, reg.vs, m, p)
+        out = {"logpdf": (float(gpar.logpdf(x, y, np.ones_like(y))), float(sharded_logpdf(gpar, x, y, np.ones_like(y))))}
+        a, b = GPARRegressor(**kw), GPARRegressor(**kw)
+        a.fit(x, y, iters=5)
+        sharded_fit(b, x, y, iters=5)
+        va, vb = a.get_variables(), b.get_variables()
+        out["fit"] = (sorted(va) == sorted(vb), max(float(np.max(np.abs(va[k] - vb[k]))) for k in va))
+        post = sharded_condition(b)
+        received = [i for i, layer in enumerate(post.layers) if layer()[0]._obs._fac.logdet is None]
+        get_engine().seed(7)
+        via = np.stack(b.sample(x[:6], posterior=True, num_samples=2, _conditioned=post))
+        get_engine().seed(7)
+        local = np.stack(b.sample(x[:6], posterior=True, num_samples=2))
+        out["condition"] = (float(np.max(np.abs(via - local))), received)
+        out["samples"] = len(sharded_sample(b, x[:5], None, num_samples=6))
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_c3_partitioning_world_size_4():
+    """p = 8, markov = 2 on four ranks (layers i and i + 4 on rank i): log-likelihood, training, packed all-gather of the
+    factors (two rounds of four layers) and sample-parallel prediction."""
+    size = 4
+    ctx = mp.get_context("spawn")
+    manager = ctx.Manager()
+    results = manager.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c3, args=(r, size, port, results)) for r in range(size)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=570)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for rank in range(size):
+        out = results[rank]
+        serial, sharded = out["logpdf"]
+        assert abs(serial - sharded) <= 1e-10 * abs(serial), (rank, serial, sharded)
+        same, maxdiff = out["fit"]
+        assert same and maxdiff < 1e-9
+        maxdiff, received = out["condition"]
+        assert maxdiff == 0.0
+        assert received == [i for i in range(8) if i % size != rank]
+        assert out["samples"] == 6
+    assert len({results[r]["logpdf"][1] for r in range(size)}) == 1

@@ -227,3 +227,31 @@ def test_missing_rows_with_imputation_chain(engine):
     have1 = ~np.isnan(y[:, 1])
     l2 = f2(x2[have1], 0.2).logpdf(y[have1, 1])
     close(total, l1 + l2, rtol=1e-10)
+
+
+def test_cholesky_retry_factor_as_in_lab(engine):
+    """lab's `B.cholesky_retry_factor` (default 1: a failed Cholesky raises; > 1: retried with the jitter x 10 while the
+    factor stays below it).  A rank-deficient noise-free covariance with epsilon = 0 fails; with the retry ladder
+    allowed to reach a workable jitter it goes through."""
+    from gpar_amd.engine import NotPositiveDefiniteError
+    from gpar_amd.gp import GP
+    from gpar_amd.kernels import Linear
+
+    f = GP(Linear().stretch(np.ones(1)))  # rank one: any three points give a singular 3 x 3 matrix
+    x = np.array([[1.0], [2.0], [3.0]])
+    y = np.array([1.0, 2.0, 3.1])
+    previous = engine.epsilon, engine.cholesky_retry_factor
+    try:
+        engine.epsilon = 1e-30
+        with pytest.raises(NotPositiveDefiniteError):
+            float(f(x).logpdf(y))
+        engine.cholesky_retry_factor = 1e25  # jitter may grow to 1e-5
+        value = float(f(x).logpdf(y))
+        assert np.isfinite(value)
+        sample = f(x).sample()
+        assert np.all(np.isfinite(sample.cpu().numpy()))
+        engine.cholesky_retry_factor = 10.0  # one retry only (1e-29): still singular in fp64
+        with pytest.raises(NotPositiveDefiniteError):
+            float(f(x).logpdf(y))
+    finally:
+        engine.epsilon, engine.cholesky_retry_factor = previous
