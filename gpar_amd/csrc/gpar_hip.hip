@@ -136,6 +136,8 @@ struct GparDeviceGuard {
     int prev = -1, dev = -1;
     explicit GparDeviceGuard(void* stream) {
         hipDevice_t d;
+        // (a null stream is the current device's default stream: nothing to switch, and per-device state is looked up by
+        // the current device)
         if (stream && hipGetDevice(&prev) == hipSuccess && hipStreamGetDevice(static_cast<hipStream_t>(stream), &d) == hipSuccess) {
             dev = (int)d;
             if (dev != prev) GPAR_HIP_IGNORE(hipSetDevice(dev));   // a failure shows up in the launch that follows

@@ -386,18 +386,30 @@ struct LookaheadState {
     int nev = 0;
     bool ok = false;
 };
-static LookaheadState g_la;
+// One state per DEVICE: streams and events belong to the device that was current when they were created, and a process may
+// drive several GPUs (every entry point makes the device of the caller's stream current - the current device for a null
+// stream - before it gets here: GparDeviceGuard).
+constexpr int GPAR_MAX_DEVICES = 16;
+static LookaheadState g_la_devices[GPAR_MAX_DEVICES];
+static LookaheadState& la_state() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return g_la_devices[dev % GPAR_MAX_DEVICES];
+}
+#define g_la la_state()
 
 static hipEvent_t la_event() {
-    if (g_la.nev >= LookaheadState::MAXE) g_la.nev = 0;   // ring: far more than a few factorisations' worth in flight
-    return g_la.ev[g_la.nev++];
+    LookaheadState& st = la_state();
+    if (st.nev >= LookaheadState::MAXE) st.nev = 0;   // ring: far more than a few factorisations' worth in flight
+    return st.ev[st.nev++];
 }
 
 static bool la_init() {
-    if (g_la.ok) return true;
+    LookaheadState& st = la_state();
+    if (st.ok) return true;
     for (int i = 0; i < LookaheadState::MAXE; ++i)
-        if (hipEventCreateWithFlags(&g_la.ev[i], hipEventDisableTiming) != hipSuccess) return false;
-    g_la.ok = true;
+        if (hipEventCreateWithFlags(&st.ev[i], hipEventDisableTiming) != hipSuccess) return false;
+    st.ok = true;
     return true;
 }
 

@@ -175,3 +175,31 @@ def test_concurrent_factorisations_complete_their_handoffs(hip, streams, n):
     ref = torch.tril(alone)
     for a in mats:
         assert torch.equal(torch.tril(a), ref)
+
+
+def test_missing_data_at_scale_with_sampled_imputation(hip):
+    """`sample_missing=True` (reference gpar/model.py:229-237) with 20 % of the observations missing
+    in a pattern that is NOT closed downwards, at n = 4096, p = 4: ragged per-layer row counts on the device, missing
+    entries drawn from the layer posteriors.  Two evaluations differ (fresh draws), agree with one another to a few per cent
+    and lie below the value with posterior-mean imputation (a mean is the likeliest fill-in); with nothing missing the flag changes nothing; the engine's safe mode (unfused
+    panels, no pipelining) reproduces the default path."""
+    from gpar_amd.regression import GPARRegressor
+
+    n, m, p = 4096, 2, 4
+    x, y = _data(n, m, p)
+    rng = np.random.default_rng(0)
+    holes = y.copy()
+    holes[rng.random(y.shape) < 0.2] = np.nan
+    holes[0] = y[0]
+    reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False, impute=True)
+    a = float(reg.logpdf(x, holes, sample_missing=True))
+    b = float(reg.logpdf(x, holes, sample_missing=True))
+    imputed = float(reg.logpdf(x, holes))
+    assert np.isfinite(a) and np.isfinite(b) and a != b
+    assert a < imputed and b < imputed and abs(a - imputed) < 0.5 * abs(imputed)
+    assert abs(a - b) < 0.05 * abs(a)
+    full = float(reg.logpdf(x, y))
+    assert float(reg.logpdf(x, y, sample_missing=True)) == full
+    with hip.safe_mode():
+        safe = float(reg.logpdf(x, y))
+    assert abs(safe - full) <= 1e-12 * abs(full)

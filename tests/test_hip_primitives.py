@@ -436,3 +436,37 @@ def test_gemm_split_k_path(env, ta, tb, mnk):
         gotc = dC.cpu().numpy()
         assert np.all(np.abs(gotc - (0.5 * opA @ opB + 2 * C))[il] <= 2e-13 * (scale + np.abs(C))[il])
         assert np.array_equal(gotc[iu], C[iu])
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 257, 1000])
+def test_pack_and_unpack_lower(env, n):
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n))
+    dA = to_dev(A)
+    packed = hip.pack_lower(dA).cpu().numpy()
+    assert np.array_equal(packed, A[np.tril_indices(n)])
+    B = to_dev(np.full((n, n), 7.0))
+    hip.unpack_lower_(to_dev(packed), B)
+    got = B.cpu().numpy()
+    assert np.array_equal(np.tril(got), np.tril(A))
+    assert np.all(got[np.triu_indices(n, 1)] == 7.0)  # the strict upper triangle is left alone
+
+
+@pytest.mark.parametrize("n", [700, 4096])
+def test_unfused_factorisation_path_agrees(env, n):
+    """gpar_potrf_ex(GPAR_POTRF_UNFUSED): the retry path after a hand-off timeout (separate leaf kernels) against the
+    default path."""
+    torch, hip, dev, to_dev = env
+    g = torch.Generator().manual_seed(n)
+    x = torch.rand(n, 3, generator=g, dtype=torch.float64).to(dev)
+    K = torch.exp(-0.5 * torch.cdist(x, x) ** 2 / 0.25)
+    K.diagonal().add_(0.1)
+    A, B = hip.alloc_matrix(n, n, dev), hip.alloc_matrix(n, n, dev)
+    A.copy_(K)
+    B.copy_(K)
+    la, ia = hip.potrf_(A)
+    lb, ib = hip.potrf_(B, fused=False, lookahead=False)
+    assert int(ia.item()) == 0 and int(ib.item()) == 0
+    assert abs(float(la) - float(lb)) <= 1e-12 * abs(float(la))
+    assert (torch.tril(A) - torch.tril(B)).abs().max() <= 1e-11
