@@ -36,12 +36,87 @@ __device__ __forceinline__ double gram_nonlin(int type, double s, double alpha) 
     return s;
 }
 
+// Squared distances / inner products of a 4 x 2 micro-tile over ND feature dims starting at d0, fully unrolled: all 3 ND
+// LDS reads are issued before the first fused multiply-add (a rolled loop over a run-time dim count waits out the LDS
+// latency and pays the loop overhead once per dim: the kernel ran at 46 % of the vector-ALU issue rate).
+template <int ND, bool LINEAR>
+__device__ __forceinline__ void gram_accum(const double* __restrict__ Za, const double* __restrict__ Zb, int d0, int ty, int cb,
+                                           double (&s)[8]) {
+    typedef double g_d2 __attribute__((ext_vector_type(2)));
+    typedef double g_d4 __attribute__((ext_vector_type(4)));
+    g_d4 za[ND];
+    g_d2 zb[ND];
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+        za[q] = *reinterpret_cast<const g_d4*>(&Za[(d0 + q) * GRAM_LD + 4 * ty]);
+        zb[q] = *reinterpret_cast<const g_d2*>(&Zb[(d0 + q) * GRAM_LD + cb]);
+    }
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (LINEAR) {
+                s[2 * i] = fma(za[q][i], zb[q][0], s[2 * i]);
+                s[2 * i + 1] = fma(za[q][i], zb[q][1], s[2 * i + 1]);
+            } else {
+                const double d0_ = za[q][i] - zb[q][0], d1_ = za[q][i] - zb[q][1];
+                s[2 * i] = fma(d0_, d0_, s[2 * i]);
+                s[2 * i + 1] = fma(d1_, d1_, s[2 * i + 1]);
+            }
+        }
+    }
+}
+
+template <bool LINEAR>
+__device__ __forceinline__ void gram_accum_dims(const double* __restrict__ Za, const double* __restrict__ Zb, int off, int nd, int ty,
+                                                int cb, double (&s)[8]) {
+    int d = off;
+    // four dims at a time: 12 doubles of operands per dim - eight at a time needed 220 registers (two waves per SIMD)
+    for (; d + 4 <= off + nd; d += 4) gram_accum<4, LINEAR>(Za, Zb, d, ty, cb, s);
+    switch (off + nd - d) {   // wave-uniform
+        case 3: gram_accum<3, LINEAR>(Za, Zb, d, ty, cb, s); break;
+        case 2: gram_accum<2, LINEAR>(Za, Zb, d, ty, cb, s); break;
+        case 1: gram_accum<1, LINEAR>(Za, Zb, d, ty, cb, s); break;
+        default: break;
+    }
+}
+
+// exp(x) for eight independent arguments x <= 0 (exponents of EQ / RQ factors), written so that the eight polynomial
+// chains interleave (the library call compiles to one serial 11-deep Horner chain per call, and with the type dispatch around
+// it the compiler emitted the eight calls of a micro-tile one after the other: latency-bound instead of issue-bound).
+// x = k ln2 + r, |r| <= ln2 / 2; exp(r) by its Taylor polynomial of degree 13 (remainder 4e-18 relative); 2^k by v_ldexp_f64,
+// which also flushes to zero / denormals below -708.  Agrees with the correctly rounded value to 1 ulp.
+__device__ __forceinline__ void gram_exp8(double (&x)[8]) {
+    constexpr double L2E = 1.4426950408889634074, LN2H = 6.93147180369123816490e-01, LN2L = 1.90821492927058770002e-10;
+    double k[8], r[8], p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = __builtin_rint(x[i] * L2E);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = fma(k[i], -LN2L, fma(k[i], -LN2H, x[i]));
+    constexpr double c[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+                              1.0 / 5040.0,       1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0,      0.5};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = c[0];
+#pragma unroll
+    for (int j = 1; j < 12; ++j) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = fma(p[i], r[i], c[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = fma(fma(p[i], r[i], 1.0), r[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_ldexp(p[i], (int)k[i]);
+}
+
+// Two passes of a 4 x 2 micro-tile per thread.  Per product term the exponents of its EQ / RQ factors are SUMMED and
+// exponentiated once (a locally periodic term is exp(-(s_per + s_dec) / 2): one exponential, not two), linear factors
+// multiply into a separate product; the factor type is wave-uniform and dispatched once per factor.
 __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double* __restrict__ z1, int n1, int ldz1,
                                                    const double* __restrict__ z2, int n2, int ldz2, int dz,
                                                    double* __restrict__ K, int ldk, int flags,
                                                    const double* __restrict__ diag_add, double diag_const,
                                                    const double* __restrict__ row_scale, int sym) {
-    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    extern __shared__ __attribute__((aligned(32))) double gsm[];
     int bm = blockIdx.y, bn = blockIdx.x;
     if (flags & GPAR_GRAM_LOWER) {
         // 1-D grid over the tiles of the lower triangle (a 2-D grid would launch as many empty workgroups again)
@@ -63,80 +138,70 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
     __syncthreads();
     const int tx = t & 15, ty = t >> 4;
     const bool vec = ((ldk & 1) == 0) && ((((uintptr_t)K) & 15u) == 0);
-    // Two passes of a 4 x 2 micro-tile per thread (columns 2 tx, 2 tx + 1 of the left, then of the right half of the tile)
-    // instead of one 4 x 4: half the live accumulators (the 4 x 4 form needed 183-206 VGPRs: two waves per SIMD for a kernel
-    // that lives on latency hiding), and every 16-byte store of a row group is one contiguous 256-byte run.
+    typedef double g_d2 __attribute__((ext_vector_type(2)));
+    typedef double g_d4 __attribute__((ext_vector_type(4)));
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         const int cb = 32 * h + 2 * tx;   // first of this thread's two columns within the tile
-        double total[4][2];
+        double total[8];                  // entry (i, j) of the 4 x 2 micro-tile at 2 i + j
 #pragma unroll
-        for (int i = 0; i < 4; ++i) total[i][0] = total[i][1] = 0.0;
+        for (int e = 0; e < 8; ++e) total[e] = 0.0;
         int f = 0;
         for (int term = 0; term < ks.nterms; ++term) {
-            double prod[4][2];
-            const double coef = ks.coef[term];
+            double expo[8], lin[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) prod[i][0] = prod[i][1] = coef;
+            for (int e = 0; e < 8; ++e) { expo[e] = 0.0; lin[e] = ks.coef[term]; }
+            bool any_exp = false;
             while (f < ks.nfactors && ks.factor[f].term == term) {
                 const int type = ks.factor[f].type, off = ks.factor[f].off, nd = ks.factor[f].nd;
-                const double alpha = ks.factor[f].alpha;
-                double s[4][2];
+                double s[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s[i][0] = s[i][1] = 0.0;
-                for (int d = off; d < off + nd; ++d) {
-                    double za[4];
+                for (int e = 0; e < 8; ++e) s[e] = 0.0;
+                if (type == GPAR_K_LINEAR) {
+                    gram_accum_dims<true>(Za, Zb, off, nd, ty, cb, s);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) za[i] = Za[d * GRAM_LD + 4 * ty + i];
-                    const double zb0 = Zb[d * GRAM_LD + cb], zb1 = Zb[d * GRAM_LD + cb + 1];
-                    if (type == GPAR_K_LINEAR) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { s[i][0] = fma(za[i], zb0, s[i][0]); s[i][1] = fma(za[i], zb1, s[i][1]); }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const double d0 = za[i] - zb0, d1 = za[i] - zb1;
-                            s[i][0] = fma(d0, d0, s[i][0]);
-                            s[i][1] = fma(d1, d1, s[i][1]);
-                        }
-                    }
-                }
-                if (type == GPAR_K_EQ) {   // the type is uniform: dispatch once per factor, not per entry
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { prod[i][0] *= exp(-0.5 * s[i][0]); prod[i][1] *= exp(-0.5 * s[i][1]); }
-                } else if (type == GPAR_K_RQ) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        prod[i][0] *= exp(-alpha * log1p(s[i][0] / (2.0 * alpha)));
-                        prod[i][1] *= exp(-alpha * log1p(s[i][1] / (2.0 * alpha)));
-                    }
+                    for (int e = 0; e < 8; ++e) lin[e] *= s[e];
                 } else {
+                    gram_accum_dims<false>(Za, Zb, off, nd, ty, cb, s);
+                    any_exp = true;
+                    if (type == GPAR_K_EQ) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { prod[i][0] *= s[i][0]; prod[i][1] *= s[i][1]; }
+                        for (int e = 0; e < 8; ++e) expo[e] = fma(-0.5, s[e], expo[e]);
+                    } else {   // RQ: (1 + s / 2 alpha)^-alpha = exp(-alpha log1p(s / 2 alpha))
+                        const double alpha = ks.factor[f].alpha, h2a = 0.5 / alpha;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) expo[e] = fma(-alpha, log1p(s[e] * h2a), expo[e]);
+                    }
                 }
                 ++f;
             }
+            if (any_exp) {
+                gram_exp8(expo);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { total[i][0] += prod[i][0]; total[i][1] += prod[i][1]; }
+                for (int e = 0; e < 8; ++e) total[e] = fma(lin[e], expo[e], total[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) total[e] += lin[e];
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + 4 * ty + i;
             if (row >= n1) continue;
             const int col = col0 + cb;
-            if (row_scale) { const double rs = row_scale[row]; total[i][0] *= rs; total[i][1] *= rs; }
+            double v0 = total[2 * i], v1 = total[2 * i + 1];
+            if (row_scale) { const double rs = row_scale[row]; v0 *= rs; v1 *= rs; }
             if (sym) {
                 const double dadd = (diag_add ? diag_add[row] : 0.0) + diag_const;
-                if (col == row) total[i][0] += dadd;
-                if (col + 1 == row) total[i][1] += dadd;
+                if (col == row) v0 += dadd;
+                if (col + 1 == row) v1 += dadd;
             }
             double* out = K + (size_t)row * ldk + col;
             if (vec && col + 1 < n2) {
-                typedef double d2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<d2*>(out) = d2{total[i][0], total[i][1]};
+                *reinterpret_cast<g_d2*>(out) = g_d2{v0, v1};
             } else {
-                if (col < n2) out[0] = total[i][0];
-                if (col + 1 < n2) out[1] = total[i][1];
+                if (col < n2) out[0] = v0;
+                if (col + 1 < n2) out[1] = v1;
             }
         }
     }

@@ -39,7 +39,7 @@ import torch
 from .engine import get_engine, joining
 from .kernels import Kernel
 
-__all__ = ["Measure", "GP", "FDD", "Obs", "PseudoObs", "SparseObs"]
+__all__ = ["Measure", "GP", "FDD", "Obs", "PseudoObs", "PseudoObsVFE", "PseudoObsFITC", "PseudoObsDTC", "SparseObs"]
 
 _LOG_2PI = math.log(2.0 * math.pi)
 
@@ -615,10 +615,16 @@ class Obs:
 
 
 class PseudoObs:
-    """Inducing-point observations, VFE approximation (stheno `PseudoObs(f(x_ind), f(x, noise), y)`), of the process
-    `fdd.p` (prior or posterior)."""
+    """Inducing-point observations (stheno `PseudoObs(f(x_ind), f(x, noise), y)`) of the process `fdd.p` (prior or
+    posterior).  `method` selects the approximation, as stheno's `PseudoObsVFE` (the default, Titsias 2009) /
+    `PseudoObsFITC` / `PseudoObsDTC` do:
+        VFE   log N(y; m, Q + D) - 1/2 tr D^-1 (K - Q)
+        DTC   log N(y; m, Q + D)
+        FITC  log N(y; m, Q + D + diag(K - Q))        (the posterior then uses D + diag(K - Q) as well)
+    with Q = K_xz K_zz^-1 K_zx."""
 
     fast_dense = False
+    method = "vfe"
 
     def __init__(self, u, fdd, y):
         if isinstance(u, tuple):
@@ -641,7 +647,7 @@ class PseudoObs:
         return p
 
     def rebased(self, gp):
-        return PseudoObs(FDD(gp, self.u.x), FDD(gp, self.fdd.x, self.fdd.noise_arg), self.y)
+        return type(self)(FDD(gp, self.u.x), FDD(gp, self.fdd.x, self.fdd.noise_arg), self.y)
 
     def _compute(self):
         if self._state is not None:
@@ -650,17 +656,25 @@ class PseudoObs:
         n, M = self.fdd.n, self.u.n
         px, pz = self.fdd.pts(), self.u.pts()
         d = self.fdd.noise
-        rs = torch.rsqrt(d)
         # L_z = chol(K_zz + eps I)
         Lz = eng.new_matrix(M, M)
         mean_z = base._moments_into(pz, Lz, None, eng.epsilon)
         del mean_z  # the bound only involves the mean at the observed inputs
         _, info = eng.potrf_(Lz)
         eng.check_info(info)
-        # Bs = D^-1/2 K_xz L_z^-T (n x M): the row scaling rides along in the Gram kernel
-        Bs = base._cross(px, pz, row_scale=rs)
-        eng.trsm_rlt_(Lz, Bs)
         kdiag = base._diag(px)
+        if self.method == "fitc":
+            # the effective noise needs q_aa = |B_:a|^2 before anything can be scaled by it: one more pass over n x M
+            Bs = base._cross(px, pz)
+            eng.trsm_rlt_(Lz, Bs)
+            d = d + torch.clamp(kdiag - eng.rownorm2(Bs), min=0.0)
+            rs = torch.rsqrt(d)
+            Bs.mul_(rs[:, None])
+        else:
+            rs = torch.rsqrt(d)
+            # Bs = D^-1/2 K_xz L_z^-T (n x M): the row scaling rides along in the Gram kernel
+            Bs = base._cross(px, pz, row_scale=rs)
+            eng.trsm_rlt_(Lz, Bs)
         resid = self.y if not base.is_posterior else self.y - base._mean_at(px)
         ys = resid.reshape(-1) * rs
         # A - I = Bs^T Bs: ONE product over the n data points (K = n is cut into slices so that the whole chip works);
@@ -669,7 +683,7 @@ class PseudoObs:
         G = eng.gemm(Bs, Bs, ta=True, c_lower=True)
         c = eng.gemv_t(Bs, ys).reshape(1, M)
         yDy = torch.sum(ys * ys)
-        trace_term = torch.sum(kdiag / d) - torch.sum(torch.diagonal(G))
+        trace_term = torch.sum(kdiag / d) - torch.sum(torch.diagonal(G)) if self.method == "vfe" else 0.0
 
         def fill(block, scale):
             block.copy_(G)
@@ -682,7 +696,7 @@ class PseudoObs:
         eng.trsm_rln_(Lz, v)
         deferring = getattr(eng, "_deferred", None) is not None
         self._state = {"Lz": Lz, "La": facA.L, "v": v, "elbo": elbo.detach() if deferring else elbo.detach().cpu(),
-                       "Bs": Bs, "G": G, "facA": facA, "kdiag": kdiag, "ys": ys}
+                       "Bs": Bs, "G": G, "facA": facA, "kdiag": kdiag, "ys": ys, "d": d}
         return self._state
 
     def _value(self):
@@ -714,6 +728,9 @@ class PseudoObs:
             (S^-1)_aa = 1/d_a - |L_A^-1 B_:a|^2 / d_a^2.
         The forward pass keeps Bs = D^-1/2 B^T, so B^T = D^1/2 Bs throughout.  The three weighted sums over kernel
         derivatives are one fused device pass each (`kernel_grads_vfe`)."""
+        if self.method == "fitc":
+            raise NotImplementedError("training through the FITC approximation is not implemented (use VFE or DTC)")
+        vfe = self.method == "vfe"
         eng = self.eng
         st = self._compute()
         n, M = self.fdd.n, self.u.n
@@ -727,15 +744,19 @@ class PseudoObs:
         Ainv_full = torch.tril(Ainv) + torch.tril(Ainv, -1).T
         # W_fu
         T = eng.new_matrix(n, M)
-        T.copy_(Bs)
-        eng.gemm(Bs, Ainv_full, alpha=-1.0, beta=1.0, out=T)  # Bs (I - A^-1)
+        if vfe:
+            T.copy_(Bs)
+        else:
+            T.zero_()  # DTC: no trace term, W_fu = G P^T = [alpha beta^T - D^-1 B^T A^-1] L_z^-1
+        eng.gemm(Bs, Ainv_full, alpha=-1.0, beta=1.0, out=T)  # Bs (I - A^-1)   [DTC: -Bs A^-1]
         T.mul_(rs[:, None])  # D^-1 B^T (I - A^-1)
         T.add_(alpha[:, None] * beta)
         eng.trsm_rln_(Lz, T)  # ... L_z^-1
         # W_uu
         S = eng.new_matrix(M, M)
         S.copy_(beta.reshape(M, 1) * beta + Ainv_full)
-        S.add_(torch.tril(G) + torch.tril(G, -1).T)  # B D^-1 B^T = A - I
+        if vfe:
+            S.add_(torch.tril(G) + torch.tril(G, -1).T)  # B D^-1 B^T = A - I (the trace term's share)
         S.diagonal().sub_(1.0)
         eng.trsm_rln_(Lz, S)  # S L_z^-1
         St = eng.new_matrix(M, M)
@@ -747,9 +768,14 @@ class PseudoObs:
         E = eng.new_matrix(n, M)
         E.copy_(Bs)
         eng.trsm_rlt_(facA.L, E)
-        noise_grad = 0.5 * (alpha * alpha - 1.0 / d + (eng.rownorm2(E) - eng.rownorm2(Bs)) / d + st["kdiag"] / (d * d))
+        if vfe:
+            noise_grad = 0.5 * (alpha * alpha - 1.0 / d + (eng.rownorm2(E) - eng.rownorm2(Bs)) / d + st["kdiag"] / (d * d))
+            wdiag = -0.5 / d
+        else:
+            noise_grad = 0.5 * (alpha * alpha - 1.0 / d + eng.rownorm2(E) / d)
+            wdiag = torch.zeros_like(d)
         ck = self.fdd.pts().ck
-        grads = eng.kernel_grads_vfe(ck, self.fdd.x, self.u.x, T, Wuu, -0.5 / d)
+        grads = eng.kernel_grads_vfe(ck, self.fdd.x, self.u.x, T, Wuu, wdiag)
         return noise_grad, grads
 
     # ---- the posterior's corrections (any base process) -----------------------------------------------
@@ -799,4 +825,13 @@ class PseudoObs:
         return corr if not self.base.is_posterior else mean + corr
 
 
+class PseudoObsFITC(PseudoObs):
+    method = "fitc"
+
+
+class PseudoObsDTC(PseudoObs):
+    method = "dtc"
+
+
+PseudoObsVFE = PseudoObs
 SparseObs = PseudoObs

@@ -14,7 +14,7 @@ import torch
 
 from .engine import get_engine
 from .engine import joining as _joining
-from .gp import Obs, PseudoObs
+from .gp import Obs, PseudoObs, PseudoObsDTC, PseudoObsFITC
 
 __all__ = ["GPAR", "merge", "construct_model", "last", "per_output"]
 
@@ -126,17 +126,21 @@ class GPAR:
         replace (bool): feed posterior means instead of observations to later layers.
         impute (bool): fill missing observations with posterior means so the data stay closed downwards.
         x_ind (tensor, optional): inducing-point locations; enables the sparse (VFE) path.
+        sparse_method (str): "vfe" (default, what the reference uses), "fitc" or "dtc".
     """
 
-    def __init__(self, replace=False, impute=False, x_ind=None):
+    def __init__(self, replace=False, impute=False, x_ind=None, sparse_method="vfe"):
         self.replace = replace
         self.impute = impute
         self.layers = []
         self.sparse = x_ind is not None
         self.x_ind = x_ind
+        if sparse_method not in ("vfe", "fitc", "dtc"):
+            raise ValueError('sparse_method must be "vfe", "fitc" or "dtc"')
+        self.sparse_method = sparse_method  # (an addition: stheno's PseudoObsVFE / FITC / DTC; the reference always uses VFE)
 
     def copy(self):
-        return GPAR(replace=self.replace, impute=self.impute, x_ind=self.x_ind)
+        return GPAR(replace=self.replace, impute=self.impute, x_ind=self.x_ind, sparse_method=self.sparse_method)
 
     def add_layer(self, model_constructor):
         out = self.copy()
@@ -353,7 +357,8 @@ class GPAR:
             available = ~torch.isnan(y[:, 0])
             x, y, w = x[available], y[available], w[available]
         if self.sparse:
-            return PseudoObs(f(x_ind), f(x, self._noise_arg(noise, w)), y)
+            cls = {"vfe": PseudoObs, "fitc": PseudoObsFITC, "dtc": PseudoObsDTC}[self.sparse_method]
+            return cls(f(x_ind), f(x, self._noise_arg(noise, w)), y)
         return Obs(f(x, self._noise_arg(noise, w)), y)
 
     @staticmethod

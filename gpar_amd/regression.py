@@ -121,7 +121,7 @@ def _model_generator(vs, m, pi, scale, scale_tie, per, per_period, per_scale, pe
 
 
 def _construct_gpar(reg, vs, m, p):
-    gpar = GPAR(replace=reg.replace, impute=reg.impute, x_ind=reg.x_ind)
+    gpar = GPAR(replace=reg.replace, impute=reg.impute, x_ind=reg.x_ind, sparse_method=reg.sparse_method)
     for pi in range(p):
         gpar = gpar.add_layer(_model_generator(vs, m, pi, **reg.model_config))
     return gpar
@@ -169,8 +169,9 @@ class GPARRegressor:
     def __init__(self, replace=False, impute=True, scale=1.0, scale_tie=False, per=False, per_period=1.0,
                  per_scale=1.0, per_decay=10.0, input_linear=False, input_linear_scale=100.0, linear=True,
                  linear_scale=100.0, nonlinear=False, nonlinear_scale=1.0, rq=False, markov=None, noise=0.1,
-                 x_ind=None, normalise_y=True, transform_y=(lambda x: x, lambda x: x)):
+                 x_ind=None, normalise_y=True, transform_y=(lambda x: x, lambda x: x), sparse_method="vfe"):
         self.replace = replace
+        self.sparse_method = sparse_method  # an addition behind the reference's keywords: "vfe" | "fitc" | "dtc"
         self.impute = impute
         self.sparse = x_ind is not None
         self.x_ind = None if x_ind is None else _uprank(_to_torch(x_ind))

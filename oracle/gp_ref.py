@@ -93,20 +93,27 @@ class Process:
         k = lambda p, q: self.k(p, q) - self.k(p, x) @ np.linalg.solve(S, self.k(x, q))
         return Process(mean, k)
 
-    def vfe_bound(self, x, y, noise, z, eps=1e-12):
+    def vfe_bound(self, x, y, noise, z, eps=1e-12, method="vfe"):
+        """Titsias' bound (method "vfe"); the DTC / FITC log-densities log N(y; m, Q + D [+ diag(K - Q)])."""
         y = np.asarray(y, dtype=np.float64).reshape(-1)
         d = np.broadcast_to(noise, y.shape).astype(np.float64)
         Kzz = self.k(z, z) + eps * np.eye(np.asarray(z).shape[0])
         Kxz = self.k(x, z)
         Q = Kxz @ np.linalg.solve(Kzz, Kxz.T)
         kdiag = np.diag(self.k(x, x))
+        if method == "fitc":
+            return _mvn_logpdf(Q + np.diag(d + kdiag - np.diag(Q)), y - self.mean(x))
+        if method == "dtc":
+            return _mvn_logpdf(Q + np.diag(d), y - self.mean(x))
         return _mvn_logpdf(Q + np.diag(d), y - self.mean(x)) - 0.5 * np.sum((kdiag - np.diag(Q)) / d)
 
-    def condition_sparse(self, x, y, noise, z, eps=1e-12):
+    def condition_sparse(self, x, y, noise, z, eps=1e-12, method="vfe"):
         y = np.asarray(y, dtype=np.float64).reshape(-1)
         d = np.broadcast_to(noise, y.shape).astype(np.float64)
         Kzz = self.k(z, z) + eps * np.eye(np.asarray(z).shape[0])
         Kxz = self.k(x, z)
+        if method == "fitc":
+            d = d + np.diag(self.k(x, x)) - np.sum(Kxz * np.linalg.solve(Kzz, Kxz.T).T, axis=1)
         Sigma = Kzz + Kxz.T @ (Kxz / d[:, None])
         b = np.linalg.solve(Sigma, Kxz.T @ ((y - self.mean(x)) / d))
         mean = lambda xs: self.mean(xs) + self.k(xs, z) @ b

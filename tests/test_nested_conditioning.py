@@ -106,3 +106,53 @@ def reg_posterior_layer_logpdf(reg, x_new, y_new):
 
     gpar = _construct_gpar(reg, reg.vs, reg.m, 1) | (reg.x, reg.y[:, :1], reg.w[:, :1])
     return gpar.logpdf(x_new, y_new[:, :1], np.ones((len(x_new), 1)))
+
+
+@pytest.mark.parametrize("method", ["vfe", "dtc", "fitc"])
+def test_inducing_point_approximations(engine, method):
+    """stheno's PseudoObsVFE / PseudoObsDTC / PseudoObsFITC: bound / log-density and posterior moments against the dense
+    closed forms; the analytic gradient of the VFE and DTC objectives against central differences."""
+    import torch
+
+    from gpar_amd.gp import PseudoObs, PseudoObsDTC, PseudoObsFITC
+    from gpar_amd.regression import GPARRegressor
+
+    cls = {"vfe": PseudoObs, "dtc": PseudoObsDTC, "fitc": PseudoObsFITC}[method]
+    kernel, spec, D = _setup(seed=2)
+    f = GP(kernel)
+    ref = gp_ref.Process.prior(spec)
+    obs = cls(f(D["z1"]), f(D["x1"], D["d1"]), D["y1"])
+    want = ref.vfe_bound(D["x1"], D["y1"], D["d1"], D["z1"], method=method)
+    assert float(obs.logpdf()) == pytest.approx(want, rel=1e-9)
+    post, rpost = f | obs, ref.condition_sparse(D["x1"], D["y1"], D["d1"], D["z1"], method=method)
+    np.testing.assert_allclose(post.mean(D["xs"]).cpu().numpy().reshape(-1), rpost.mean(D["xs"]), rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(post(D["xs"]).var().cpu().numpy(), rpost.k(D["xs"], D["xs"]), rtol=1e-7, atol=1e-9)
+
+    # through the regressor, and its training gradient (one layer: no inputs forwarded between layers)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 1, (40, 1))
+    y = np.sin(5 * x) + 0.05 * rng.standard_normal((40, 1))
+    reg = GPARRegressor(x_ind=np.linspace(0, 1, 7), scale=0.3, linear=True, nonlinear=True, noise=0.05, normalise_y=False, sparse_method=method)
+    base = float(reg.logpdf(x, y))
+    assert np.isfinite(base)
+    if method == "fitc":
+        reg.vs.requires_grad(True)
+        with pytest.raises(NotImplementedError):
+            reg.logpdf(torch.tensor(x), torch.tensor(y)).backward()
+        return
+    reg.vs.requires_grad(True)
+    reg.logpdf(torch.tensor(x), torch.tensor(y)).backward()
+    latents = reg.vs.get_vars()
+    grad = np.concatenate([(v.grad if v.grad is not None else torch.zeros_like(v)).numpy().reshape(-1) for v in latents])
+    reg.vs.requires_grad(False)
+    names = reg.vs.names
+    x0 = reg.vs.get_vector(names)
+    fd = np.zeros_like(x0)
+    for i in range(len(x0)):
+        for sgn in (+1, -1):
+            xi = x0.copy()
+            xi[i] += sgn * 1e-5
+            reg.vs.set_vector(xi, names)
+            fd[i] += sgn * float(reg.logpdf(x, y)) / 2e-5
+    reg.vs.set_vector(x0, names)
+    np.testing.assert_allclose(grad, fd, rtol=2e-5, atol=1e-6 * np.max(np.abs(fd)))
