@@ -19,7 +19,7 @@ GEMM_C_LOWER = 1
 GEMM_A_LOWER = 2
 POTRF_NO_LOOKAHEAD = 1
 POTRF_UNFUSED = 2
-WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE = 1, 2, 3, 4
+WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE, WS_INPUT_GRAD = 1, 2, 3, 4, 5
 GRAD_NACC = GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS
 
 ABI_VERSION = 2
@@ -84,6 +84,10 @@ SIGNATURES = {
         _c_int,
         [ctypes.POINTER(KSpec), _ptr, _ptr, _c_int, _c_int, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int,
          _ptr, _ptr],
+    ),
+    "gpar_gram_input_grad": (
+        _c_int,
+        [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr],
     ),
     "gpar_potrf": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "gpar_potrf_ex": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr]),

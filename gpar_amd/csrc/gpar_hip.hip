@@ -251,6 +251,38 @@ int gpar_gram_grad_cross(const gpar_kspec_t* ks, const double* z1, const double*
     return gram_grad_launch(ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2, dz, W, ldw, mode, workspace, nblocks, out, stream);
 }
 
+int gpar_gram_input_grad(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz,
+                         const double* W, int ldw, int mode, int nsplit, double* workspace, double* out, int ldo, void* stream) {
+    GPAR_API_GUARD;
+    if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS)
+        return GPAR_ARG_ERROR(3);
+    if (dz < 0 || dz > GPAR_MAX_DIMS || nsplit <= 0) return GPAR_ARG_ERROR(4);
+    if (mode != GPAR_GRAD_SYM && mode != GPAR_GRAD_RECT) return GPAR_ARG_ERROR(13);
+    if (mode == GPAR_GRAD_SYM && (n2 != n1 || z2 != z1)) return GPAR_ARG_ERROR(9);
+    {
+        int cnt[GPAR_MAX_TERMS] = {0};
+        for (int f = 0; f < ks->nfactors; ++f) {
+            const int t = ks->factor[f].term;
+            if (t < 0 || t >= ks->nterms || ++cnt[t] > GRAD_MAXF) return GPAR_ARG_ERROR(6);
+        }
+    }
+    if (n1 <= 0 || dz == 0) return 0;
+    if (n2 <= 0) {
+        for (int r = 0; r < n1; ++r) GPAR_HIP_TRY(hipMemsetAsync(out + (size_t)r * ldo, 0, sizeof(double) * dz, (hipStream_t)stream));
+        return 0;
+    }
+    const size_t lds = ((size_t)2 * dz * GRAM_LD + (size_t)GRAM_T * dz) * sizeof(double);
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&gram_input_grad_kernel), 160 * 1024));
+    if (lds > 160 * 1024) return GPAR_ARG_ERROR(7);
+    hipLaunchKernelGGL(gram_input_grad_kernel, dim3(gpar_ceil_div(n1, GRAM_T), nsplit), dim3(256), lds, (hipStream_t)stream, *ks, z1, n1,
+                       ldz1, z2, n2, ldz2, dz, W, ldw, mode, nsplit, workspace);
+    const long long total = (long long)n1 * dz;
+    hipLaunchKernelGGL(gram_input_grad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)workspace, nsplit, n1, dz, out, ldo);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
 int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, void* stream) {
     GPAR_API_GUARD;
     if (N <= 0 || nf <= 0) return 0;
@@ -336,6 +368,7 @@ long long gpar_workspace_doubles(int op, int a, int b, int c) {
         case GPAR_WS_GEMV_T: return (long long)gemv_t_chunks(a) * (b > 0 ? b : 0);      /* rows, cols */
         case GPAR_WS_GRAM_GRAD: return (long long)(a > 0 ? a : 0) * GRAD_NACC;          /* nblocks */
         case GPAR_WS_CHOL_INVERSE: return (long long)a * b;                             /* n, ldx: the X matrix */
+        case GPAR_WS_INPUT_GRAD: return (long long)a * b * (c > 1 ? c : 1);             /* n1, dz, nsplit */
         default: return -1;
     }
 }

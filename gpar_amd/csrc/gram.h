@@ -459,6 +459,152 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(gpar_kspec_t ks, const d
         partial[(size_t)blockIdx.x * GRAD_NACC + k] = ((acc[k] + acc[GRAD_NACC + k]) + acc[2 * GRAD_NACC + k]) + acc[3 * GRAD_NACC + k];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Gradient with respect to the INPUTS (in feature space): for a weight matrix W over pairs (a, b),
+//     out[a][q] = sum_b W(a, b) * d k(z1_a, z2_b) / d z1_a[q]
+//               = sum_b W(a, b) * rest_f(a, b) * dphi_f/ds(a, b) * 2 (z1_a[q] - z2_b[q])     (EQ / RQ factor f holding feature q)
+//               = sum_b W(a, b) * rest_f(a, b) * z2_b[q]                                      (linear factor)
+// with rest_f = coef * prod_{f' != f} phi_f'.  What torch autograd computes in the reference when a layer's inputs are
+// themselves functions of hyper-parameters - posterior means fed forward by `replace` / `impute` / inducing points under
+// `fit(fix=False)` (gpar/regression.py:447-456, gpar/model.py:291-322) - and what moving inducing points needs.
+//   mode GPAR_GRAD_RECT: W is n1 x n2;   GPAR_GRAD_SYM: z2 == z1 and W is symmetric, given by its lower triangle.
+// One workgroup per (64-row block, column split): it walks the 64-column tiles of its split, every thread a 4 x 4 patch;
+// row sums are reduced over the 16 lanes that share the rows and accumulated in LDS [64][dz]; splits are summed in order.
+__global__ __launch_bounds__(256) void gram_input_grad_kernel(gpar_kspec_t ks, const double* __restrict__ z1, int n1, int ldz1,
+                                                              const double* __restrict__ z2, int n2, int ldz2, int dz,
+                                                              const double* __restrict__ W, int ldw, int mode, int nsplit,
+                                                              double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    const int dzl = dz > 0 ? dz : 1;
+    double* Za = gsm;
+    double* Zb = Za + (size_t)dzl * GRAM_LD;
+    double* acc = Zb + (size_t)dzl * GRAM_LD;   // [64][dzl]
+    const int t = threadIdx.x;
+    const int tx = t & 15, ty = t >> 4;
+    const int bm = blockIdx.x, split = blockIdx.y;
+    const int row0 = bm * GRAM_T;
+    const int nt2 = (n2 + GRAM_T - 1) / GRAM_T;
+    for (int i = t; i < GRAM_T * dzl; i += 256) acc[i] = 0.0;
+    for (int idx = t; idx < GRAM_T * dz; idx += 256) {
+        const int r = idx / dz, d = idx - r * dz;
+        Za[d * GRAM_LD + r] = (row0 + r < n1) ? z1[(size_t)(row0 + r) * ldz1 + d] : 0.0;
+    }
+    for (int bn = split; bn < nt2; bn += nsplit) {
+        const int col0 = bn * GRAM_T;
+        __syncthreads();
+        for (int idx = t; idx < GRAM_T * dz; idx += 256) {
+            const int r = idx / dz, d = idx - r * dz;
+            Zb[d * GRAM_LD + r] = (col0 + r < n2) ? z2[(size_t)(col0 + r) * ldz2 + d] : 0.0;
+        }
+        __syncthreads();
+        double w[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0 + 4 * ty + i, col = col0 + 4 * tx + j;
+                double v = 0.0;
+                if (row < n1 && col < n2) {
+                    if (mode == GPAR_GRAD_SYM) v = (col <= row) ? W[(size_t)row * ldw + col] : W[(size_t)col * ldw + row];
+                    else v = W[(size_t)row * ldw + col];
+                }
+                w[i][j] = v;
+            }
+        int f0 = 0;
+        for (int term = 0; term < ks.nterms; ++term) {
+            int nf = 0;
+            while (f0 + nf < ks.nfactors && ks.factor[f0 + nf].term == term) ++nf;
+            const double coef = ks.coef[term];
+            double phi[GRAD_MAXF][4][4], sv[GRAD_MAXF][4][4];
+#pragma unroll
+            for (int ff = 0; ff < GRAD_MAXF; ++ff) {
+                if (ff < nf) {
+                    const gpar_factor_t fa = ks.factor[f0 + ff];
+                    double s[4][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[i][j] = 0.0;
+                    for (int d = fa.off; d < fa.off + fa.nd; ++d) {
+                        double za[4], zb[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) za[i] = Za[d * GRAM_LD + 4 * ty + i];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) zb[j] = Zb[d * GRAM_LD + 4 * tx + j];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (fa.type == GPAR_K_LINEAR) s[i][j] = fma(za[i], zb[j], s[i][j]);
+                                else { const double df = za[i] - zb[j]; s[i][j] = fma(df, df, s[i][j]); }
+                            }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { sv[ff][i][j] = s[i][j]; phi[ff][i][j] = gram_nonlin(fa.type, s[i][j], fa.alpha); }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { sv[ff][i][j] = 0.0; phi[ff][i][j] = 1.0; }
+                }
+            }
+#pragma unroll
+            for (int ff = 0; ff < GRAD_MAXF; ++ff) {
+                if (ff >= nf) continue;
+                const gpar_factor_t fa = ks.factor[f0 + ff];
+                double g[4][4];   // W * rest * (d phi / d s * 2  for EQ / RQ,  1 for linear)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        double rest = coef;
+#pragma unroll
+                        for (int f2 = 0; f2 < GRAD_MAXF; ++f2)
+                            if (f2 != ff) rest *= phi[f2][i][j];
+                        if (fa.type == GPAR_K_EQ) g[i][j] = -w[i][j] * rest * phi[ff][i][j];
+                        else if (fa.type == GPAR_K_RQ) g[i][j] = -w[i][j] * rest * phi[ff][i][j] / (1.0 + sv[ff][i][j] / (2.0 * fa.alpha));
+                        else g[i][j] = w[i][j] * rest;
+                    }
+                for (int d = fa.off; d < fa.off + fa.nd; ++d) {
+                    double za[4], zb[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) za[i] = Za[d * GRAM_LD + 4 * ty + i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) zb[j] = Zb[d * GRAM_LD + 4 * tx + j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double p = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) p = fma(g[i][j], fa.type == GPAR_K_LINEAR ? zb[j] : za[i] - zb[j], p);
+                        // the 16 lanes tx = 0 .. 15 of one ty are consecutive lanes: reduce within the 16-lane row
+#pragma unroll
+                        for (int off = 8; off > 0; off >>= 1) p += __shfl_xor(p, off, 16);
+                        if (tx == 0) acc[(4 * ty + i) * dzl + d] += p;
+                    }
+                }
+            }
+            f0 += nf;
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < GRAM_T * dz; i += 256) {
+        const int r = i / dz, d = i - r * dz;
+        if (row0 + r < n1) partial[((size_t)split * n1 + row0 + r) * dz + d] = acc[r * dzl + d];
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_input_grad_reduce_kernel(const double* __restrict__ partial, int nsplit, int n1, int dz,
+                                                                     double* __restrict__ out, int ldo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)n1 * dz) return;
+    const int r = (int)(i / dz), d = (int)(i - (long long)r * dz);
+    double s = 0.0;
+    for (int q = 0; q < nsplit; ++q) s += partial[((size_t)q * n1 + r) * dz + d];
+    out[(size_t)r * ldo + d] = s;
+}
+
 __global__ __launch_bounds__(256) void gram_grad_reduce_kernel(const double* __restrict__ partial, int nblocks,
                                                                double* __restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

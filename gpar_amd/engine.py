@@ -75,6 +75,10 @@ class HipEngine:
     # ---- memory ----------------------------------------------------------------------------------
     def tensor(self, x):
         if isinstance(x, torch.Tensor):
+            if x.requires_grad and torch.is_grad_enabled():
+                # an input that is a function of hyper-parameters (a posterior mean fed forward under fit(fix=False)):
+                # the graph is kept, the layer objects differentiate through it (gp._PosteriorMean, gp._LogMarginal)
+                return x.to(device=self.device, dtype=torch.float64)
             return x.detach().to(device=self.device, dtype=torch.float64)
         return torch.as_tensor(x, dtype=torch.float64).to(self.device)
 
@@ -157,6 +161,45 @@ class HipEngine:
         raw = hip.gram_grad(ck, z, zd, W).cpu().numpy()
         return self._grads_from_moments(ck, raw, 0.5)
 
+    def kernel_diag_input_grads(self, ck, x, w):
+        """d / d x of  sum_a w_a k(x_a, x_a)  (n x width).  EQ / RQ factors are 1 on the diagonal: only products of linear
+        factors move with x."""
+        x = self._mat(x).detach()
+        out = torch.zeros(x.shape[0], ck.width, dtype=torch.float64, device=x.device)
+        z = hip.featurize(ck, x)
+        fs = ck.fspec
+        by_term = {}
+        for ti, fi, off, nd in ck.layout:
+            if ck.kernel.terms[ti].factors[fi].type == "linear":
+                by_term.setdefault(ti, []).append((off, nd))
+        for ti, factors in by_term.items():
+            coef = float(ck.kspec.coef[ti])
+            values = [torch.sum(z[:, off : off + nd] ** 2, dim=1) for off, nd in factors]
+            for k, (off, nd) in enumerate(factors):
+                rest = w * coef
+                for k2, v in enumerate(values):
+                    if k2 != k:
+                        rest = rest * v
+                for q in range(off, off + nd):
+                    out[:, int(fs.col[q])] += rest * 2.0 * z[:, q] * float(fs.inv_scale[q])  # linear factors are never periodic
+        return out
+
+    def kernel_grads_weighted(self, ck, x1, x2, W, sym=False):
+        """sum_ab W_ab dK(x1_a, x2_b)/dtheta for every kernel parameter (full sums, no factor 1/2).  sym: x2 is x1 and W is
+        symmetric, given by its lower triangle."""
+        x1 = self._mat(x1)
+        f1 = hip.featurize(ck, x1)
+        periodic = self._periodic(ck)
+        d1 = hip.featurize_dfreq(ck, x1) if periodic else None
+        if sym:
+            raw = hip.gram_grad_cross(ck, f1, d1, f1, d1, self._mat(W), hip.GRAD_SYM)
+        else:
+            x2 = self._mat(x2)
+            f2 = hip.featurize(ck, x2)
+            d2 = hip.featurize_dfreq(ck, x2) if periodic else None
+            raw = hip.gram_grad_cross(ck, f1, d1, f2, d2, self._mat(W), hip.GRAD_RECT)
+        return self._grads_from_moments(ck, raw.cpu().numpy(), 1.0)
+
     def kernel_grads_vfe(self, ck, x, z, W_fu, W_uu, wdiag):
         """sum_aj W_fu[a, j] dK(x_a, z_j) + sum_ij W_uu[i, j] dK(z_i, z_j) + sum_a wdiag[a] dk(x_a, x_a) for every kernel
         parameter (the gradient of the inducing-point bound, gp.PseudoObs.gradients): three fused device passes whose
@@ -170,6 +213,28 @@ class HipEngine:
         raw = raw + hip.gram_grad_cross(ck, fz, dz, fz, dz, self._mat(W_uu), hip.GRAD_SYM)
         raw = raw + hip.gram_grad_cross(ck, fx, dx, fx, dx, wdiag.contiguous(), hip.GRAD_DIAG)
         return self._grads_from_moments(ck, raw.cpu().numpy(), 1.0)
+
+    def kernel_input_grads(self, ck, x1, x2, W, sym=False):
+        """d / d x1 of  sum_ab W_ab k(x1_a, x2_b)  as an n1 x width matrix (x2 held fixed).  `sym`: x2 is x1, W is symmetric
+        and given by its lower triangle, and BOTH arguments move: d / d x of sum_ab W_ab k(x_a, x_b) = 2 sum_b W_ab d_1 k.
+        The device pass works in feature space (csrc/gram.h: gram_input_grad_kernel); the chain back to design-matrix
+        columns - 1 / scale, and the derivative of the periodic embedding - is applied here."""
+        x1 = self._mat(x1)
+        z1 = hip.featurize(ck, x1)
+        z2 = z1 if sym else hip.featurize(ck, self._mat(x2))
+        gz = hip.gram_input_grad(ck, z1, z2, self._mat(W), hip.GRAD_SYM if sym else hip.GRAD_RECT)
+        out = torch.zeros(x1.shape[0], ck.width, dtype=torch.float64, device=x1.device)
+        fs = ck.fspec
+        for q in range(ck.dz):
+            c, inv, freq, embed = int(fs.col[q]), float(fs.inv_scale[q]), float(fs.freq[q]), int(fs.embed[q])
+            if embed == _lib.EMBED_SIN:
+                dz = inv * freq * torch.cos(freq * x1[:, c])
+            elif embed == _lib.EMBED_COS:
+                dz = -inv * freq * torch.sin(freq * x1[:, c])
+            else:
+                dz = inv
+            out[:, c] += gz[:, q] * dz
+        return 2.0 * out if sym else out
 
     @staticmethod
     def _periodic(ck):

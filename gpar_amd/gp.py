@@ -178,18 +178,51 @@ def kernel_parameters(kernel):
     return out
 
 
+def _param_grads(params, shapes, grads, scale):
+    """Gradient dictionary of an engine pass (coef / per-factor scales, periods, alpha) -> one tensor per kernel parameter."""
+    outs = []
+    for (kind, ti, fi, tensor), shape in zip(params, shapes):
+        if kind == "coef":
+            val = np.asarray(grads["coef"][ti])
+        else:
+            val = np.asarray(grads["factors"][ti][fi][kind], dtype=np.float64)
+        numel = int(np.prod(shape)) if shape else 1
+        if val.size != numel:
+            val = val.sum()  # a scalar parameter broadcast over several features
+        outs.append(torch.as_tensor(np.asarray(val, dtype=np.float64) * scale, dtype=tensor.dtype).reshape(shape).to(tensor.device))
+    return outs
+
+
+def _add_grads(a, b):
+    """Sum of two engine gradient dictionaries of the same kernel."""
+    if a is None:
+        return b
+    out = {"coef": [x + y for x, y in zip(a["coef"], b["coef"])], "factors": []}
+    for fa, fb in zip(a["factors"], b["factors"]):
+        out["factors"].append([{k: (None if ga[k] is None else np.asarray(ga[k]) + np.asarray(gb[k])) for k in ga} for ga, gb in zip(fa, fb)])
+    return out
+
+
+def _shaped_noise_grad(noise_grad, shape, device):
+    numel = int(np.prod(shape)) if shape else 1
+    out = noise_grad.sum().reshape(shape) if numel == 1 else noise_grad.reshape(shape)
+    return out.to(device)
+
+
 class _LogMarginal(torch.autograd.Function):
-    """log N(y; 0, K_theta + D) - or, for inducing-point observations, the VFE bound - as a differentiable function of
-    the kernel parameters and the noise vector.
+    """log N(y; 0, K_theta(X) + D) - or, for inducing-point observations, the VFE / DTC bound - as a differentiable
+    function of the kernel parameters, the noise vector and (when they are themselves functions of hyper-parameters: fed
+    forward posterior means, or inducing inputs being optimised) the inputs X and inducing inputs Z.
 
     Forward is the fused Gram + augmented Cholesky on the device.  Backward is analytic:
-    with W = alpha alpha^T - K^-1,  d/dtheta = 1/2 sum_ab W_ab dK_ab/dtheta; K^-1 comes from L (TRSM on the
-    identity + SYRK) and all kernel-parameter sums are produced by one fused pass over W on the device.
-    torch then chains these through whatever produced the parameters (bound transforms, products, noise / w).
+    with W = alpha alpha^T - K^-1,  d/dtheta = 1/2 sum_ab W_ab dK_ab/dtheta and d/dX = 1/2 d/dX sum_ab W_ab k(x_a, x_b);
+    K^-1 comes from L (TRSM on the identity + SYRK), the kernel-parameter sums from one fused pass over W, the input
+    gradients from a second one (csrc/gram.h).  torch then chains these through whatever produced the arguments (bound
+    transforms, noise / w, `_update_inputs`' concatenations, `_PosteriorMean`).
     """
 
     @staticmethod
-    def forward(ctx, obs, noise, *tensors):
+    def forward(ctx, obs, noise, X, Z, *tensors):
         ctx.obs = obs
         ctx.noise_shape = None if noise is None else tuple(noise.shape)
         ctx.shapes = [tuple(t.shape) for t in tensors]
@@ -202,21 +235,37 @@ class _LogMarginal(torch.autograd.Function):
         gval = float(g)
         out_noise = None
         if ctx.noise_shape is not None:
-            ng = noise_grad * gval
-            numel = int(np.prod(ctx.noise_shape)) if ctx.noise_shape else 1
-            out_noise = ng.sum().reshape(ctx.noise_shape) if numel == 1 else ng.reshape(ctx.noise_shape)
-            out_noise = out_noise.to(obs._noise_device)
-        outs = []
-        for (kind, ti, fi, tensor), shape in zip(obs._params, ctx.shapes):
-            if kind == "coef":
-                val = np.asarray(grads["coef"][ti])
-            else:
-                val = np.asarray(grads["factors"][ti][fi][kind], dtype=np.float64)
-            numel = int(np.prod(shape)) if shape else 1
-            if val.size != numel:
-                val = val.sum()  # a scalar parameter broadcast over several features
-            outs.append(torch.as_tensor(np.asarray(val, dtype=np.float64) * gval, dtype=tensor.dtype).reshape(shape).to(tensor.device))
-        return (None, out_noise, *outs)
+            out_noise = _shaped_noise_grad(noise_grad * gval, ctx.noise_shape, obs._noise_device)
+        gX = gZ = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            gX, gZ = obs.input_gradients(ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+            gX = None if gX is None else gX * gval
+            gZ = None if gZ is None else gZ * gval
+        return (None, out_noise, gX, gZ, *_param_grads(obs._params, ctx.shapes, grads, gval))
+
+
+class _PosteriorMean(torch.autograd.Function):
+    """Posterior mean of `f | obs` at x* as a differentiable function of the kernel parameters, the noise, the training
+    inputs X, the inducing inputs Z and x* itself: the column `_update_inputs` feeds to the next layer
+    (reference gpar/model.py:291-322, differentiated by torch autograd there when fit(fix=False) trains layers jointly).
+    Backward: `Obs.mean_gradients` / `PseudoObs.mean_gradients` (weighted kernel-derivative passes on the device)."""
+
+    @staticmethod
+    def forward(ctx, obs, xs_value, xs, noise, X, Z, *tensors):
+        ctx.obs, ctx.xs = obs, xs_value
+        ctx.noise_shape = None if noise is None else tuple(noise.shape)
+        ctx.noise_device = None if noise is None else noise.device
+        ctx.shapes = [tuple(t.shape) for t in tensors]
+        ctx.params = kernel_parameters(obs.base.kernel)
+        return obs.mean_at(obs.base._pts(xs_value))
+
+    @staticmethod
+    def backward(ctx, g):
+        obs = ctx.obs
+        need = ctx.needs_input_grad
+        out = obs.mean_gradients(ctx.xs, g.detach().reshape(-1), want_xs=need[2], want_x=need[4], want_z=need[5])
+        g_noise = None if ctx.noise_shape is None else _shaped_noise_grad(out["noise"], ctx.noise_shape, ctx.noise_device)
+        return (None, None, out.get("xs"), g_noise, out.get("x"), out.get("z"), *_param_grads(ctx.params, ctx.shapes, out["params"], 1.0))
 
 
 class Measure:
@@ -302,7 +351,18 @@ class GP:
 
     # ---- public ------------------------------------------------------------------------------------
     def mean(self, x):
-        return self._mean_at(self._pts(x))
+        eng = self.engine
+        xm = _as_matrix(eng, x)
+        if self.is_posterior and torch.is_grad_enabled() and not self._obs.base.is_posterior and xm.shape[0] > 0 and self._obs.fdd.n > 0:
+            obs = self._obs
+            params = kernel_parameters(self.kernel)
+            noise = obs.fdd.noise_arg if _needs_grad(obs.fdd.noise_arg) else None
+            X = obs.fdd.x if obs.fdd.x.requires_grad else None
+            Z = obs.u.x if isinstance(obs, PseudoObs) and obs.u.x.requires_grad else None
+            xs = xm if xm.requires_grad else None
+            if params or noise is not None or X is not None or Z is not None or xs is not None:
+                return _PosteriorMean.apply(obs, xm.detach(), xs, noise, X, Z, *[p[3] for p in params])
+        return self._mean_at(self._pts(xm))
 
     def marginal_moments(self, x, noise=None):
         """(mean, variance) of f(x) (+ noise) point by point - no n* x n* covariance is formed."""
@@ -452,10 +512,11 @@ class Obs:
         if not self.base.is_posterior and torch.is_grad_enabled():
             params = kernel_parameters(self.base.kernel)
             noise = self.fdd.noise_arg if _needs_grad(self.fdd.noise_arg) else None
-            if params or noise is not None:
+            X = self.fdd.x if self.fdd.x.requires_grad else None
+            if params or noise is not None or X is not None:
                 self._params = params
                 self._noise_device = None if noise is None else noise.device
-                return _LogMarginal.apply(self, noise, *[p[3] for p in params])
+                return _LogMarginal.apply(self, noise, X, None, *[p[3] for p in params])
         return self.factor().logpdf()
 
     def _value(self):
@@ -468,8 +529,43 @@ class Obs:
         a = fac.alpha()
         eng.gemm(a, a, ta=True, alpha=1.0, beta=-1.0, out=W, c_lower=True)
         ck, _ = self.fdd.features()
-        grads = eng.kernel_grads(ck, self.fdd.x, W)
+        grads = eng.kernel_grads(ck, self.fdd.x.detach(), W)
+        self._W = W
         return 0.5 * torch.diagonal(W).clone(), grads
+
+    def input_gradients(self, want_x, want_z):
+        """d logpdf / d X = 1/2 d/dX sum_ab W_ab k(x_a, x_b) (both arguments of k move)."""
+        ck, _ = self.fdd.features()
+        gX = 0.5 * self.eng.kernel_input_grads(ck, self.fdd.x.detach(), None, self._W, sym=True) if want_x else None
+        return gX, None
+
+    def mean_gradients(self, xs, g, want_xs=True, want_x=True, want_z=False):
+        """Gradients of  g^T mean(xs),  mean(xs) = K(xs, X) alpha, alpha = S^-1 y, S = K(X, X) + D:
+             d = sum_ab (g_a alpha_b) dK(xs_a, X_b) - sum_bc (beta_b alpha_c) dS_bc,      beta = S^-1 K(X, xs) g."""
+        eng, fac = self.eng, self.factor()
+        ck, z = self.fdd.features()
+        X = self.fdd.x.detach()
+        n = self.fdd.n
+        alpha = fac.alpha().reshape(-1)  # n
+        pxs = self.base._pts(xs)
+        Ks = eng.gram(ck, pxs.z, z)  # n* x n
+        beta = eng.gemv_t(Ks, g).reshape(1, n).clone()
+        eng.trsm_rlt_(fac.L, beta)
+        eng.trsm_rln_(fac.L, beta)
+        beta = beta.reshape(-1)
+        W_rect = eng.new_matrix(xs.shape[0], n)
+        W_rect.copy_(g[:, None] * alpha[None, :])
+        W_sym = eng.new_matrix(n, n)
+        W_sym.copy_(-0.5 * (beta[:, None] * alpha[None, :] + alpha[:, None] * beta[None, :]))
+        params = _add_grads(eng.kernel_grads_weighted(ck, xs, X, W_rect), eng.kernel_grads_weighted(ck, X, None, W_sym, sym=True))
+        out = {"params": params, "noise": -beta * alpha}
+        if want_xs:
+            out["xs"] = eng.kernel_input_grads(ck, xs, X, W_rect)
+        if want_x:
+            Wt = eng.new_matrix(n, xs.shape[0])
+            Wt.copy_(W_rect.T)
+            out["x"] = eng.kernel_input_grads(ck, X, xs, Wt) + eng.kernel_input_grads(ck, X, None, W_sym, sym=True)
+        return out
 
     def adopt_factor(self):
         """Install an empty factor whose buffer the caller fills (a factor computed by another rank)."""
@@ -707,10 +803,12 @@ class PseudoObs:
         if not self.base.is_posterior and torch.is_grad_enabled():
             params = kernel_parameters(self.base.kernel)
             noise = self.fdd.noise_arg if _needs_grad(self.fdd.noise_arg) else None
-            if params or noise is not None:
+            X = self.fdd.x if self.fdd.x.requires_grad else None
+            Z = self.u.x if self.u.x.requires_grad else None
+            if params or noise is not None or X is not None or Z is not None:
                 self._params = params
                 self._noise_device = None if noise is None else noise.device
-                return _LogMarginal.apply(self, noise, *[p[3] for p in params])
+                return _LogMarginal.apply(self, noise, X, Z, *[p[3] for p in params])
         return self._value()
 
     elbo = logpdf
@@ -775,8 +873,73 @@ class PseudoObs:
             noise_grad = 0.5 * (alpha * alpha - 1.0 / d + eng.rownorm2(E) / d)
             wdiag = torch.zeros_like(d)
         ck = self.fdd.pts().ck
-        grads = eng.kernel_grads_vfe(ck, self.fdd.x, self.u.x, T, Wuu, wdiag)
+        grads = eng.kernel_grads_vfe(ck, self.fdd.x.detach(), self.u.x.detach(), T, Wuu, wdiag)
+        self._weights = (T, Wuu, wdiag)
         return noise_grad, grads
+
+    def input_gradients(self, want_x, want_z):
+        """dF / dX and dF / dZ from the same three weight arrays as the parameter gradients:
+        F' = sum W_fu dK(X, Z) + sum W_uu dK(Z, Z) + sum wdiag dk(x, x)."""
+        eng = self.eng
+        T, Wuu, wdiag = self._weights
+        ck = self.fdd.pts().ck
+        X, Z = self.fdd.x.detach(), self.u.x.detach()
+        gX = gZ = None
+        if want_x:
+            gX = eng.kernel_input_grads(ck, X, Z, T) + eng.kernel_diag_input_grads(ck, X, wdiag)
+        if want_z:
+            Tt = eng.new_matrix(Z.shape[0], X.shape[0])
+            Tt.copy_(T.T)
+            gZ = eng.kernel_input_grads(ck, Z, X, Tt) + eng.kernel_input_grads(ck, Z, None, Wuu, sym=True)
+        return gX, gZ
+
+    def mean_gradients(self, xs, g, want_xs=True, want_x=True, want_z=True):
+        """Gradients of  g^T mean(xs),  mean(xs) = K(xs, Z) v,  v = Sigma^-1 K_zx D^-1 y,  Sigma = K_zz + K_zx D^-1 K_xz.
+        With h = Sigma^-1 K(Z, xs) g, p = K_xz v (the mean at X) and q = K_xz h:
+            d = sum (g v^T) dK(xs, Z) + sum W_fu dK(X, Z) + sum W_uu dK(Z, Z) - sum_a q_a (y_a - p_a) / d_a^2 dd_a,
+            W_fu = ((y - p) / d) h^T - (q / d) v^T,     W_uu = -1/2 (h v^T + v h^T).
+        (VFE / DTC: the effective noise is the observation noise; FITC's depends on the kernel and is not covered.)"""
+        if self.method == "fitc":
+            raise NotImplementedError("differentiating the posterior mean of the FITC approximation is not implemented")
+        eng, st = self.eng, self._compute()
+        ck = self.fdd.pts().ck
+        X, Z = self.fdd.x.detach(), self.u.x.detach()
+        n, M = self.fdd.n, self.u.n
+        d = self.fdd.noise
+        v = st["v"].reshape(-1)
+        pxs = self.base._pts(xs)
+        Ksz = eng.gram(ck, pxs.z, self.u.pts().z)  # n* x M
+        Kxz = eng.gram(ck, self.fdd.pts().z, self.u.pts().z)  # n x M
+        h = eng.gemv_t(Ksz, g).reshape(1, M).clone()
+        eng.trsm_rlt_(st["Lz"], h)
+        eng.trsm_rlt_(st["La"], h)
+        eng.trsm_rln_(st["La"], h)
+        eng.trsm_rln_(st["Lz"], h)
+        h = h.reshape(-1)
+        p_ = eng.gemm(Kxz, v.reshape(1, M), tb=True).reshape(-1)
+        q_ = eng.gemm(Kxz, h.reshape(1, M), tb=True).reshape(-1)
+        resid = self.y.reshape(-1).detach() - p_
+        W_sz = eng.new_matrix(xs.shape[0], M)
+        W_sz.copy_(g[:, None] * v[None, :])
+        W_fu = eng.new_matrix(n, M)
+        W_fu.copy_((resid / d)[:, None] * h[None, :] - (q_ / d)[:, None] * v[None, :])
+        W_uu = eng.new_matrix(M, M)
+        W_uu.copy_(-0.5 * (h[:, None] * v[None, :] + v[:, None] * h[None, :]))
+        params = _add_grads(eng.kernel_grads_weighted(ck, xs, Z, W_sz), eng.kernel_grads_weighted(ck, X, Z, W_fu))
+        params = _add_grads(params, eng.kernel_grads_weighted(ck, Z, None, W_uu, sym=True))
+        out = {"params": params, "noise": -q_ * resid / (d * d)}
+        if want_xs:
+            out["xs"] = eng.kernel_input_grads(ck, xs, Z, W_sz)
+        if want_x:
+            out["x"] = eng.kernel_input_grads(ck, X, Z, W_fu)
+        if want_z:
+            A_ = eng.new_matrix(M, xs.shape[0])
+            A_.copy_(W_sz.T)
+            B_ = eng.new_matrix(M, n)
+            B_.copy_(W_fu.T)
+            out["z"] = (eng.kernel_input_grads(ck, Z, xs, A_) + eng.kernel_input_grads(ck, Z, X, B_)
+                        + eng.kernel_input_grads(ck, Z, None, W_uu, sym=True))
+        return out
 
     # ---- the posterior's corrections (any base process) -----------------------------------------------
     def _P(self, p):

@@ -31,6 +31,7 @@ __all__ = [
     "trmv_lower",
     "gram_grad",
     "gram_grad_cross",
+    "gram_input_grad",
     "chol_inverse",
 ]
 
@@ -405,6 +406,29 @@ def gram_grad_cross(ck, z1, zd1, z2, zd2, W, mode, nblocks=None):
             out.data_ptr(), stream_ptr(z1.device),
         ),
         "gpar_gram_grad_cross",
+    )
+    return out
+
+
+def gram_input_grad(ck, z1, z2, W, mode):
+    """out[a][q] = sum_b W(a, b) d k(z1_a, z2_b) / d z1_a[q] (feature space; n1 x dz).  mode GRAD_RECT (W: n1 x n2) or
+    GRAD_SYM (z2 is z1, W symmetric, lower triangle read)."""
+    lib = _lib.load()
+    _check_mat(z1, "z1")
+    _check_mat(z2, "z2")
+    _check_mat(W, "W")
+    n1, n2 = z1.shape[0], z2.shape[0]
+    out = alloc_matrix(n1, max(ck.dz, 1), z1.device, zero=True)
+    if ck.dz == 0 or n1 == 0:
+        return out
+    row_blocks = (n1 + 63) // 64
+    col_tiles = max(1, (n2 + 63) // 64)
+    nsplit = max(1, min(col_tiles, 512 // max(row_blocks, 1)))
+    work = torch.empty(max(1, lib.gpar_workspace_doubles(_lib.WS_INPUT_GRAD, n1, ck.dz, nsplit)), dtype=torch.float64, device=z1.device)
+    _lib.check(
+        lib.gpar_gram_input_grad(ctypes.byref(ck.kspec), z1.data_ptr(), n1, _ld(z1), z2.data_ptr(), n2, _ld(z2), ck.dz, W.data_ptr(),
+                                 _ld(W), int(mode), nsplit, work.data_ptr(), out.data_ptr(), _ld(out), stream_ptr(z1.device)),
+        "gpar_gram_input_grad",
     )
     return out
 

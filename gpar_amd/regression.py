@@ -121,7 +121,11 @@ def _model_generator(vs, m, pi, scale, scale_tie, per, per_period, per_scale, pe
 
 
 def _construct_gpar(reg, vs, m, p):
-    gpar = GPAR(replace=reg.replace, impute=reg.impute, x_ind=reg.x_ind, sparse_method=reg.sparse_method)
+    x_ind = reg.x_ind
+    if x_ind is not None and getattr(reg, "_x_ind_trainable", False):
+        # inducing inputs as a variable of the store (an addition: the reference keeps them fixed, todo.tasks:5)
+        x_ind = vs.get(init=np.asarray(x_ind, dtype=np.float64), name="x_ind")
+    gpar = GPAR(replace=reg.replace, impute=reg.impute, x_ind=x_ind, sparse_method=reg.sparse_method)
     for pi in range(p):
         gpar = gpar.add_layer(_model_generator(vs, m, pi, **reg.model_config))
     return gpar
@@ -219,12 +223,19 @@ class GPARRegressor:
             self.y = normalise_y(self.y)
         self.is_conditioned = True
 
-    def fit(self, x, y, w=None, greedy=False, fix=True, **kw_args):
+    def fit(self, x, y, w=None, greedy=False, fix=True, optimise_x_ind=False, **kw_args):
         """Train layer by layer with L-BFGS-B on the negative log marginal likelihood; keyword arguments go to
-        `minimise_l_bfgs_b` (`iters`, `f_calls`, `trace`).  (reference regression.py:391-459)"""
+        `minimise_l_bfgs_b` (`iters`, `f_calls`, `trace`).  (reference regression.py:391-459)
+
+        `optimise_x_ind` (an addition, off by default; the reference's todo.tasks:5): the inducing inputs `x_ind` become the
+        variable "x_ind" of `self.vs` and are trained along with every layer's hyper-parameters (the gradient with respect to
+        inducing locations comes from the same device passes as the joint gradient of `fix=False`)."""
         self.condition(x, y, w)
         if greedy:
             raise NotImplementedError("Greedy search is not implemented yet.")
+        if optimise_x_ind and not self.sparse:
+            raise ValueError("optimise_x_ind needs inducing points (x_ind)")
+        self._x_ind_trainable = bool(optimise_x_ind) or getattr(self, "_x_ind_trainable", False)
         eng = get_engine()
         x_dev, y_dev, w_dev = eng.tensor(self.x), eng.tensor(self.y), eng.tensor(self.w)
         y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
@@ -239,11 +250,18 @@ class GPARRegressor:
             def objective(vs):
                 gpar = _construct_gpar(self, vs, self.m, pi + 1)
                 if fix:
-                    return -gpar.logpdf(fixed_x, y_cached, None, only_last_layer=True, outputs=[pi], x_ind=fixed_x_ind)
+                    x_ind_pi = fixed_x_ind
+                    if optimise_x_ind:  # the m base columns are the variable; the columns appended by earlier layers stay fixed
+                        x_ind_pi = torch.cat([eng.tensor(vs["x_ind"]), fixed_x_ind[:, self.m :]], dim=1)
+                    return -gpar.logpdf(fixed_x, y_cached, None, only_last_layer=True, outputs=[pi], x_ind=x_ind_pi)
                 return -gpar.logpdf(x_dev, y_cached, None, only_last_layer=False)
 
             names = [f"{pi}/*"] if fix else [f"{i}/*" for i in range(pi + 1)]
+            if optimise_x_ind:
+                names = names + ["x_ind"]
             minimise_l_bfgs_b(objective, self.vs, names=names, **kw_args)
+            if optimise_x_ind and "x_ind" in self.vs:
+                self.x_ind = self.vs["x_ind"].detach().clone()
 
         from .parallel import layers_train_independently
 

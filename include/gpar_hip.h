@@ -145,6 +145,16 @@ int gpar_gram_grad_cross(const gpar_kspec_t* ks, const double* z1, const double*
                          const double* zd2, int n2, int ldz2, int dz, const double* W, int ldw, int mode, double* workspace,
                          int nblocks, double* out, void* stream);
 
+/* Gradient with respect to the inputs, in feature space:  out[a][q] = sum_b W(a, b) d k(z1_a, z2_b) / d z1_a[q]  for the
+ * pair weights W (GPAR_GRAD_RECT: n1 x n2;  GPAR_GRAD_SYM: z2 == z1, W symmetric, lower triangle read).  out: n1 x dz (ldo);
+ * workspace: gpar_workspace_doubles(GPAR_WS_INPUT_GRAD, n1, dz, nsplit) doubles; nsplit >= 1 column splits (summed in order).
+ * The caller chains d z / d x (1 / scale, and the derivative of the periodic embedding) back to the design-matrix columns.
+ * [torch autograd through mlkernels' pairwise distances when a layer's inputs are posterior means of earlier layers -
+ *  fit(fix=False) with replace / impute / inducing points: gpar/regression.py:447-456 through gpar/model.py:291-322 - and
+ *  the derivative with respect to inducing-point locations (the reference's todo.tasks:5)] */
+int gpar_gram_input_grad(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz,
+                         const double* W, int ldw, int mode, int nsplit, double* workspace, double* out, int ldo, void* stream);
+
 /* Partial right-looking blocked Cholesky of the leading `nf` columns of the symmetric N x N matrix A
  * (lower triangle).  On exit A[:, :nf] holds L (N x nf, lower trapezoid) and A[nf:, nf:] holds the Schur
  * complement A22 - L21 L21^T.  nf == N is the ordinary potrf.  logdet (device, optional) += 2*sum log L_jj;
@@ -213,6 +223,7 @@ int gpar_unpack_lower(const double* in, int n, double* A, int lda, void* stream)
 #define GPAR_WS_GEMV_T 2
 #define GPAR_WS_GRAM_GRAD 3
 #define GPAR_WS_CHOL_INVERSE 4
+#define GPAR_WS_INPUT_GRAD 5   /* (n1, dz, nsplit)  gpar_gram_input_grad */
 long long gpar_workspace_doubles(int op, int a, int b, int c);
 /* Standard normals from Philox-4x32-10 + Box-Muller: out[r][c], element index = r*cols + c in the stream
  * identified by (seed, offset).   [B.randn in Normal.sample] */

@@ -38,6 +38,7 @@ def _np(t):
     return t.detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)
 
 
+
 class OracleEngine:
     name = "oracle"
 
@@ -51,6 +52,8 @@ class OracleEngine:
     # ---- memory ----------------------------------------------------------------------------------
     def tensor(self, x):
         if isinstance(x, torch.Tensor):
+            if x.requires_grad and torch.is_grad_enabled():
+                return x.to(device="cpu", dtype=torch.float64)
             return x.detach().to(device="cpu", dtype=torch.float64)
         return torch.as_tensor(np.asarray(x, dtype=np.float64))
 
@@ -88,6 +91,42 @@ class OracleEngine:
         w = np.tril(_np(W))
         w = w + np.tril(w, -1).T
         return ok.kernel_grads(ck.spec, _np(x), w)
+
+    def kernel_input_grads(self, ck, x1, x2, W, sym=False):
+        if sym:
+            w = np.tril(_np(W))
+            w = w + np.tril(w, -1).T
+            return torch.from_numpy(2.0 * ok.kernel_input_grads(ck.spec, _np(x1), _np(x1), w))
+        return torch.from_numpy(ok.kernel_input_grads(ck.spec, _np(x1), _np(x2), _np(W)))
+
+    def kernel_diag_input_grads(self, ck, x, w):
+        """d / d x of sum_a w_a k(x_a, x_a), by central differences of the kernel diagonal (exact to ~1e-9: the diagonal is a
+        polynomial in x for the kernels of this package)."""
+        xs, ws = _np(x), _np(w).reshape(-1)
+        out = np.zeros_like(xs)
+        for c in range(xs.shape[1]):
+            step = np.zeros_like(xs)
+            step[:, c] = 1e-5
+            out[:, c] = ws * (ok.gram_diag(ck.spec, xs + step) - ok.gram_diag(ck.spec, xs - step)) / 2e-5
+        return torch.from_numpy(out)
+
+    def kernel_grads_weighted(self, ck, x1, x2, W, sym=False):
+        """sum_ab W_ab dK(x1_a, x2_b)/dtheta for every kernel parameter (full sums).  sym: x2 is x1, W symmetric (lower)."""
+        if sym:
+            w = np.tril(_np(W))
+            w = w + np.tril(w, -1).T
+            half = ok.kernel_grads(ck.spec, _np(x1), w)
+        else:
+            a, b = _np(x1), _np(x2)
+            n1, n2 = a.shape[0], b.shape[0]
+            big = np.zeros((n1 + n2, n1 + n2))
+            big[:n1, n1:] = 0.5 * _np(W)
+            big[n1:, :n1] = 0.5 * _np(W).T
+            half = ok.kernel_grads(ck.spec, np.concatenate([a, b], axis=0), big)
+        out = {"coef": [2.0 * c for c in half["coef"]], "factors": []}
+        for fgrads in half["factors"]:
+            out["factors"].append([{k: (None if v is None else 2.0 * np.asarray(v)) for k, v in g.items()} for g in fgrads])
+        return out
 
     def kernel_grads_vfe(self, ck, x, z, W_fu, W_uu, wdiag):
         """sum_aj W_fu[a, j] dK(x_a, z_j) + sum_ij W_uu[i, j] dK(z_i, z_j) + sum_a wdiag[a] dk(x_a, x_a) for every kernel

@@ -470,3 +470,36 @@ def test_unfused_factorisation_path_agrees(env, n):
     assert int(ia.item()) == 0 and int(ib.item()) == 0
     assert abs(float(la) - float(lb)) <= 1e-12 * abs(float(la))
     assert (torch.tril(A) - torch.tril(B)).abs().max() <= 1e-11
+
+
+@pytest.mark.parametrize("m,p_cols", [(1, []), (2, [2]), (3, [3, 4, 5])])
+@pytest.mark.parametrize("n1,n2", [(5, 9), (64, 64), (130, 77), (300, 513)])
+def test_kernel_input_gradients_match_oracle(env, m, p_cols, n1, n2):
+    """gpar_gram_input_grad (+ the host chain from features to design-matrix columns) against the oracle's explicit
+    derivative matrices: rectangular weights, and the symmetric case where both arguments of the kernel move; and the
+    weighted parameter sums used by the posterior-mean gradient."""
+    torch, hip, dev, to_dev = env
+    from gpar_amd.engine import HipEngine
+    from gpar_amd.kernels import compile_kernel
+    from oracle import kernels as ok
+
+    eng = HipEngine()
+    width = m + (max(p_cols) - m + 1 if p_cols else 0)
+    rng = np.random.default_rng(n1 + 3 * n2 + m)
+    x1, x2 = rng.uniform(-1, 1, (n1, width)), rng.uniform(-1, 1, (n2, width))
+    W = rng.standard_normal((n1, n2))
+    Ws = rng.standard_normal((n1, n1))
+    Ws = Ws + Ws.T
+    for name, k in _kernels(m, p_cols).items():
+        if name == "zero":
+            continue
+        ck = compile_kernel(k, width)
+        spec = ok.spec_to_dict(k.resolve(width))
+        got = eng.kernel_input_grads(ck, to_dev(x1), to_dev(x2), to_dev(W)).cpu().numpy()
+        ref = ok.kernel_input_grads(spec, x1, x2, W)
+        scale = max(1.0, np.max(np.abs(ref)))
+        assert np.max(np.abs(got - ref)) <= 1e-11 * scale, name
+        lower = to_dev(np.tril(Ws) + np.triu(np.full((n1, n1), np.nan), 1))
+        got = eng.kernel_input_grads(ck, to_dev(x1), None, lower, sym=True).cpu().numpy()
+        ref = 2.0 * ok.kernel_input_grads(spec, x1, x1, Ws)
+        assert np.max(np.abs(got - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref))), name

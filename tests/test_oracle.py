@@ -274,3 +274,23 @@ def regressor_from_case(case):
         else:
             reg.vs.bnd(init=value, name=name)
     return reg
+
+
+@pytest.mark.parametrize("config", [dict(linear=True, nonlinear=True), dict(linear=True, nonlinear=True, rq=True, per=True, input_linear=True)])
+def test_kernel_input_gradients_match_finite_differences(config):
+    """oracle/kernels.kernel_input_grads (the reference for the device pass gram_input_grad_kernel): derivative of
+    sum_ab W_ab k(x1_a, x2_b) with respect to every entry of x1, against central differences."""
+    rng = np.random.default_rng(3)
+    m, pi = 2, 2
+    spec = _random_layer(rng, config, m=m, pi=pi, p=3)
+    x1, x2 = rng.uniform(-1, 1, (7, m + pi)), rng.uniform(-1, 1, (5, m + pi))
+    W = rng.standard_normal((7, 5))
+    got = ok.kernel_input_grads(spec, x1, x2, W)
+    fd = np.zeros_like(x1)
+    for a in range(x1.shape[0]):
+        for c in range(x1.shape[1]):
+            for sgn in (+1, -1):
+                xp = x1.copy()
+                xp[a, c] += sgn * 1e-6
+                fd[a, c] += sgn * np.sum(W * ok.gram(spec, xp, x2)) / 2e-6
+    np.testing.assert_allclose(got, fd, rtol=1e-6, atol=1e-8)

@@ -381,3 +381,77 @@ def test_paper_workload_stand_ins(engine, name, size):
     assert out["gpar"]["finite"] and out["independent"]["finite"]
     g, i = np.nanmean(out["gpar"]["smse"]), np.nanmean(out["independent"]["smse"])
     assert g < i, (name, out)
+
+
+@pytest.mark.parametrize("kw,missing", [
+    (dict(impute=True, replace=False), True),                                        # imputed posterior means
+    (dict(impute=True, replace=True), True),                                         # every forwarded value is a posterior mean
+    (dict(impute=False, replace=False, x_ind=np.linspace(0, 1, 7)), False),          # inducing inputs extended by posterior means
+    (dict(impute=True, replace=True, x_ind=np.linspace(0, 1, 7)), True),             # examples/paper/air_temp.py
+    (dict(impute=True, replace=True, x_ind=np.linspace(0, 1, 7), sparse_method="dtc", rq=True), True),
+])
+def test_joint_gradient_is_exact_through_forwarded_posterior_means(engine, kw, missing):
+    """fit(fix=False) differentiates the JOINT objective (reference gpar/regression.py:447-456): when imputation, `replace` or
+    inducing points feed posterior means of layer j into the inputs of layers > j, those columns depend on layer j's
+    hyper-parameters and torch autograd differentiates through `_update_inputs` (gpar/model.py:291-322) there.  Here the
+    chain runs through `gp._PosteriorMean` and the input gradients of `gp._LogMarginal`; checked against central
+    differences of the joint log-likelihood in every dependent regime (round 1 treated the columns as constants)."""
+    rng = np.random.default_rng(17)
+    n, p = 26, 3
+    x = np.sort(rng.uniform(0, 1, n))
+    y = np.stack([np.sin(5 * x), np.cos(4 * x) + 0.4 * np.sin(5 * x) ** 2, x * np.sin(5 * x)], axis=1) + 0.05 * rng.standard_normal((n, p))
+    if missing:
+        y[rng.random((n, p)) < 0.2] = np.nan
+        y[0] = [0.1, 0.9, 0.0]
+    reg = GPARRegressor(scale=0.3, linear=True, linear_scale=3.0, nonlinear=True, noise=0.05, normalise_y=False, **kw)
+    with torch.no_grad():
+        reg.logpdf(x, y)
+    reg.vs.requires_grad(True)
+    reg.logpdf(torch.tensor(x), torch.tensor(y)).backward()
+    latents = reg.vs.get_vars()
+    grad = np.concatenate([(v.grad if v.grad is not None else torch.zeros_like(v)).numpy().reshape(-1) for v in latents])
+    reg.vs.requires_grad(False)
+    names = reg.vs.names
+    x0 = reg.vs.get_vector(names)
+    fd = np.zeros_like(x0)
+    for i in range(len(x0)):
+        for sgn in (+1, -1):
+            xi = x0.copy()
+            xi[i] += sgn * 1e-5
+            reg.vs.set_vector(xi, names)
+            fd[i] += sgn * float(reg.logpdf(x, y)) / 2e-5
+    reg.vs.set_vector(x0, names)
+    np.testing.assert_allclose(grad, fd, rtol=5e-5, atol=2e-6 * np.max(np.abs(fd)))
+
+
+def test_inducing_inputs_can_be_optimised(engine):
+    """`fit(..., optimise_x_ind=True)` (the reference's todo.tasks:5): the gradient of the bound with respect to the inducing
+    locations against central differences, and a fit that moves them to a better bound."""
+    rng = np.random.default_rng(23)
+    x = np.sort(rng.uniform(0, 1, 40))
+    y = np.stack([np.sin(8 * x), np.cos(6 * x) * x], axis=1) + 0.05 * rng.standard_normal((40, 2))
+    z0 = np.linspace(0.3, 0.7, 6)  # deliberately bunched in the middle
+    reg = GPARRegressor(x_ind=z0, scale=0.2, linear=True, nonlinear=True, noise=0.05, normalise_y=False)
+    reg._x_ind_trainable = True
+    with torch.no_grad():
+        before = float(reg.logpdf(x, y))
+    assert "x_ind" in reg.vs
+    reg.vs.requires_grad(True, "x_ind")
+    reg.logpdf(torch.tensor(x), torch.tensor(y)).backward()
+    grad = reg.vs.get_vars("x_ind")[0].grad.numpy().reshape(-1).copy()
+    reg.vs.requires_grad(False)
+    z = reg.vs.get_vector(["x_ind"])
+    fd = np.zeros_like(z)
+    for i in range(len(z)):
+        for sgn in (+1, -1):
+            zi = z.copy()
+            zi[i] += sgn * 1e-6
+            reg.vs.set_vector(zi, ["x_ind"])
+            fd[i] += sgn * float(reg.logpdf(x, y)) / 2e-6
+    reg.vs.set_vector(z, ["x_ind"])
+    np.testing.assert_allclose(grad, fd, rtol=1e-4, atol=1e-5 * np.max(np.abs(fd)))
+    reg.fit(x, y, iters=15, optimise_x_ind=True)
+    after = float(reg.logpdf(x, y))
+    moved = np.asarray(reg.x_ind).reshape(-1)
+    assert after > before + 1.0
+    assert moved.min() < 0.25 or moved.max() > 0.75  # they spread out over the data
