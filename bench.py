@@ -181,7 +181,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
             "traffic": pmc_traffic(n, m, p),
-            "traffic_source": "profiles/r01_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)",
+            "traffic_source": "profiles/r02_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)",
             "launches": launches.value,
             "flop_per_launch": flops.value / launches.value,
             "avg_launch_ms": ms.value / launches.value,
@@ -261,7 +261,7 @@ def main():
 def pmc_traffic(n, m, p):
     """HBM bytes per trailing-SYRK launch from the committed PMC passes of this very workload (null for any other
     workload: counters cannot be collected from inside the timed process)."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_bench_pmc_traffic.json")
     if (n, m, p) != (16384, 4, 8) or not os.path.exists(path):
         return None
     with open(path) as f:

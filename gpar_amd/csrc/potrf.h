@@ -572,7 +572,10 @@ static int trsm_rlt_run(const double* L, int n, int ldl, double* B, int nrows, i
 // column r, so block [c0, c1) only involves rows < c1 - the n^3 of a full solve becomes n^3 / 3.
 static int trsm_rlt_run2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int upper_tri, hipStream_t stream) {
     if (nrows <= 0) return 0;
-    const int NB = env_int("GPAR_TRSM_NB", n >= 4096 ? 512 : (n >= 1024 ? 256 : 64));
+    // Block width: 512-column fused blocks (panel2.h) + one GEMM update each from n = 1024 on.  (Measured on the inducing-point
+    // solve of C4, K_xz L_z^-T with 65536 x 1024: 256-column blocks 20.4 ms per evaluation, 512 19.9, the whole factor in one
+    // launch 20.6 - the flops are the same and the block kernel runs them at the same ~55 % of the matrix-core rate.)
+    const int NB = env_int("GPAR_TRSM_NB", n >= 1024 ? 512 : 64);
     const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && NB > 64 && gpar_aligned16(L) && gpar_aligned16(B) && (ldl % 2 == 0) && (ldb % 2 == 0);
     // As in gpar_potrf, while many columns remain two blocks are solved back to back (the second after a narrow update of
     // its own columns by the first) and everything to the right then gets ONE rank-2*NB update instead of two rank-NB ones.

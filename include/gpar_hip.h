@@ -19,9 +19,12 @@
  *     (elements between consecutive rows).  For symmetric matrices the LOWER triangle is authoritative;
  *     the strict upper triangle is never read; it may hold anything on entry and is SCRATCH: gpar_potrf keeps the
  *     hand-off flags of its persistent panel kernel there (two rows of 56 words per 512-column panel).
- *   - Plain pointers and sizes only.  The caller owns every buffer, including workspace; the library
- *     never allocates or frees device memory and never synchronises the device, so every call is
- *     asynchronous on `stream` (a hipStream_t passed as void*).
+ *   - Plain pointers and sizes only.  The caller owns every buffer, including workspace
+ *     (gpar_workspace_doubles gives the sizes); the library never allocates or frees device MEMORY.  Every compute call
+ *     only enqueues work on `stream` (a hipStream_t passed as void*) and returns; nothing synchronises the host except
+ *     gpar_profile_read (a measurement aid).  What the library does create, lazily and once per device: one low-priority
+ *     side stream per caller stream and a ring of events (gpar_potrf's look-ahead), the events of the profile hook, and the
+ *     per-kernel dynamic-LDS attributes - so the first call on a device must not be made inside a stream capture.
  *   - Return value: 0 = launched OK; < 0 = -(hipError_t) or -1000-x for argument errors.  Numerical
  *     failure (non-positive pivot) is reported LAPACK-style through a device-side `info` word
  *     (1-based index of the first bad pivot, 0 = success) so that no host sync is forced.
@@ -162,8 +165,10 @@ int gpar_gram_input_grad(const gpar_kspec_t* ks, const double* z1, int n1, int l
  * Appending rows below K turns this one routine into the whole exact-GP computation:
  *   row  [y^T, 0]      -> z^T = (L^-1 y)^T and -|z|^2          (log marginal likelihood, gpar/model.py:226)
  *   rows [K_*x, K_**]  -> V^T = K_*x L^-T and K_** - V^T V      (posterior covariance, gpar/model.py:264,270)
- * Requires the whole GPU to itself while it runs (its panel kernel spins on in-launch hand-offs between co-resident
- * workgroups; every spin is bounded and a timeout is reported as info = -77).
+ * Its panel kernel hands tiles between workgroups of one launch; a workgroup only ever waits for workgroups with a LOWER
+ * block index (dispatched before it), so nothing depends on all of them being co-resident and several factorisations may
+ * run at once from different streams; every wait is bounded all the same, and a timeout is reported as info = -77
+ * (results invalid: retry with GPAR_POTRF_UNFUSED).
  * [matrix.cholesky -> torch.linalg.cholesky (LAPACK dpotrf)] */
 int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, void* stream);
 /* The same with hints.  GPAR_POTRF_NO_LOOKAHEAD: the caller keeps three or more factorisations in flight on streams of its

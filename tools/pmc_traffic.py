@@ -14,7 +14,10 @@ KERNEL = "gemm_f64_kernel<false, true, 1,"  # both tile forms: every trailing-up
 
 
 def read(dirname, counter):
-    rows = list(csv.DictReader(open(dirname + "/pmc_counter_collection.csv")))
+    import glob
+
+    path = sorted(glob.glob(dirname + "/**/*counter_collection.csv", recursive=True))[0]
+    rows = list(csv.DictReader(open(path)))
     return [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and KERNEL in r["Kernel_Name"]]
 
 
