@@ -210,6 +210,493 @@ __device__ __forceinline__ void p2_strip(const double* __restrict__ Cs, pan_d4 (
     }
 }
 
+// Right-looking Cholesky of the 64 x 64 LDS tile T (lower), 8-column blocks pipelined over the waves like pnl_diag (wave 0:
+// lane = row, brings block jb up to date with block jb - 1 and factors it; waves 1-3 apply block jb - 1 to the columns to
+// the right), with the pivot chain cut down to what the next pivot depends on.  Wave 0 issues in order, so every
+// instruction between two pivots is on the chain whether or not the next pivot needs it (pnl_diag: ~35 per pivot):
+//   * the wave-uniform coefficients of the rank-1 update are read (v_readlane) from the UNSCALED column while the
+//     reciprocal square root is still in flight, and the update uses (a_ij / d) a_kj instead of l_ij l_kj;
+//   * d^-1/2: v_rsq_f64 (2^-23 relative) + ONE cubic step  r (1 + e (1/2 + 3/8 e)),  e = 1 - d r^2  (error ~ e^3);
+//   * the diagonal element is d r like every other element of the column (no separate square root), the positivity check is
+//     one ballot per tile (a non-positive pivot turns into NaN / inf and stays), the log-determinant reads the diagonal
+//     back from LDS at the end;
+//   * wave 0 keeps its previous block's 8 values in registers instead of re-reading them from LDS.
+// One 8-column block of wave 0's share: acc = this lane's 8 values of block jb; UPDATE: the rank-8 update of block jb - 1
+// (prev = this lane's values of that block, coefficients from LDS) is applied column by column INSIDE the pivot loop - the
+// eight independent multiply-adds of column j + 1 are issued in the shadow of pivot j's reciprocal square root.
+template <bool UPDATE>
+__device__ __forceinline__ void p2_diag_block(const double* __restrict__ T, int jb, int i, double (&acc)[8], const double (&prev)[8]) {
+    pan_d2 c[8][4];
+    if (UPDATE) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const pan_d2* cs = reinterpret_cast<const pan_d2*>(&T[(8 * jb + k) * PNL_LD + 8 * (jb - 1)]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[k][q] = cs[q];
+        }
+    }
+    const pan_d2* src = reinterpret_cast<const pan_d2*>(&T[i * PNL_LD + 8 * jb]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
+    auto update_col = [&](int k) {
+        double u0 = acc[k], u1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { u0 = fma(-prev[2 * q], c[k][q][0], u0); u1 = fma(-prev[2 * q + 1], c[k][q][1], u1); }
+        acc[k] = u0 + u1;
+    };
+    if (UPDATE) update_col(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double d = gpar_readlane_f64(acc[j], 8 * jb + j);
+        double r = __builtin_amdgcn_rsq(d);
+        double a[8];
+#pragma unroll
+        for (int j2 = j + 1; j2 < 8; ++j2) a[j2] = gpar_readlane_f64(acc[j], 8 * jb + j2);
+        if (UPDATE && j + 1 < 8) update_col(j + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const double e = fma(-d * r, r, 1.0);
+        r = fma(r * e, fma(0.375, e, 0.5), r);
+        const double tc = acc[j] * (r * r);
+#pragma unroll
+        for (int j2 = j + 1; j2 < 8; ++j2) acc[j2] = fma(-tc, a[j2], acc[j2]);
+        acc[j] = acc[j] * r;
+    }
+}
+
+template <bool STAMP = false>
+__device__ __forceinline__ void p2_diag(double* __restrict__ T, int col0, const PanelArgs& p, int t, long long* __restrict__ st = nullptr) {
+    const int i = t & 63, w = t >> 6;
+    double prev[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) prev[q] = 0.0;
+    for (int jb = 0; jb < 8; ++jb) {
+        if (w == 0) {
+            if (STAMP && t == 0) st[3 * jb] = (long long)__builtin_readcyclecounter();
+            double acc[8];
+            if (jb == 0) p2_diag_block<false>(T, jb, i, acc, prev);
+            else p2_diag_block<true>(T, jb, i, acc, prev);
+            pan_d2* dst = reinterpret_cast<pan_d2*>(&T[i * PNL_LD + 8 * jb]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) prev[q] = acc[q];
+            if (STAMP && t == 0) st[3 * jb + 2] = (long long)__builtin_readcyclecounter();
+        } else if (jb > 0) {
+            pnl_rank8(T, T, jb - 1, i, 8 * jb + 8 + (w - 1), 3);
+        }
+        __syncthreads();
+    }
+    if (t < 64) {
+        const double mydiag = T[i * PNL_LD + i];
+        const unsigned long long badmask = __ballot(!(mydiag > 0.0));
+        double ld = 2.0 * log(mydiag);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ld += __shfl_xor(ld, off, 64);
+        if (t == 0) {
+            if (p.logdet) atomicAdd(p.logdet, ld);
+            if (badmask && p.info) atomicCAS(p.info, 0, col0 + __builtin_ctzll(badmask) + 1);
+        }
+    }
+}
+
+// ---- third form of the diagonal-tile factorisation: wave-uniform coefficients through DPP -----------------------------
+// A lone wave issues one instruction every ~4.3 cycles whatever it is (tools/ubench_dp_latency.hip: dependent v_fma_f64
+// 4.3 cycles, v_rsq_f64 16), so the pivot chain of pnl_diag / p2_diag is bound by its INSTRUCTION COUNT (~34 per pivot,
+// ~60 with the rank-8 update interleaved), and a third of those are v_readlane pairs and LDS broadcast reads that only
+// move wave-uniform coefficients.  Here they come with the arithmetic: the 16 lanes of a DPP row are
+//     lanes 0-7:  rows 8 jb .. 8 jb + 7 of the tile (the block's own diagonal rows, replicated in every DPP row),
+//     lanes 8-15: eight other rows (wave w < 2, DPP row R: rows 32 w + 8 R .. + 7),
+// and  v_fmac_f64_dpp acc, -x row_newbcast:k, y  multiplies by lane k's x of the same DPP row - the coefficient
+// L[8 jb + k][.] - in the instruction that uses it (DP-ALU DPP supports exactly this control).  Two waves factor (both
+// carry the replicated rows, so they never talk), the other two apply the previous block's rank-8 update to the columns to
+// the right on the matrix cores (16 x 16 blocks, K = 8).  Per pivot: v_rsq_f64 + one cubic correction (5) + scaling +
+// (7 - j) multiply-adds = ~16 issue slots; the rank-8 update of the block's own columns is 64 more, without LDS reads.
+// The bodies are generated (tools/gen_diag_asm.py) and kept as one asm statement per block so that the hazards of DPP
+// (two wait states after a vector write of any register it reads) and of transcendental results (one) are under control.
+// GENERATED by tools/gen_diag_asm.py -------------------------------------------------------------------------------
+#define P3_ASM_FIRST \
+    "s_nop 1\n" \
+    "v_mov_b64_dpp %8, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %13, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %0, %0, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %1, -%0, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %2, -%0, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%0, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%0, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%0, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%0, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%0, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %1 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %13, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %1, %1, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %2, -%1, %1 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%1, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%1, %1 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%1, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%1, %1 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%1, %1 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %13, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %2, %2, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %3, -%2, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%2, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%2, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%2, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%2, %2 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %3 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %13, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %3, %3, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %4, -%3, %3 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%3, %3 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%3, %3 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%3, %3 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %13, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %4, %4, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %5, -%4, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%4, %4 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%4, %4 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %13, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %5, %5, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %6, -%5, %5 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%5, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "s_nop 0\n" \
+    "v_mov_b64_dpp %8, %6 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %13, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %6, %6, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %7, -%6, %6 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "s_nop 1\n" \
+    "v_mov_b64_dpp %8, %7 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %13, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %7, %7, %9\n"
+
+#define P3_ASM_UPDATE \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %0, -%13, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %1, -%13, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %2, -%13, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%13, %13 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%13, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%13, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%13, %13 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%13, %13 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %0, -%14, %14 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %1, -%14, %14 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %2, -%14, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%14, %14 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%14, %14 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%14, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%14, %14 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%14, %14 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %0, -%15, %15 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %1, -%15, %15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %2, -%15, %15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%15, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%15, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%15, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%15, %15 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%15, %15 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %0, -%16, %16 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %1, -%16, %16 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %2, -%16, %16 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%16, %16 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%16, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%16, %16 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%16, %16 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%16, %16 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %0, -%17, %17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %1, -%17, %17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %2, -%17, %17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%17, %17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%17, %17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%17, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%17, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%17, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %0, -%18, %18 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %1, -%18, %18 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %2, -%18, %18 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%18, %18 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%18, %18 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%18, %18 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%18, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%18, %18 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %0, -%19, %19 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %1, -%19, %19 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %2, -%19, %19 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%19, %19 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%19, %19 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%19, %19 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%19, %19 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%19, %19 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %0, -%20, %20 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %1, -%20, %20 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %2, -%20, %20 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%20, %20 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%20, %20 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%20, %20 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%20, %20 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%20, %20 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %21, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %0, %0, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %1, -%0, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %2, -%0, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%0, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%0, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%0, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%0, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%0, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %1 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %21, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %1, %1, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %2, -%1, %1 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %3, -%1, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%1, %1 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%1, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%1, %1 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%1, %1 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %21, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %2, %2, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %3, -%2, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %4, -%2, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%2, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%2, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%2, %2 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %3 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %21, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %3, %3, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %4, -%3, %3 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %5, -%3, %3 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%3, %3 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%3, %3 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %21, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %4, %4, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %5, -%4, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %6, -%4, %4 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%4, %4 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_mov_b64_dpp %8, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %21, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %5, %5, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %6, -%5, %5 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp %7, -%5, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "s_nop 0\n" \
+    "v_mov_b64_dpp %8, %6 row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %21, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %6, %6, %9\n" \
+    "s_nop 1\n" \
+    "v_fmac_f64_dpp %7, -%6, %6 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "s_nop 1\n" \
+    "v_mov_b64_dpp %8, %7 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+    "v_rsq_f64 %9, %8\n" \
+    "s_nop 0\n" \
+    "v_mul_f64 %11, %8, %9\n" \
+    "v_fma_f64 %10, -%11, %9, 1.0\n" \
+    "v_fma_f64 %12, %10, %21, 0.5\n" \
+    "v_mul_f64 %11, %9, %10\n" \
+    "v_fma_f64 %9, %11, %12, %9\n" \
+    "v_mul_f64 %7, %7, %9\n"
+
+// END GENERATED -----------------------------------------------------------------------------------------------------
+
+template <bool UPDATE>
+__device__ __forceinline__ void p3_diag_block(double (&acc)[8], const double (&prev)[8]) {
+    double D, R, E, T1, T2;
+    const double c375 = 0.375;
+    if (UPDATE) {
+        asm volatile(P3_ASM_UPDATE
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                       "=&v"(D), "=&v"(R), "=&v"(E), "=&v"(T1), "=&v"(T2)
+                     : "v"(prev[0]), "v"(prev[1]), "v"(prev[2]), "v"(prev[3]), "v"(prev[4]), "v"(prev[5]), "v"(prev[6]), "v"(prev[7]),
+                       "v"(c375));
+    } else {
+        asm volatile(P3_ASM_FIRST
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                       "=&v"(D), "=&v"(R), "=&v"(E), "=&v"(T1), "=&v"(T2)
+                     : "v"(c375));
+    }
+}
+
+template <bool STAMP = false>
+__device__ __forceinline__ void p3_diag(double* __restrict__ T, int col0, const PanelArgs& p, int t, long long* __restrict__ st = nullptr) {
+    const int lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    double held[8];   // threads 0-7: the replicated rows' results of the previous round, not yet in LDS (see below)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) held[q] = 0.0;
+    for (int jb = 0; jb < 8; ++jb) {
+        // (wave 1 owns rows 32-63: nothing of it is left below the last block)
+        if (w == 0 || (w == 1 && jb < 7)) {
+            if (STAMP && t == 0) st[3 * jb] = (long long)__builtin_readcyclecounter();
+            const int row = l15 < 8 ? 8 * jb + l15 : 32 * w + 8 * lk + (l15 - 8);
+            double acc[8], prev[8];
+            const pan_d2* src = reinterpret_cast<const pan_d2*>(&T[row * PNL_LD + 8 * jb]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
+            if (jb > 0) {
+                const pan_d2* ps = reinterpret_cast<const pan_d2*>(&T[row * PNL_LD + 8 * (jb - 1)]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const pan_d2 v = ps[q]; prev[2 * q] = v[0]; prev[2 * q + 1] = v[1]; }
+                // The replicated rows of round jb - 1 go to LDS only now.  The two factoring waves do not synchronise inside a
+                // round, and beside a trailing-update workgroup one of them can fall a whole round behind: written at the end
+                // of round jb - 1, these rows reached LDS before wave 1 had read them at the START of that round (observed:
+                // one tile in ~2000, only with a SYRK co-resident).  Nobody reads them during round jb.
+                if (t < 8) {
+                    pan_d2* hd = reinterpret_cast<pan_d2*>(&T[(8 * (jb - 1) + t) * PNL_LD + 8 * (jb - 1)]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hd[q] = pan_d2{held[2 * q], held[2 * q + 1]};
+                }
+                p3_diag_block<true>(acc, prev);
+            } else {
+                p3_diag_block<false>(acc, prev);
+            }
+            // rows below the block: written by their only holder (rows above it carry the strict upper triangle's scratch
+            // through the same arithmetic and are dropped); the replicated rows: held by wave 0's first DPP row - in the last
+            // round, which wave 1 sits out, written at once
+            if (l15 >= 8 ? (row > 8 * jb + 7) : (t < 8 && jb == 7)) {
+                pan_d2* dst = reinterpret_cast<pan_d2*>(&T[row * PNL_LD + 8 * jb]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) held[q] = acc[q];
+            if (STAMP && t == 0) st[3 * jb + 2] = (long long)__builtin_readcyclecounter();
+        } else if (w >= 2 && jb > 0) {
+            // T[mi][ni] -= L[mi][jb - 1] L[ni][jb - 1]^T  (K = 8) for the 16 x 16 blocks that reach columns >= 8 jb + 8
+            const int c0 = 8 * jb + 8, kb = 8 * (jb - 1) + lk;
+            int idx = 0;
+            for (int ni = c0 >> 4; ni < 4; ++ni)
+                for (int mi = ni; mi < 4; ++mi, ++idx) {
+                    if ((idx & 1) != (w & 1)) continue;
+                    double* C = &T[(16 * mi + lk) * PNL_LD + 16 * ni + l15];
+                    pan_d4 c = pan_d4{C[0], C[4 * PNL_LD], C[8 * PNL_LD], C[12 * PNL_LD]};
+                    const double* a = &T[(16 * mi + l15) * PNL_LD + kb];
+                    const double* b = &T[(16 * ni + l15) * PNL_LD + kb];
+                    const double a0 = -a[0], a1 = -a[4], b0 = b[0], b1 = b[4];
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+                    if (16 * ni + l15 >= c0) { C[0] = c[0]; C[4 * PNL_LD] = c[1]; C[8 * PNL_LD] = c[2]; C[12 * PNL_LD] = c[3]; }
+                }
+        }
+        __syncthreads();
+    }
+    if (t < 64) {
+        const double mydiag = T[lane * PNL_LD + lane];
+        const unsigned long long badmask = __ballot(!(mydiag > 0.0));
+        double ld = 2.0 * log(mydiag);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ld += __shfl_xor(ld, off, 64);
+        if (t == 0) {
+            if (p.logdet) atomicAdd(p.logdet, ld);
+            if (badmask && p.info) atomicCAS(p.info, 0, col0 + __builtin_ctzll(badmask) + 1);
+        }
+    }
+}
+
 // Tiles (mi, ni), mi >= ni, of a 64 x 64 lower triangle dealt over the four waves: slot q of wave w.
 //   w0: (0,0) (1,0) (2,0)    w1: (1,1) (2,1) (3,0)    w2: (2,2) (3,1)    w3: (3,3) (3,2)
 __device__ __forceinline__ int p2_dtile_m(int w, int q) { return q == 0 ? w : (w == 0 ? q : (w == 1 ? q + 1 : 3)); }
@@ -386,7 +873,11 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
             }
         __syncthreads();
         P2_STAMP(trow, 1);   // diagonal tile assembled
+#ifdef GPAR_EXPERIMENT_OLD_DIAG
         pnl_diag(Cs, r0, p, t);
+#else
+        p3_diag(Cs, r0, p, t);
+#endif
         __syncthreads();
         P2_STAMP(trow, 2);   // factored
         p2_inverse_blocks(Cs, w, lane);   // into four strictly upper 16 x 16 blocks of the tile (scratch by the ABI's convention)
