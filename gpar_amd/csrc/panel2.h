@@ -817,6 +817,12 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
             for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] = T[mi][v];
         __syncthreads();
         P2_STAMP(c, 4);   // strip done
+        // A team row block's last strip: its diagonal tile is requested BEFORE the write-through stores of X (memory
+        // operations return in order: requested behind them it would arrive with their acknowledgement) and rides out the
+        // accumulation below in 32 registers.
+        const bool last = TEAM && c == ncol - 1;
+        pan_d2 dt[8];
+        if (last) p2_gload(B, ldb, brows, r0, bc0 + 64 * trow, t, dt);
         p2_gstore(B, ldb, brows, r0, bc0 + 64 * c, Xs, t, TEAM);
         if (TEAM) {
             // D += X X^T for the tiles on and below the diagonal of this row block's diagonal tile
@@ -844,26 +850,27 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
                 if (w < 2) dacc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][2], fb[cur][2], dacc[2], 0, 0, 0);
             }
             P2_STAMP(c, 5);   // diagonal-tile accumulation done
-            // The diagonal tile is requested now, behind the write-through stores of X: memory operations return in order, so it
-            // arrives with their acknowledgement, which the publication has to wait for anyway (requested before the stores it
-            // would hold 32 registers through the accumulation; requested after the publication it costs a round trip).
-            const bool last = c == ncol - 1;
-            pan_d2 dt[8];
-            if (last) p2_gload(B, ldb, brows, r0, bc0 + 64 * trow, t, dt);
-            p2_publish(p, trow, (unsigned long long)c + 1);
-            if (last) p2_sstore(Cs, t, dt);   // parked in Cs: the triangle is dead, every wave is past the barrier above
+            if (!last) {
+                p2_publish(p, trow, (unsigned long long)c + 1);
+            } else {
+                // the tile is parked in Cs (the triangle is dead: every wave is past the barrier that ended the strip); X is
+                // published after the barrier that the assembly below needs anyway
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                p2_sstore(Cs, t, dt);
+            }
             P2_STAMP(c, 6);   // published
         }
     }
     if (TEAM) {
-        __syncthreads();
         P2_STAMP(trow, 0);
-        if (ncol == 0) {   // (otherwise the tile was requested under the last accumulation and is in Cs)
+        if (ncol == 0) {   // (otherwise the tile is in Cs already)
             pan_d2 dt[8];
             p2_gload(B, ldb, brows, r0, bc0 + 64 * trow, t, dt);
             p2_sstore(Cs, t, dt);
         }
         __syncthreads();
+        if (ncol > 0 && t == 0)   // every wave has drained its write-through stores of the last X
+            __hip_atomic_store(pnl_flag(p, trow), (unsigned long long)ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             if (q < 2 || w < 2) {
@@ -884,7 +891,8 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
         __syncthreads();
         {   // the lower triangle in 16-byte write-through stores (the pair that holds the diagonal element of an even row also
             // writes its right-hand neighbour: scratch - the progress words sit in row 0 from column 8 on, the inverses from
-            // column 32 on in rows 0 .. 31)
+            // column 32 on in rows 0 .. 31).  (Issued before the inverses are computed they only delayed the inverses' own
+            // stores: 1.56 -> 1.88 us for this stretch.)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int e = t + 256 * q;

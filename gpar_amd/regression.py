@@ -131,9 +131,19 @@ def _construct_gpar(reg, vs, m, p):
     return gpar
 
 
-def _init_weights(w, y):
+def _default_weights(rows, cols):
+    """The reference's default, a matrix of ones - made where it is used.  (A CPU `torch.ones` of 32768 elements or more
+    opens an OpenMP parallel region; its worker threads - one per host core - then spin, and in a container with a CPU
+    quota that throttles the process for tens of milliseconds: seen as one 60 ms evaluation in three at C4.)"""
+    from .engine import get_engine
+
+    return torch.ones(rows, cols, dtype=torch.float64, device=get_engine().device)
+
+
+def _init_weights(w, y, attribute=False):
     if w is None:
-        return torch.ones(*y.shape, dtype=torch.float64)
+        # (`condition` keeps the reference's attribute: a host tensor, made once)
+        return torch.ones(*y.shape, dtype=torch.float64) if attribute else _default_weights(*y.shape)
     return _uprank(_to_torch(w))
 
 
@@ -201,7 +211,7 @@ class GPARRegressor:
         """Store (and transform / normalise) the training data without training (reference regression.py:339-389)."""
         self.x = _uprank(_to_torch(x))
         self.y = self._transform_y(_uprank(_to_torch(y)))
-        self.w = _init_weights(w, self.y)
+        self.w = _init_weights(w, self.y, attribute=True)
         self.n, self.m = self.x.shape
         self.p = self.y.shape[1]
         if self.normalise_y:
@@ -304,7 +314,7 @@ class GPARRegressor:
         elif not posterior and p is None:
             raise ValueError("Must specify number of outputs to sample.")
         if w is None:
-            w = torch.ones(x.shape[0], self.p if posterior else p, dtype=torch.float64)
+            w = _default_weights(x.shape[0], self.p if posterior else p)
         else:
             w = _uprank(_to_torch(w))
         if posterior and conditioned is not None:

@@ -177,6 +177,35 @@ def test_concurrent_factorisations_complete_their_handoffs(hip, streams, n):
         assert torch.equal(torch.tril(a), ref)
 
 
+def test_factorisation_is_repeatable_beside_its_own_trailing_updates(hip):
+    """With look-ahead the panel kernel shares compute units with the trailing update, whose waves can hold a panel wave back
+    for a whole round of the diagonal-tile factorisation; the waves of a workgroup that do not synchronise inside a round
+    must not depend on running in step (a write-after-read race of that kind showed up once in ~2000 tiles, and only here).
+    48 repetitions of an augmented n = 8192 factorisation: identical bits, and the same bits with look-ahead off."""
+    from gpar_amd import hip as H
+
+    dev = hip.device
+    n = 8192
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(n, 3, generator=g, dtype=torch.float64).to(dev)
+    A0 = H.alloc_matrix(n + 1, n + 1, dev, zero=True)
+    A0[:n, :n] = torch.exp(-0.5 * torch.cdist(x, x) ** 2 / 0.25)
+    A0[:n, :n].diagonal().add_(0.1)
+    A0[n, :n] = torch.sin(6.0 * x[:, 0])
+    ref = None
+    for rep in range(49):
+        B = H.alloc_matrix(n + 1, n + 1, dev)
+        B.copy_(A0)
+        logdet, info = H.potrf_(B, nf=n, lookahead=rep > 0)
+        assert int(info.item()) == 0
+        L = torch.tril(B)
+        if ref is None:
+            ref, ref_logdet = L.clone(), float(logdet)
+        else:
+            assert torch.equal(L, ref), f"repetition {rep} differs"
+            assert float(logdet) == ref_logdet
+
+
 def test_missing_data_at_scale_with_sampled_imputation(hip):
     """`sample_missing=True` (reference gpar/model.py:229-237) with 20 % of the observations missing
     in a pattern that is NOT closed downwards, at n = 4096, p = 4: ragged per-layer row counts on the device, missing
