@@ -46,6 +46,7 @@ struct GemmArgs {
     int fastA, fastB, fastC;
     int ksplit;          // > 0: blockIdx.y selects the K range [y * ksplit, (y + 1) * ksplit) and the output slab y
     long long part_stride;   // elements between consecutive partial slabs of C (split-K)
+    long long batch_a, batch_b, batch_c;   // blockIdx.z selects problem z of a batch: operands advance by these many elements
     long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memrealtime stamps + hardware ids, normally null
 };
 
@@ -260,18 +261,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     // XCD-aware, bijective remap of the block index: the dispatcher places block b on XCD b % 8; give each
     // XCD a contiguous run of tiles so neighbouring tiles (shared operand panels) hit the same L2.
     const long long t_start = p.stamps ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, chip-wide
-    int idx;
-    if (p.flags & (GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_A_LOWER)) {
+    p.A += (size_t)blockIdx.z * p.batch_a;
+    p.B += (size_t)blockIdx.z * p.batch_b;
+    p.C += (size_t)blockIdx.z * p.batch_c;
+    int idx = 0, tm = -1, tn = -1;
+    const bool tri_rect = !(p.flags & GPAR_GEMM_C_LOWER) && BM == GEMM_BM;
+    if (tri_rect && (p.flags & GPAR_GEMM_K_TO_COL) && !(p.flags & (GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_A_LOWER)) && (p.tiles_n & 7) == 0) {
+        // K grows with the tile COLUMN (upper-triangular op(B)): the tiles of one column share their B panel and their K
+        // length.  XCD x (the dispatcher puts block b on XCD b % 8) works through whole columns x, x + 8, ... of the
+        // longest-first order: equal work per XCD, the shared panel stays in that XCD's L2, short tiles end the launch.
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+        tn = p.tiles_n - 1 - ((j / p.tiles_m) * 8 + xcd);
+        tm = j % p.tiles_m;
+    } else if (p.flags & (GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_A_LOWER | GPAR_GEMM_K_TO_COL)) {
         // tiles differ in K length by up to n / 128 x (long ones first in the enumeration): contiguous runs per XCD would
-        // hand one XCD all the long tiles (the triangular-aware inverse ran at 28 TF that way); deal them round-robin
+        // hand one XCD all the long tiles (the triangular-aware inverse ran at 28 TF that way); deal them round-robin.  (K_FROM_ROW
+        // without C_LOWER, grouped by rows like the columns above: 8.6 -> 9.2 ms at 8192^3 / 2 - the row-major enumeration
+        // already starts with the longest tiles.)
         idx = blockIdx.x / (GEMM_BM / BM);
     } else {
         const int nb = gridDim.x / (GEMM_BM / BM), b = blockIdx.x / (GEMM_BM / BM);
         const int xcd = b & 7, q = nb >> 3, r = nb & 7;
         idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
-    int tm, tn;
-    if (p.flags & GPAR_GEMM_C_LOWER) {
+    if (tm >= 0) {
+        // (mapped above)
+    } else if (p.flags & GPAR_GEMM_C_LOWER) {
         // lower-trapezoid enumeration: rows tm < tiles_n hold tm+1 tiles, the rest hold tiles_n tiles
         const int tri = p.tiles_n * (p.tiles_n + 1) / 2;
         if (idx < tri) {
@@ -295,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     const bool a_lower = (p.flags & GPAR_GEMM_A_LOWER) != 0;
     // with a triangular op(A) nothing beyond k = m0 + 127 contributes to this tile
     int kend = a_lower ? min(p.k, m0 + BM) : p.k;
+    if (p.flags & GPAR_GEMM_K_TO_COL) kend = min(kend, n0 + GEMM_BN);   // upper-triangular op(B): nothing below the tile's last column
     // K_FROM_ROW: both operands vanish for k < their row (upper-triangular factors): with col <= row nothing
     // before k = m0 contributes to this tile
     int kbeg = (p.flags & GPAR_GEMM_K_FROM_ROW) ? min(m0, kend) : 0;
@@ -434,11 +450,13 @@ inline int gemm_num_tiles(int tiles_m, int tiles_n, int flags) {
     return tiles_m * tiles_n;
 }
 
+// `batch` > 1: that many independent problems of the same shape in one launch, problem z reading A + z * batch_a etc.
 static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
                        const double* B, int ldb, double beta, double* C, int ldc, int flags, hipStream_t stream,
-                       int role = 0) {
-    if (m <= 0 || n <= 0) return 0;
+                       int role = 0, int batch = 1, long long batch_a = 0, long long batch_b = 0, long long batch_c = 0) {
+    if (m <= 0 || n <= 0 || batch <= 0) return 0;
     GemmArgs p;
+    p.batch_a = batch_a; p.batch_b = batch_b; p.batch_c = batch_c;
     p.A = A; p.B = B; p.C = C;
     p.m = m; p.n = n; p.k = k;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -465,11 +483,11 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     // half tiles (two workgroups per 128 x 128 tile) while a launch has fewer tiles than the chip has compute units
     static int half_tiles = -1;
     if (half_tiles < 0) { const char* e = getenv("GPAR_GEMM_HALF_TILES"); half_tiles = e ? atoi(e) : 256; }
-    const bool half = !ta && tb && ntiles <= half_tiles && k >= 64 && !(flags & (GPAR_GEMM_A_LOWER | GPAR_GEMM_K_FROM_ROW));
+    const bool half = !ta && tb && ntiles * batch <= half_tiles && k >= 64 && !(flags & (GPAR_GEMM_A_LOWER | GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_K_TO_COL));
     static int lds_extra = -1;
     if (lds_extra < 0) { const char* e = getenv("GPAR_GEMM_LDS_EXTRA"); lds_extra = e ? atoi(e) : 0; }
     const int GEMM_LDS_REQ = GEMM_LDS_BYTES + lds_extra;   // experiment knob: > 6.2 KB extra forces one workgroup per CU
-    dim3 grid(half ? 2 * ntiles : ntiles), block(256);
+    dim3 grid(half ? 2 * ntiles : ntiles, 1, batch), block(256);
     if (half && role == 1) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1, 64>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (half) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0, 64>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (role == 1 && !ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, GEMM_LDS_REQ, stream, p);
@@ -502,6 +520,7 @@ static int gemm_splitk_launch(int ta, int tb, int m, int n, int k, double alpha,
     if (m <= 0 || n <= 0) return 0;
     if (splits <= 1 || !workspace) return gemm_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, stream);
     GemmArgs p;
+    p.batch_a = p.batch_b = p.batch_c = 0;
     p.A = A; p.B = B; p.C = workspace;
     p.m = m; p.n = n; p.k = k;
     p.lda = lda; p.ldb = ldb; p.ldc = n;

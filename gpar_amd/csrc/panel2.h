@@ -972,4 +972,24 @@ static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nro
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// X_bb = L_bb^-T for ALL 64 S-column diagonal blocks of a factor in one launch (X holds the identity on entry): the
+// triangular-solve row-block task on the identity, blockIdx.y = diagonal block.  Leaves of the recursive inversion in
+// chol_inverse_run (potrf.h).
+__global__ __launch_bounds__(256, 2) void trinv_blocks2_kernel(TrsmBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    const int c0 = 64 * a.S * blockIdx.y;
+    const int r0 = c0 + 64 * blockIdx.x;   // row block blockIdx.x of the block: zero left of its own column block
+    const PanelArgs none{nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
+    p2_row_block<false, false>(none, a.L, a.ldl, a.n, c0, c0, a.B, a.ldb, a.nrows, r0, c0, a.S, (int)blockIdx.x, 0, psm);
+}
+
+static int trinv_blocks_fused2(const double* L, int n, int ldl, double* X, int ldx, int S, hipStream_t stream) {
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&trinv_blocks2_kernel), P2_LDS_BYTES));
+    TrsmBlockArgs a{L, n, ldl, X, n, ldx, 0, S, 1};
+    hipLaunchKernelGGL(trinv_blocks2_kernel, dim3(S, n / (64 * S)), dim3(256), P2_LDS_BYTES, stream, a);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace gpar

@@ -363,6 +363,8 @@ static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* 
 static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
                              hipStream_t stream);
 static int env_int(const char* name, int dflt);
+static int trinv_blocks_fused2(const double* L, int n, int ldl, double* X, int ldx, int S, hipStream_t stream);
+
 static inline int potrf_panel_any(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed) {
     return env_int("GPAR_PANEL_V", 2) >= 2 ? potrf_panel_fused2(A, N, lda, k0, W, logdet, info, stream, prezeroed)
                                            : potrf_panel_fused(A, N, lda, k0, W, logdet, info, stream, prezeroed);
@@ -632,10 +634,41 @@ __global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ 
     if (c < n) X[(size_t)r * ldx + c] = (r == c) ? 1.0 : 0.0;
 }
 
+// X = L^-T by recursive blocked inversion (n a multiple of 512):
+//     [A 0; B C]^-T = [A^-T, -A^-T B^T C^-T; 0, C^-T]
+// leaves: all 512 x 512 diagonal blocks at once (trinv_blocks2_kernel); level s = 512, 1024, ...: for every pair of
+// neighbouring s-blocks  T = X11 B^T  (NT, k from the tile's first row: X11 is upper triangular) into the scratch matrix,
+// X12 = -T X22  (NN, k up to the tile's last column) - the pairs of a level in ONE batched launch each.  Same n^3 / 3 flops
+// as the triangular-aware solve of the identity, but the dependent chain is log2(n / 512) levels of large products instead
+// of n / 512 block kernels with an update each (32 + 30 launches, the block kernels latency-bound: 32 ms -> see DESIGN).
+static int trinv_recursive(const double* L, int n, int ldl, double* X, int ldx, double* T, int ldt, hipStream_t stream) {
+    const int leaf = 512;
+    int rc = trinv_blocks_fused2(L, n, ldl, X, ldx, leaf / 64, stream);
+    for (int s = leaf; s < n && !rc; s *= 2) {
+        const int full = n / (2 * s);   // pairs with two whole blocks
+        const long long sx = 2LL * s * (ldx + 1), sl = 2LL * s * (ldl + 1), st = 2LL * s * (ldt + 1);
+        if (full > 0) {
+            rc = gemm_launch(0, 1, s, s, s, 1.0, X, ldx, L + (size_t)s * ldl, ldl, 0.0, T + s, ldt, GPAR_GEMM_K_FROM_ROW, stream, 0, full, sx, sl, st);
+            if (!rc) rc = gemm_launch(0, 0, s, s, s, -1.0, T + s, ldt, X + (size_t)s * (ldx + 1), ldx, 0.0, X + s, ldx, GPAR_GEMM_K_TO_COL, stream, 0, full, st, sx, sx);
+        }
+        const int o = 2 * s * full, s2 = n - (o + s);   // a last pair whose second block is short (a multiple of 512)
+        if (!rc && s2 > 0) {
+            const double* X11 = X + (size_t)o * (ldx + 1);
+            double* Tp = T + (size_t)o * ldt + o + s;
+            rc = gemm_launch(0, 1, s, s2, s, 1.0, X11, ldx, L + (size_t)(o + s) * ldl + o, ldl, 0.0, Tp, ldt, GPAR_GEMM_K_FROM_ROW, stream);
+            if (!rc) rc = gemm_launch(0, 0, s, s2, s2, -1.0, Tp, ldt, X + (size_t)(o + s) * (ldx + 1), ldx, 0.0, X + (size_t)o * ldx + o + s, ldx,
+                                      GPAR_GEMM_K_TO_COL, stream);
+        }
+    }
+    return rc;
+}
+
 static int chol_inverse_run(const double* L, int n, int ldl, double* X, int ldx, double* Kinv, int ldk, hipStream_t stream) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(set_identity_kernel, dim3(gpar_ceil_div(n, 256), n), dim3(256), 0, stream, X, n, ldx);
-    int rc = trsm_rlt_run2(L, n, ldl, X, n, ldx, 1, stream);
+    const bool recursive = env_int("GPAR_INVERSE_RECURSIVE", 1) && env_int("GPAR_PANEL_V", 2) >= 2 && n >= 1024 && n % 512 == 0 && gpar_aligned16(L) &&
+                           gpar_aligned16(X) && gpar_aligned16(Kinv) && ldl % 2 == 0 && ldx % 2 == 0 && ldk % 2 == 0;
+    int rc = recursive ? trinv_recursive(L, n, ldl, X, ldx, Kinv, ldk, stream) : trsm_rlt_run2(L, n, ldl, X, n, ldx, 1, stream);
     if (rc) return rc;
     return gemm_launch(0, 1, n, n, n, 1.0, X, ldx, X, ldx, 0.0, Kinv, ldk, GPAR_GEMM_C_LOWER | GPAR_GEMM_K_FROM_ROW, stream);
 }

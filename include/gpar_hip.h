@@ -100,7 +100,8 @@ typedef struct {
 #define GPAR_GRAM_LOWER 1  /* symmetric Gram (z1 == z2): write only tiles that touch the lower triangle */
 #define GPAR_GEMM_C_LOWER 1 /* C is square-aligned: compute/store only elements with col <= row */
 #define GPAR_GEMM_A_LOWER 2 /* treat op(A) as lower triangular (entries with k > m are zero) */
-#define GPAR_GEMM_K_FROM_ROW 4 /* with C_LOWER: op(A)[m][k] = op(B)^T[n][k] = 0 for k < row, so k starts at the tile's first row */
+#define GPAR_GEMM_K_FROM_ROW 4 /* op(A)[m][k] is stored as zero for k < m (with C_LOWER also op(B)^T[n][k] for k < row): k starts at the tile's first row */
+#define GPAR_GEMM_K_TO_COL 8 /* op(B)[k][n] is stored as zero for k > n (upper-triangular op(B)): k ends with the tile's last column */
 
 int gpar_abi_version(void);
 size_t gpar_sizeof_fspec(void);

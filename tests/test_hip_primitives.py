@@ -398,9 +398,11 @@ def test_cross_and_diagonal_gradient_passes_match_oracle(env, n, M):
                     assert np.allclose(gf[key], rf[key], rtol=1e-10, atol=1e-12 * scale), (name, key, t, fi)
 
 
-@pytest.mark.parametrize("n", [1, 50, 64, 129, 700, 1500, 4200])
+@pytest.mark.parametrize("n", [1, 50, 64, 129, 700, 1500, 4200, 1024, 1536, 2560, 4096])
 def test_chol_inverse(env, n):
-    """Triangular-aware (L L^T)^-1: two-level TRSM of the identity + SYRK that starts k at the tile's first row."""
+    """Triangular-aware (L L^T)^-1: L^-T by the two-level TRSM of the identity - or, for multiples of 512, by recursive blocked
+    inversion (batched diagonal blocks, then levels of batched triangular-aware products; 1536 and 2560 have short last
+    blocks) - + SYRK that starts k at the tile's first row."""
     torch, hip, dev, to_dev = env
     rng = np.random.default_rng(n)
     A = _spd(rng, n, cond=50.0)
