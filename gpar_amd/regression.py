@@ -63,6 +63,14 @@ def _to_torch(x):
     return torch.tensor(np.asarray(x))
 
 
+def _to_engine(x):
+    """A transient input (not kept as an attribute) goes to the engine's device before any arithmetic: element-wise host
+    operators on n x p arrays open OpenMP regions whose workers then spin (see _default_weights)."""
+    from .engine import get_engine
+
+    return x if x is None else get_engine().tensor(x if isinstance(x, torch.Tensor) else np.asarray(x))
+
+
 def _uprank(x):
     if x.dim() == 0:
         return x.reshape(1, 1)
@@ -292,8 +300,8 @@ class GPARRegressor:
         """Log-density of observations under the prior (or, with `posterior`, the conditioned model).  Returns a
         numpy scalar unless x or y was a torch tensor (reference regression.py:461-506)."""
         any_torch = isinstance(x, torch.Tensor) or isinstance(y, torch.Tensor)
-        x = _uprank(_to_torch(x))
-        y = self._unnormalise_y(self._transform_y(_uprank(_to_torch(y))))  # sic: reference regression.py:483
+        x = _uprank(_to_engine(x))
+        y = self._unnormalise_y(self._transform_y(_uprank(_to_engine(y))))  # sic: reference regression.py:483
         w = _init_weights(w, y)
         m, p = x.shape[1], y.shape[1]
         if posterior and not self.is_conditioned:
@@ -308,7 +316,7 @@ class GPARRegressor:
 
     def _sample_device(self, x, w, p, posterior, num_samples, latent, conditioned=None, marginal=False):
         """The samples of `sample` as engine tensors (n* x p each), output transforms undone."""
-        x = _uprank(_to_torch(x))
+        x = _uprank(_to_engine(x))
         if posterior and not self.is_conditioned:
             raise RuntimeError("Must condition or fit model before sampling from the posterior.")
         elif not posterior and p is None:
