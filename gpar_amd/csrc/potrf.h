@@ -683,53 +683,73 @@ static int chol_inverse_run(const double* L, int n, int ldl, double* X, int ldx,
 constexpr int TRSV_NB = 512;
 constexpr int TRSV_LD = 65;
 
+// One 512-column block, eight 64-column sub-blocks from last to first.  Wave 0 solves a sub-block entirely in registers: lane =
+// column, the 64 rows of the triangle it needs (L[i][lane], zero above the diagonal) requested up front - during the
+// previous sub-block's update phase - and a 64-step chain of {multiply by the reciprocal pivot, v_readlane, multiply-add}.
+// Waves 1-3 apply the new x_s to the sub-blocks to its left: each has the 64 rows of its FIRST column block in registers
+// before x_s exists (requested while wave 0 solves; wave 1 takes the next sub-block to be solved), so the dependent part is
+// 64 multiply-adds against LDS broadcasts; further column blocks follow with their own loads.  (The first version staged
+// the triangle through LDS, read one row per step from it inside the chain and loaded the update rows only after the
+// solve: 13 us per sub-block, 106 us per block; this one ~2.)
 __global__ __launch_bounds__(256) void trsv_block_kernel(const double* __restrict__ L, int ldl, double* __restrict__ b, int c0, int c1) {
     __shared__ double xb[TRSV_NB];
-    __shared__ double Ls[64 * TRSV_LD];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int W = c1 - c0;
     for (int i = t; i < W; i += 256) xb[i] = b[c0 + i];
     const int nsub = (W + 63) / 64;
+    double lv[64];   // wave 0: the triangle's column `lane`; waves 1-3: column `lane` of the update rows
+    double dg = 1.0;
+    auto load_triangle = [&](int s) {
+        const int cs = c0 + 64 * s;
+        const int cb = (c1 - cs < 64) ? c1 - cs : 64;
+        const int lc = lane < cb ? lane : cb - 1;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) lv[i] = L[(size_t)(cs + (i < cb ? i : cb - 1)) * ldl + cs + lc];   // clamped, never behind a branch
+        dg = L[(size_t)(cs + lc) * ldl + cs + lc];
+    };
+    if (w == 0) load_triangle(nsub - 1);
+    __syncthreads();
     for (int s = nsub - 1; s >= 0; --s) {
         const int cs = c0 + 64 * s;
         const int cb = (c1 - cs < 64) ? c1 - cs : 64;
-        __syncthreads();   // xb settled (initial fill / previous update), Ls free
-        // L_ss (lower part is all that is used) -> LDS, rows contiguous; clamped addresses, no branches around loads
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = t + 256 * q, i = e >> 6, j = e & 63;
-            const int ic = i < cb ? i : cb - 1, jc = j < cb ? j : cb - 1;
-            Ls[i * TRSV_LD + j] = L[(size_t)(cs + ic) * ldl + cs + (jc <= ic ? jc : ic)];
-        }
-        __syncthreads();
-        if (w == 0) {
-            double bj = lane < cb ? xb[64 * s + lane] : 0.0;
-            const double rinv = 1.0 / Ls[(lane < cb ? lane : 0) * TRSV_LD + (lane < cb ? lane : 0)];
-            double xval = 0.0;
-            for (int j = cb - 1; j >= 0; --j) {
-                const double xj = gpar_readlane_f64(bj * rinv, j);
-                if (lane == j) xval = xj;
-                const double lj = Ls[j * TRSV_LD + lane];   // L[j][lane], needed for lane < j
-                if (lane < j) bj = fma(-xj, lj, bj);
-            }
-            if (lane < cb) xb[64 * s + lane] = xval;
-        }
-        __syncthreads();
-        // b_c -= x_s L[s-block][c-block] for the sub-blocks to the left, inside this 512-column block
-        for (int c = w; c < s; c += 4) {
-            const double* Lp = L + (size_t)cs * ldl + c0 + 64 * c + lane;
-            // all 64 loads are in flight before the first is used (a rolled loop waits out a memory round trip per
-            // iteration); rows beyond cb are read from a clamped address and multiplied by zero
-            double lv[64];
+        const int myc = s - w;   // waves 1-3: first column block to update
+        if (w > 0 && myc >= 0) {
+            const double* Lp = L + (size_t)cs * ldl + c0 + 64 * myc + lane;
 #pragma unroll
             for (int i = 0; i < 64; ++i) lv[i] = Lp[(size_t)(i < cb ? i : cb - 1) * ldl];
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int i = 0; i < 64; ++i) acc[i & 3] = fma(i < cb ? xb[64 * s + i] : 0.0, lv[i], acc[i & 3]);
-            xb[64 * c + lane] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
+        if (w == 0) {
+            // entries above the diagonal (row i < column) and beyond a ragged edge are zero: a lane's right-hand side then stops
+            // changing once its own step has passed, and its solution is read off after the loop
+#pragma unroll
+            for (int i = 0; i < 64; ++i) lv[i] = (lane < i && i < cb) ? lv[i] : 0.0;
+            double bj = lane < cb ? xb[64 * s + lane] : 0.0;
+            const double rinv = lane < cb ? 1.0 / dg : 0.0;
+#pragma unroll
+            for (int i = 63; i >= 0; --i) {
+                const double xi = gpar_readlane_f64(bj * rinv, i);   // (zero for i >= cb)
+                bj = fma(-xi, lv[i], bj);
+            }
+            if (lane < cb) xb[64 * s + lane] = bj * rinv;
+        }
+        __syncthreads();   // x_s is in xb
+        if (w == 0) {
+            if (s > 0) load_triangle(s - 1);   // in flight under the update phase
+        } else {
+            for (int c = myc; c >= 0; c -= 3) {
+                if (c != myc) {
+                    const double* Lp = L + (size_t)cs * ldl + c0 + 64 * c + lane;
+#pragma unroll
+                    for (int i = 0; i < 64; ++i) lv[i] = Lp[(size_t)(i < cb ? i : cb - 1) * ldl];
+                }
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < 64; ++i) acc[i & 3] = fma(i < cb ? xb[64 * s + i] : 0.0, lv[i], acc[i & 3]);
+                xb[64 * c + lane] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            }
+        }
+        __syncthreads();   // every update of this step has landed
     }
-    __syncthreads();
     for (int i = t; i < W; i += 256) b[c0 + i] = xb[i];
 }
 
