@@ -493,8 +493,14 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         return G > 1 && (k > 0 || pair_first) && pol.fused && nbo % 64 == 0 && k + G * nbo <= nf && (N - k) >= pol.pair_rows && (k % 2 == 0) && (lda % 2 == 0) &&
                gpar_aligned16(A);
     };
+    // Experiment knob, off: the last `tail` columns through ONE panel kernel (up to 16 column blocks).  Measured slower with the
+    // left-looking kernel too - n = 1024 as one 16-block panel 0.43 ms against 0.33 ms as two panels + a tiny update, C4
+    // 18.1 -> 19.7 ms: a team row's products for column block c (c chunks of 0.55 us) run while row c factors its
+    // diagonal tile (5 us), and from c ~ 10 on they outlast it and join the chain.
+    const int tail = pol.fused ? env_int("GPAR_POTRF_TAIL", 0) : 0;
+    auto panel_end = [&](int k) { return (nf - k <= tail || k + nbo >= nf) ? nf : k + nbo; };
     for (int k0 = 0, knext = 0; k0 < nf; k0 = knext) {
-        int kend = (k0 + nbo < nf) ? k0 + nbo : nf;
+        int kend = panel_end(k0);
         // a ragged tail (nf not a multiple of 64) becomes its own narrow panel so the wide part stays fusable
         if (pol.fused && (kend - k0) > 64 && (kend - k0) % 64 != 0) kend = k0 + (kend - k0) / 64 * 64;
         int rc = 0;
@@ -520,8 +526,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         if (rc) return rc;
         if (kend >= N) break;
         // columns the next step factors (one panel, or two if it pairs): [kend, next_end)
-        const int next_w = groupable(kend) ? G * nbo : nbo;
-        const int next_end = (kend + next_w < nf) ? kend + next_w : nf;
+        const int next_end = groupable(kend) ? kend + G * nbo : panel_end(kend);
         bool pa;
         if (!la || kend >= nf) {
             // no further panel to overlap with (or look-ahead off): one update of everything that is left
