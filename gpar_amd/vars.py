@@ -21,17 +21,29 @@ __all__ = ["Vars"]
 
 
 class _Var:
-    __slots__ = ("latent", "kind", "lower", "upper")
+    __slots__ = ("latent", "kind", "lower", "upper", "_cached", "_cached_version")
 
     def __init__(self, latent, kind, lower=None, upper=None):
         self.latent, self.kind, self.lower, self.upper = latent, kind, lower, upper
+        self._cached, self._cached_version = None, -1
 
     def value(self):
         if self.kind == "get":
             return self.latent
+        # Outside autograd the constrained value only changes when the latent is written (in place: its version counter
+        # moves): an evaluation of a p-layer model otherwise spends ~40 tiny host-side torch operators per layer here
+        # (0.2 of the 0.36 ms a layer of C2 costs the host).
+        track = torch.is_grad_enabled() and self.latent.requires_grad
+        if not track and self._cached is not None and self._cached_version == self.latent._version:
+            return self._cached
         if self.kind == "pos":
-            return torch.exp(self.latent)
-        return self.lower + (self.upper - self.lower) * torch.sigmoid(self.latent)
+            value = torch.exp(self.latent)
+        else:
+            value = self.lower + (self.upper - self.lower) * torch.sigmoid(self.latent)
+        if not track:
+            self._cached, self._cached_version = value.detach(), self.latent._version
+            return self._cached
+        return value
 
 
 class Vars:

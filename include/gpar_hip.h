@@ -187,8 +187,9 @@ int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb
 int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);
 
 /* Kinv (lower triangle) <- (L L^T)^-1 given the Cholesky factor L; X is an n x n workspace (holds L^-T on exit).
- * Triangular-aware: 2 n^3 / 3 flops.  [the K^-1 that the analytic gradient 1/2 tr((aa^T - K^-1) dK) needs;
- * replaces autograd through cholesky / solve_triangular, gpar/regression.py:459] */
+ * Triangular-aware: 2 n^3 / 3 flops.  Kinv doubles as scratch while L^-T is formed (recursive blocked inversion for n a
+ * multiple of 512, otherwise the solve of the identity).  [the K^-1 that the analytic gradient
+ * 1/2 tr((aa^T - K^-1) dK) needs; replaces autograd through cholesky / solve_triangular, gpar/regression.py:459] */
 int gpar_chol_inverse(const double* L, int n, int ldl, double* X, int ldx, double* Kinv, int ldk, void* stream);
 
 /* C <- alpha * op(A) op(B) + beta * C with op(A) m x k, op(B) k x n.  ta: A is stored k x m (transposed);
@@ -199,8 +200,8 @@ int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A
 
 /* As gpar_gemm, with the K range cut into `splits` slices whose partial products go to `workspace`
  * (splits * m * n doubles) and are summed in slice order by a second kernel: for outputs with few 128 x 128 tiles and
- * a very long K (the inducing-point matrix B D^-1 B^T: M x M from K = n).  Deterministic.  A_LOWER / K_FROM_ROW are
- * not meaningful here. */
+ * a very long K (the inducing-point matrix B D^-1 B^T: M x M from K = n).  Deterministic.  A_LOWER / K_FROM_ROW / K_TO_COL
+ * are not meaningful here. */
 int gpar_gemm_splitk(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
                      int ldb, double beta, double* C, int ldc, int flags, int splits, double* workspace, void* stream);
 
