@@ -17,6 +17,8 @@ K_EQ, K_RQ, K_LINEAR = 0, 1, 2
 GRAM_LOWER = 1
 GEMM_C_LOWER = 1
 GEMM_A_LOWER = 2
+GEMM_K_FROM_ROW = 4
+GEMM_K_TO_COL = 8
 POTRF_NO_LOOKAHEAD = 1
 POTRF_UNFUSED = 2
 WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE, WS_INPUT_GRAD = 1, 2, 3, 4, 5

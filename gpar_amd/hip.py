@@ -174,8 +174,10 @@ def trsm_rln_(L, B):
     return B
 
 
-def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False, a_lower=False):
-    """out <- alpha op(A) op(B) + beta out;  ta: A stored k x m;  tb: B stored n x k."""
+def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False, a_lower=False, k_from_row=False, k_to_col=False):
+    """out <- alpha op(A) op(B) + beta out;  ta: A stored k x m;  tb: B stored n x k.  `k_from_row` / `k_to_col`: op(A) is
+    upper triangular (stored zeros left of its diagonal) / op(B) is upper triangular (stored zeros below it): the K loop
+    skips the blocks that are zero."""
     lib = _lib.load()
     _check_mat(A, "A")
     _check_mat(B, "B")
@@ -188,13 +190,14 @@ def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False,
         if beta != 0.0:
             raise ValueError("beta != 0 needs an `out`")
     _check_mat(out, "out")
-    flags = (_lib.GEMM_C_LOWER if c_lower else 0) | (_lib.GEMM_A_LOWER if a_lower else 0)
+    flags = ((_lib.GEMM_C_LOWER if c_lower else 0) | (_lib.GEMM_A_LOWER if a_lower else 0) | (_lib.GEMM_K_FROM_ROW if k_from_row else 0)
+             | (_lib.GEMM_K_TO_COL if k_to_col else 0))
     # few output tiles but a very long K: cut K into slices so that the launch fills the chip's 512 workgroup slots (two
     # 73.7 KB workgroups per CU) in one round; deterministic two-pass sum.  (The workspace comes from torch's stream-aware
     # caching allocator: no hipMalloc after the first call of a given size.)
     tm, tn = (m + 127) // 128, (n + 127) // 128
     tiles = (min(tm, tn) * (min(tm, tn) + 1) // 2 + (tm - min(tm, tn)) * min(tm, tn)) if c_lower else tm * tn
-    if not a_lower and k >= 8192 and tiles <= 128:
+    if not (a_lower or k_from_row or k_to_col) and k >= 8192 and tiles <= 128:
         splits = max(2, min(64, 512 // max(tiles, 1), k // 1024))
         work = torch.empty(lib.gpar_workspace_doubles(_lib.WS_GEMM_SPLITK, m, n, splits), dtype=torch.float64, device=A.device)
         _lib.check(

@@ -413,6 +413,22 @@ def test_chol_inverse(env, n):
     assert np.allclose(got[il], ref[il], rtol=1e-9, atol=1e-11 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n", [384, 1024, 1300])
+def test_gemm_triangular_aware_k_ranges(env, n):
+    """K_FROM_ROW (upper-triangular op(A), zeros stored left of its diagonal) and K_TO_COL (upper-triangular op(B), zeros stored
+    below its diagonal) only shorten the K loop: same numbers as the plain product; the two factors of the recursive
+    triangular inversion (gpar_chol_inverse) are this pair.  (1024: tile counts that take the per-XCD column grouping.)"""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    U = np.triu(rng.standard_normal((n, n)))
+    D = rng.standard_normal((n, n))
+    dU, dD = to_dev(U), to_dev(D)
+    got = hip.gemm(dU, dD, tb=True, k_from_row=True).cpu().numpy()       # U D^T
+    assert np.allclose(got, U @ D.T, rtol=1e-11, atol=1e-11 * n)
+    got = hip.gemm(dD, dU, k_to_col=True, alpha=-1.0).cpu().numpy()       # -D U
+    assert np.allclose(got, -(D @ U), rtol=1e-11, atol=1e-11 * n)
+
+
 @pytest.mark.parametrize("ta,tb", [(True, False), (False, False), (False, True)])
 @pytest.mark.parametrize("mnk", [(1, 300, 9000), (257, 130, 20000), (1025, 1025, 16411)])
 def test_gemm_split_k_path(env, ta, tb, mnk):
