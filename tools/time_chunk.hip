@@ -52,7 +52,7 @@ __device__ __forceinline__ void chunk_v4(pan_d4 (&acc)[4], double a0, double b0)
 
 // the chunk as the kernel runs it: tiles arrive from global memory through registers, two barriers per chunk
 template <int STEP>
-__global__ __launch_bounds__(256, 2) void loopk(const double* __restrict__ G, double* out, long long* st, int reps) {
+__global__ __launch_bounds__(256, 2) void loopk(const double* __restrict__ G, double* out, long long* st, int reps, int span) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
     double* Cs = psm; double* Xs = psm + PNL_TILE;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void loopk(const double* __restrict__ G, do
         if (STEP >= 1) __syncthreads();
         if (STEP >= 2) { p2_sstore(Cs, t, la); p2_sstore(Xs, t, xa); }
         if (STEP >= 1) __syncthreads();
-        if (STEP >= 3) { p2_gload(base, 4096, 64, 0, 64 * ((2 * r + 2) & 63), t, la); p2_gload(base, 4096, 64, 0, 64 * ((2 * r + 3) & 63), t, xa); }
+        if (STEP >= 3) { p2_gload(base, 4096, 64, 0, 64 * ((2 * r + 2) & span), t, la); p2_gload(base, 4096, 64, 0, 64 * ((2 * r + 3) & span), t, xa); }
         __builtin_amdgcn_sched_barrier(0);
         p2_chunk(Cs, Xs, acc, w, l15, lk);
     }
@@ -79,6 +79,72 @@ __global__ __launch_bounds__(256, 2) void loopk(const double* __restrict__ G, do
     if (STEP < 3) s += la[0][0] + xa[0][0];
     out[blockIdx.x * 256 + t] = s;
     if (t == 0 && blockIdx.x == 0) st[8 + STEP] = c1 - c0;
+}
+
+// LDS-direct variant: K = 32 half-chunks, operands global -> LDS without passing through registers (global_load_lds_dwordx4),
+// double-buffered in four 16 KB half-tiles (unpadded rows of 256 bytes, 16-byte chunks XOR-swizzled by row), one barrier each.
+typedef __attribute__((address_space(3))) void* lds_ptr;
+__device__ __forceinline__ void half_load(const double* __restrict__ tile, int ld, int kbase, double* __restrict__ buf, int t) {
+    const int lane = t & 63, w = t >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * (4 * q + w) + (lane >> 4), p = lane & 15, j = p ^ ((r & 7) << 1);
+        __builtin_amdgcn_global_load_lds(tile + (size_t)r * ld + kbase + 2 * j, (lds_ptr)(buf + 128 * (4 * q + w)), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ double half_at(const double* __restrict__ buf, int r, int k) {
+    return buf[r * 32 + 2 * (((k >> 1) ^ ((r & 7) << 1))) + (k & 1)];
+}
+__device__ __forceinline__ void half_chunk(const double* __restrict__ Lh, const double* __restrict__ Xh, pan_d4 (&acc)[4], int w, int l15, int lk) {
+    double a0[4], a1[4], b0, b1;
+    b0 = half_at(Xh, 16 * w + l15, lk);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) a0[mi] = half_at(Lh, 16 * mi + l15, lk);
+#pragma unroll
+    for (int k4 = 0; k4 < 8; k4 += 2) {
+        b1 = half_at(Xh, 16 * w + l15, 4 * (k4 + 1) + lk);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a1[mi] = half_at(Lh, 16 * mi + l15, 4 * (k4 + 1) + lk);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[mi], b0, acc[mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k4 + 2 < 8) {
+            b0 = half_at(Xh, 16 * w + l15, 4 * (k4 + 2) + lk);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a0[mi] = half_at(Lh, 16 * mi + l15, 4 * (k4 + 2) + lk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[mi], b1, acc[mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+__global__ __launch_bounds__(256, 2) void ldsk(const double* __restrict__ G, double* out, long long* st, int reps, int span) {
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    pan_d4 acc[4];
+    for (int mi = 0; mi < 4; ++mi) acc[mi] = pan_d4{0, 0, 0, 0};
+    const double* base = G + (size_t)blockIdx.x * 64 * 4096;
+    // buffers: [L half 0 | X half 0 | L half 1 | X half 1], 2048 doubles each
+    half_load(base, 4096, 0, psm, t);
+    half_load(base, 4096, 64, psm + 2048, t);
+    const long long c0 = (long long)__builtin_readcyclecounter();
+    for (int h = 0; h < 2 * reps; ++h) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        double* nb = psm + 4096 * ((h + 1) & 1);
+        half_load(base, 4096, (32 * (h + 1)) & (64 * span + 63), nb, t);
+        half_load(base, 4096, (32 * (h + 1) + 2048) & (64 * span + 63) , nb + 2048, t);
+        __builtin_amdgcn_sched_barrier(0);
+        const double* cb = psm + 4096 * (h & 1);
+        half_chunk(cb, cb + 2048, acc, w, l15, lk);
+    }
+    const long long c1 = (long long)__builtin_readcyclecounter();
+    double s = 0;
+    for (int mi = 0; mi < 4; ++mi) s += acc[mi][0] + acc[mi][1] + acc[mi][2] + acc[mi][3];
+    out[blockIdx.x * 256 + t] = s;
+    if (t == 0 && blockIdx.x == 0) st[12] = c1 - c0;
 }
 
 template <int V>
@@ -122,14 +188,20 @@ int main() {
     hipMalloc(&G, 8ull * 512 * 64 * 4096);
     hipMemset(G, 0, 8ull * 512 * 64 * 4096);
     const char* ln[] = {"chunk alone", "+ two barriers", "+ 16 ds_write_b128 of the next tiles", "+ the next tiles' global loads in flight"};
+    for (int span : {63, 3})
     for (int grid : {1, 256}) {
-        printf("the chunk loop as the kernel runs it, grid = %d\n", grid);
+        printf("the chunk loop as the kernel runs it, grid = %d, operand tiles from %s\n", grid, span == 63 ? "HBM (every tile read once)" : "L2 (four tiles re-read)");
 #define RUNL(V) hipFuncSetAttribute(reinterpret_cast<const void*>(&loopk<V>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES); \
-        hipLaunchKernelGGL(loopk<V>, dim3(grid), dim3(256), P2_LDS_BYTES, 0, G, o, st, reps); hipLaunchKernelGGL(loopk<V>, dim3(grid), dim3(256), P2_LDS_BYTES, 0, G, o, st, reps);
+        hipLaunchKernelGGL(loopk<V>, dim3(grid), dim3(256), P2_LDS_BYTES, 0, G, o, st, reps, span); hipLaunchKernelGGL(loopk<V>, dim3(grid), dim3(256), P2_LDS_BYTES, 0, G, o, st, reps, span);
         RUNL(0) RUNL(1) RUNL(2) RUNL(3)
         hipDeviceSynchronize();
         long long s2[16]; hipMemcpy(s2, st, 8 * 16, hipMemcpyDeviceToHost);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ldsk), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
+        hipLaunchKernelGGL(ldsk, dim3(grid), dim3(256), P2_LDS_BYTES, 0, G, o, st, reps, span); hipLaunchKernelGGL(ldsk, dim3(grid), dim3(256), P2_LDS_BYTES, 0, G, o, st, reps, span);
+        hipDeviceSynchronize();
+        hipMemcpy(s2, st, 8 * 16, hipMemcpyDeviceToHost);
         for (int v = 0; v < 4; ++v) printf("   %-45s %7.0f cycles per chunk (64 products = 4096 cycles of matrix-core time)\n", ln[v], s2[8 + v] / (double)reps);
+        printf("   %-45s %7.0f cycles per chunk\n", "LDS-direct loads, K = 32 halves, double-buffered", s2[12] / (double)reps);
     }
     return 0;
 }
