@@ -290,7 +290,11 @@ static PotrfPolicy potrf_policy(int N) {
     p.nbm = env_int("GPAR_POTRF_NBM", p.nbm);
     p.lookahead = env_int("GPAR_POTRF_LOOKAHEAD", p.lookahead);
     p.split = env_int("GPAR_POTRF_SPLIT", 0);
-    p.pair_rows = env_int("GPAR_POTRF_PAIR_ROWS", 9216);   // n = 8192 measured slightly slower paired (7.19 vs 7.10 ms)
+    // n = 8192 measured slower grouped (5.38 vs 5.19 ms alone).  From N = 12288 on panels stay grouped until 6144 rows are left:
+    // with two factorisations in flight (the pipelined C3 evaluation) the longer serial stretch hides under the other stream's
+    // updates, 197.9 -> 194.9 ms per evaluation; alone it costs 0.5 % at n = 16384 (tools/exp_pair_rows.sh).  The rule depends
+    // on the size only, so that a factorisation returns the same bits whatever runs beside it.
+    p.pair_rows = env_int("GPAR_POTRF_PAIR_ROWS", N >= 12288 ? 6144 : 9216);
     p.group = env_int("GPAR_POTRF_GROUP", 3);
     if (p.nbo < 64) p.nbo = 64;
     if (p.nbm < 64) p.nbm = 64;

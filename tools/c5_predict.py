@@ -17,3 +17,7 @@ mean, lo, hi = reg.predict(xs, num_samples=S, credible_bounds=True); t2 = tic()
 print(f"C5: logpdf {v:.6f} ({1e3*(t1-t0):.0f} ms incl. first-call setup); predict S={S} n*=2048: {t2-t1:.2f} s; "
       f"finite={np.isfinite(mean).all() and np.isfinite(lo).all() and np.isfinite(hi).all()}, bounds ordered={(lo <= hi).all()}, "
       f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+t3 = tic(); mean2, lo2, hi2 = reg.predict(xs, num_samples=S, credible_bounds=True); t4 = tic()
+mm, lm, hm = reg.predict(xs, num_samples=S, credible_bounds=True, marginal=True); t5 = tic()
+print(f"    again: {t4-t3:.2f} s;   marginal=True: {t5-t4:.2f} s;   |mean - marginal mean| max {np.abs(mean2 - mm).max():.3f} "
+      f"(bounds half-width median {np.median(hi2 - lo2) / 2:.3f})")

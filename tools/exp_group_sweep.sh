@@ -1,9 +1,14 @@
 #!/bin/bash
-# Re-sweep of the panel grouping of gpar_potrf with the second-generation panel kernel: C3 evaluation time against
-# GPAR_POTRF_GROUP / GPAR_POTRF_PAIR_ROWS (panels per trailing update while that many rows remain), same session.
+# Re-sweep of the panel grouping of gpar_potrf and the pipeline depth at C3 (same session)
 cd "$(dirname "$0")/.."
-for cfg in "3 9216" "3 8192" "3 7168" "3 6144" "4 9216" "4 8192" "4 6144" "2 9216" "2 6144" "3 9216"; do
-    set -- $cfg
-    echo "== GROUP=$1 PAIR_ROWS=$2"
-    GPAR_POTRF_GROUP=$1 GPAR_POTRF_PAIR_ROWS=$2 timeout 300 python tools/run_config.py C3 --evals 6 --warmup 2 2>&1 | tail -2 | cut -c1-260
-done
+run() { python tools/run_config.py C3 --evals 6 --warmup 2 2>&1 | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); ms = sorted(d['ms']); print('$1', 'median', round(ms[len(ms)//2], 2), [round(x, 1) for x in d['ms']])"; }
+run default
+GPAR_POTRF_PAIR_ROWS=6144 run pair_rows=6144
+GPAR_POTRF_PAIR_ROWS=7168 run pair_rows=7168
+GPAR_POTRF_PAIR_ROWS=5120 run pair_rows=5120
+GPAR_POTRF_GROUP=4 GPAR_POTRF_PAIR_ROWS=6144 run group4_6144
+GPAR_LAYER_PIPELINE=3 run pipe3
+GPAR_LAYER_PIPELINE=3 GPAR_POTRF_PAIR_ROWS=6144 run pipe3_6144
+run default
