@@ -288,6 +288,25 @@ def test_gradient_matches_oracle(hip):
     np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(ref)))
 
 
+def test_gradient_matches_oracle_at_a_size_that_takes_the_recursive_inverse(hip):
+    """n = 1024 (a multiple of 512): K^-1 behind the analytic gradient comes from the recursive blocked inversion
+    (batched diagonal blocks + one level of triangular-aware products), and every factorisation is two fused panels."""
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(1024, 2, 2, seed=33)
+
+    def grads():
+        reg = GPARRegressor(scale=0.5, rq=True, linear=True, nonlinear=True, noise=0.1, normalise_y=False, impute=False)
+        with torch.no_grad():
+            reg.logpdf(x, y)
+        reg.vs.requires_grad(True)
+        reg.logpdf(torch.tensor(x), torch.tensor(y)).backward()
+        return np.concatenate([v.grad.numpy().reshape(-1) for v in reg.vs.get_vars()])
+
+    ref, got = _on("oracle", grads), _on("hip", grads)
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(ref)))
+
+
 def test_sparse_gradient_and_training_match_oracle(hip):
     """Inducing-point (VFE) path under training: gradient of the bound with respect to every hyper-parameter, and the
     hyper-parameters after a short L-BFGS-B run, HIP vs oracle (all kernel families; 257 points so the cross-gradient pass
