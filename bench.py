@@ -46,10 +46,10 @@ def synthetic(n, m, p, seed=1234):
     return x, np.stack(cols, axis=1)
 
 
-def c3_regressor():
+def c3_regressor(replace=False):
     from gpar_amd.regression import GPARRegressor
 
-    return GPARRegressor(scale=0.5, linear=True, nonlinear=True, markov=2, noise=0.1, replace=False, impute=True,
+    return GPARRegressor(scale=0.5, linear=True, nonlinear=True, markov=2, noise=0.1, replace=replace, impute=True,
                          normalise_y=False)
 
 
@@ -315,6 +315,16 @@ def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=20, num_samples=1
         reg.predict(xs, num_samples=num_samples, latent=True, marginal=True)
         sync()
         leg["predict_marginal_ms"] = 1e3 * (time.perf_counter() - t3)
+        # SURVEY 8(d)'s second predict series: replace=True (posterior means are fed forward instead of samples: every sample sees
+        # the same inputs, one triangular solve of n* rows per layer) - same trained hyper-parameters, conditioning included
+        reg_r = c3_regressor(replace=True)
+        reg_r.vs = reg.vs.copy(detach=True)
+        sync()
+        t4 = time.perf_counter()
+        reg_r.condition(x_np, y_np)
+        reg_r.predict(xs, num_samples=num_samples, latent=True)
+        sync()
+        leg["predict_replace_ms"] = 1e3 * (time.perf_counter() - t4)
     return leg
 
 
