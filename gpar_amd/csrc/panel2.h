@@ -210,99 +210,10 @@ __device__ __forceinline__ void p2_strip(const double* __restrict__ Cs, pan_d4 (
     }
 }
 
-// Right-looking Cholesky of the 64 x 64 LDS tile T (lower), 8-column blocks pipelined over the waves like pnl_diag (wave 0:
-// lane = row, brings block jb up to date with block jb - 1 and factors it; waves 1-3 apply block jb - 1 to the columns to
-// the right), with the pivot chain cut down to what the next pivot depends on.  Wave 0 issues in order, so every
-// instruction between two pivots is on the chain whether or not the next pivot needs it (pnl_diag: ~35 per pivot):
-//   * the wave-uniform coefficients of the rank-1 update are read (v_readlane) from the UNSCALED column while the
-//     reciprocal square root is still in flight, and the update uses (a_ij / d) a_kj instead of l_ij l_kj;
-//   * d^-1/2: v_rsq_f64 (2^-23 relative) + ONE cubic step  r (1 + e (1/2 + 3/8 e)),  e = 1 - d r^2  (error ~ e^3);
-//   * the diagonal element is d r like every other element of the column (no separate square root), the positivity check is
-//     one ballot per tile (a non-positive pivot turns into NaN / inf and stays), the log-determinant reads the diagonal
-//     back from LDS at the end;
-//   * wave 0 keeps its previous block's 8 values in registers instead of re-reading them from LDS.
-// One 8-column block of wave 0's share: acc = this lane's 8 values of block jb; UPDATE: the rank-8 update of block jb - 1
-// (prev = this lane's values of that block, coefficients from LDS) is applied column by column INSIDE the pivot loop - the
-// eight independent multiply-adds of column j + 1 are issued in the shadow of pivot j's reciprocal square root.
-template <bool UPDATE>
-__device__ __forceinline__ void p2_diag_block(const double* __restrict__ T, int jb, int i, double (&acc)[8], const double (&prev)[8]) {
-    pan_d2 c[8][4];
-    if (UPDATE) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const pan_d2* cs = reinterpret_cast<const pan_d2*>(&T[(8 * jb + k) * PNL_LD + 8 * (jb - 1)]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c[k][q] = cs[q];
-        }
-    }
-    const pan_d2* src = reinterpret_cast<const pan_d2*>(&T[i * PNL_LD + 8 * jb]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
-    auto update_col = [&](int k) {
-        double u0 = acc[k], u1 = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { u0 = fma(-prev[2 * q], c[k][q][0], u0); u1 = fma(-prev[2 * q + 1], c[k][q][1], u1); }
-        acc[k] = u0 + u1;
-    };
-    if (UPDATE) update_col(0);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const double d = gpar_readlane_f64(acc[j], 8 * jb + j);
-        double r = __builtin_amdgcn_rsq(d);
-        double a[8];
-#pragma unroll
-        for (int j2 = j + 1; j2 < 8; ++j2) a[j2] = gpar_readlane_f64(acc[j], 8 * jb + j2);
-        if (UPDATE && j + 1 < 8) update_col(j + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const double e = fma(-d * r, r, 1.0);
-        r = fma(r * e, fma(0.375, e, 0.5), r);
-        const double tc = acc[j] * (r * r);
-#pragma unroll
-        for (int j2 = j + 1; j2 < 8; ++j2) acc[j2] = fma(-tc, a[j2], acc[j2]);
-        acc[j] = acc[j] * r;
-    }
-}
-
-template <bool STAMP = false>
-__device__ __forceinline__ void p2_diag(double* __restrict__ T, int col0, const PanelArgs& p, int t, long long* __restrict__ st = nullptr) {
-    const int i = t & 63, w = t >> 6;
-    double prev[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) prev[q] = 0.0;
-    for (int jb = 0; jb < 8; ++jb) {
-        if (w == 0) {
-            if (STAMP && t == 0) st[3 * jb] = (long long)__builtin_readcyclecounter();
-            double acc[8];
-            if (jb == 0) p2_diag_block<false>(T, jb, i, acc, prev);
-            else p2_diag_block<true>(T, jb, i, acc, prev);
-            pan_d2* dst = reinterpret_cast<pan_d2*>(&T[i * PNL_LD + 8 * jb]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
-#pragma unroll
-            for (int q = 0; q < 8; ++q) prev[q] = acc[q];
-            if (STAMP && t == 0) st[3 * jb + 2] = (long long)__builtin_readcyclecounter();
-        } else if (jb > 0) {
-            pnl_rank8(T, T, jb - 1, i, 8 * jb + 8 + (w - 1), 3);
-        }
-        __syncthreads();
-    }
-    if (t < 64) {
-        const double mydiag = T[i * PNL_LD + i];
-        const unsigned long long badmask = __ballot(!(mydiag > 0.0));
-        double ld = 2.0 * log(mydiag);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ld += __shfl_xor(ld, off, 64);
-        if (t == 0) {
-            if (p.logdet) atomicAdd(p.logdet, ld);
-            if (badmask && p.info) atomicCAS(p.info, 0, col0 + __builtin_ctzll(badmask) + 1);
-        }
-    }
-}
-
-// ---- third form of the diagonal-tile factorisation: wave-uniform coefficients through DPP -----------------------------
+// ---- the diagonal-tile factorisation: wave-uniform coefficients through DPP ------------------------------------------
 // A lone wave issues one instruction every ~4.3 cycles whatever it is (tools/ubench_dp_latency.hip: dependent v_fma_f64
-// 4.3 cycles, v_rsq_f64 16), so the pivot chain of pnl_diag / p2_diag is bound by its INSTRUCTION COUNT (~34 per pivot,
-// ~60 with the rank-8 update interleaved), and a third of those are v_readlane pairs and LDS broadcast reads that only
+// 4.3 cycles, v_rsq_f64 16), so the pivot chain of pnl_diag (panel.h) is bound by its INSTRUCTION COUNT (~34 per pivot,
+// ~60 with the rank-8 update of the block's own columns; trimming its bookkeeping and interleaving that update gained 5 %), and a third of those are v_readlane pairs and LDS broadcast reads that only
 // move wave-uniform coefficients.  Here they come with the arithmetic: the 16 lanes of a DPP row are
 //     lanes 0-7:  rows 8 jb .. 8 jb + 7 of the tile (the block's own diagonal rows, replicated in every DPP row),
 //     lanes 8-15: eight other rows (wave w < 2, DPP row R: rows 32 w + 8 R .. + 7),
