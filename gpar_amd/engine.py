@@ -93,7 +93,13 @@ class HipEngine:
 
     # ---- kernels ---------------------------------------------------------------------------------
     def compile(self, kernel, width):
-        return compile_kernel(kernel, width)
+        # (kernel objects are immutable expression trees: a layer constructor memoised by the variable store hands the same
+        # object to every evaluation, and its device specification with it)
+        cache = kernel.__dict__.setdefault("_compiled", {})
+        ck = cache.get(width)
+        if ck is None:
+            ck = cache[width] = compile_kernel(kernel, width)
+        return ck
 
     def features(self, ck, x):
         return hip.featurize(ck, self._mat(x))

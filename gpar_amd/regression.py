@@ -84,7 +84,13 @@ def _model_generator(vs, m, pi, scale, scale_tie, per, per_period, per_scale, pe
     """Constructor of layer `pi`: kernel over the inputs + kernel over the selected previous outputs, and the
     observation-noise variance; hyper-parameters are created in `vs` on first use (reference regression.py:72-182)."""
 
+    config = repr((m, pi, scale, scale_tie, per, per_period, per_scale, per_decay, input_linear, input_linear_scale, linear,
+                   linear_scale, nonlinear, nonlinear_scale, rq, markov, noise))
+
     def model():
+        return vs.memo(config, build)
+
+    def build():
         m_inds, p_inds, p_num = _determine_indices(m, pi, markov)
         k_in, k_out = ZeroKernel(), ZeroKernel()
 
