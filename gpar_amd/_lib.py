@@ -91,6 +91,11 @@ SIGNATURES = {
         _c_int,
         [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr],
     ),
+    "gpar_logpdf_dense": (
+        _c_int,
+        [ctypes.POINTER(FSpec), ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, ctypes.c_long, _ptr, _c_dbl, _ptr, _c_int, _ptr, _c_int,
+         _ptr, _ptr, _ptr, _c_int, _ptr],
+    ),
     "gpar_potrf": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "gpar_potrf_ex": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr]),
     "gpar_trsm_rlt": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),

@@ -152,26 +152,17 @@ struct GparDeviceGuard {
     GparDeviceGuard gpar_device_guard(stream)
 #define GPAR_API_GUARD_NOSTREAM std::lock_guard<std::mutex> gpar_api_guard(g_api_mutex)
 
-extern "C" {
-
-int gpar_abi_version(void) { return GPAR_ABI_VERSION; }
-size_t gpar_sizeof_fspec(void) { return sizeof(gpar_fspec_t); }
-size_t gpar_sizeof_kspec(void) { return sizeof(gpar_kspec_t); }
-
-int gpar_featurize(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* z, int ldz, void* stream) {
-    GPAR_API_GUARD;
+static int featurize_launch(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* z, int ldz, hipStream_t stream) {
     if (!fs || fs->dz < 0 || fs->dz > GPAR_MAX_DIMS) return GPAR_ARG_ERROR(2);
     if (n <= 0 || fs->dz == 0) return 0;
     const long total = (long)n * fs->dz;
-    hipLaunchKernelGGL(featurize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *fs, x, n,
-                       ldx, z, ldz);
+    hipLaunchKernelGGL(featurize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, *fs, x, n, ldx, z, ldz);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
 
-int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz,
-              double* K, int ldk, int flags, const double* diag_add, double diag_const, const double* row_scale, void* stream) {
-    GPAR_API_GUARD;
+static int gram_launch(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz, double* K,
+                       int ldk, int flags, const double* diag_add, double diag_const, const double* row_scale, hipStream_t stream) {
     if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS)
         return GPAR_ARG_ERROR(3);
     if (dz < 0 || dz > GPAR_MAX_DIMS) return GPAR_ARG_ERROR(4);
@@ -182,8 +173,68 @@ int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const 
     const int nt1 = gpar_ceil_div(n1, GRAM_T), nt2 = gpar_ceil_div(n2, GRAM_T);
     dim3 grid(nt2, nt1);
     if (flags & GPAR_GRAM_LOWER) grid = dim3((unsigned)((long long)nt1 * (nt1 + 1) / 2), 1);
-    hipLaunchKernelGGL(gram_kernel, grid, dim3(256), lds, (hipStream_t)stream, *ks, z1, n1, ldz1, z2, n2, ldz2, dz, K, ldk,
-                       flags, diag_add, diag_const, row_scale, sym);
+    hipLaunchKernelGGL(gram_kernel, grid, dim3(256), lds, stream, *ks, z1, n1, ldz1, z2, n2, ldz2, dz, K, ldk, flags, diag_add,
+                       diag_const, row_scale, sym);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+// row n of the augmented matrix <- observations, corner / log-determinant / info word <- 0
+__global__ __launch_bounds__(256) void logpdf_prepare_kernel(const double* __restrict__ y, long incy, int n, double* __restrict__ A, int lda,
+                                                             double* __restrict__ logdet, int* __restrict__ info) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) A[(size_t)n * lda + i] = y[(size_t)i * incy];
+    if (i == n) {
+        A[(size_t)n * lda + n] = 0.0;
+        logdet[0] = 0.0;
+        info[0] = 0;
+    }
+}
+
+__global__ void logpdf_value_kernel(const double* __restrict__ A, int lda, int n, double n_log_2pi, const double* __restrict__ logdet,
+                                    double* __restrict__ value) {
+    // the corner holds -|L^-1 y|^2 (potrf.h: the augmented row's Schur complement).  Two additions and an exact scaling, the
+    // product n log 2 pi formed on the host: the same roundings as the host-side expression this replaces (a multiply next to
+    // an add would be contracted into a fused multiply-add here), so that the fused and the separate paths return the same bits.
+    value[0] = -0.5 * ((logdet[0] + n_log_2pi) - A[(size_t)n * lda + n]);
+}
+
+extern "C" {
+
+int gpar_abi_version(void) { return GPAR_ABI_VERSION; }
+size_t gpar_sizeof_fspec(void) { return sizeof(gpar_fspec_t); }
+size_t gpar_sizeof_kspec(void) { return sizeof(gpar_kspec_t); }
+
+int gpar_featurize(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* z, int ldz, void* stream) {
+    GPAR_API_GUARD;
+    return featurize_launch(fs, x, n, ldx, z, ldz, (hipStream_t)stream);
+}
+
+int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz,
+              double* K, int ldk, int flags, const double* diag_add, double diag_const, const double* row_scale, void* stream) {
+    GPAR_API_GUARD;
+    return gram_launch(ks, z1, n1, ldz1, z2, n2, ldz2, dz, K, ldk, flags, diag_add, diag_const, row_scale, (hipStream_t)stream);
+}
+
+// One dense layer's log marginal likelihood in one call (SURVEY 8(b)'s fused a2-a4; gpar/model.py:226 for a prior process):
+// features -> Gram + noise + jitter into the top-left n x n of the (n + 1) x (n + 1) buffer A -> y into row n -> partial
+// factorisation -> value = -1/2 (log|K| + n log 2 pi + |L^-1 y|^2).  The same launches the separate entry points make; what
+// it saves is the caller's side: a Python host spends ~0.1 ms per layer on the five calls and the small tensor operations
+// between them, which at n = 4096 decides when the last of four pipelined layers starts.
+int gpar_logpdf_dense(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, const double* y, long incy,
+                      const double* noise_diag, double jitter, double* z, int ldz, double* A, int lda, double* logdet, int* info,
+                      double* value, int potrf_flags, void* stream) {
+    GPAR_API_GUARD;
+    if (!fs || !ks || !A || !logdet || !info || !value || (n > 0 && (!x || !y))) return GPAR_ARG_ERROR(1);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = featurize_launch(fs, x, n, ldx, z, ldz, st);
+    if (!rc && n > 0) rc = gram_launch(ks, z, n, ldz, z, n, ldz, fs->dz, A, lda, GPAR_GRAM_LOWER, noise_diag, jitter, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(logpdf_prepare_kernel, dim3(gpar_ceil_div(n + 1, 256)), dim3(256), 0, st, y, incy, n, A, lda, logdet, info);
+    if (n > 0) rc = potrf_run(A, n + 1, n, lda, logdet, info, st, potrf_flags);
+    if (rc) return rc;
+    hipLaunchKernelGGL(logpdf_value_kernel, dim3(1), dim3(1), 0, st, (const double*)A, lda, n, (double)n * 1.8378770664093453,
+                       (const double*)logdet, value);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

@@ -115,6 +115,13 @@ class HipEngine:
         safe = getattr(self._tls, "safe", False)
         return hip.potrf_(A, nf=nf, lookahead=not safe and getattr(self._tls, "pipe_depth", 0) < 3, fused=not safe)
 
+    def logpdf_dense(self, ck, x, y, noise_diag, jitter):
+        """One dense layer's log marginal likelihood in one library call (value as a 0-d device tensor, info word)."""
+        safe = getattr(self._tls, "safe", False)
+        depth = getattr(self._tls, "pipe_depth", 0)
+        value, _, info, _ = hip.logpdf_dense(ck, self._mat(x), y, noise_diag, jitter, lookahead=not safe and depth < 3, fused=not safe)
+        return value, info
+
     @contextlib.contextmanager
     def safe_mode(self):
         """Factorisations inside use the unfused panel path (separate leaf kernels, nothing waits inside a launch), without

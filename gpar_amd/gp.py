@@ -517,7 +517,22 @@ class Obs:
                 self._params = params
                 self._noise_device = None if noise is None else noise.device
                 return _LogMarginal.apply(self, noise, X, None, *[p[3] for p in params])
+        if self._value_only():
+            # one library call: features, Gram, observations, factorisation, value (the factor is not kept)
+            eng = self.eng
+            ck = eng.compile(self.base.kernel, self.fdd.x.shape[1])
+            value, info = eng.logpdf_dense(ck, self.fdd.x, self.y, self.fdd.noise, eng.epsilon)
+            eng.check_info(info)
+            return value.detach()
         return self.factor().logpdf()
+
+    def _value_only(self):
+        """The caller wants the number and nothing else (`transient`, set by GPAR.logpdf for layers that feed nobody), of a
+        prior process, with checks deferred (the value stays on the device) and no retry ladder to climb."""
+        eng = self.eng
+        return (getattr(self, "transient", False) and self._fac is None and not self.base.is_posterior and self.fdd.n > 0
+                and hasattr(eng, "logpdf_dense") and getattr(eng, "_deferred", None) is not None
+                and getattr(eng, "cholesky_retry_factor", 1.0) <= 1.0 and isinstance(self.y, torch.Tensor) and self.y.is_cuda)
 
     def _value(self):
         return self.factor().logpdf()

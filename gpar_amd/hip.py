@@ -81,6 +81,37 @@ def featurize(ck, x):
     return z
 
 
+def logpdf_dense(ck, x, y, noise_diag, jitter, lookahead=True, fused=True):
+    """log N(y; 0, k(x, x) + diag(noise_diag) + jitter I) in one library call (gpar_logpdf_dense): returns
+    (value, logdet, info) as one-element device tensors and the (n + 1) x (n + 1) factor buffer."""
+    lib = _lib.load()
+    _check_mat(x, "x")
+    n = x.shape[0]
+    y = y.reshape(-1)
+    if y.numel() != n or y.dtype != torch.float64 or not y.is_cuda:
+        raise ValueError("y must hold one fp64 device value per row of x")
+    nptr = None
+    if noise_diag is not None:
+        noise_diag = noise_diag.reshape(-1).contiguous()
+        if noise_diag.numel() != n:
+            raise ValueError("noise_diag must hold one value per row of x")
+        nptr = noise_diag.data_ptr()
+    z = alloc_matrix(n, max(ck.dz, 1), x.device)
+    A = alloc_matrix(n + 1, n + 1, x.device)
+    words = torch.empty(2, dtype=torch.float64, device=x.device)   # value, logdet
+    info = torch.empty(1, dtype=torch.int32, device=x.device)
+    flags = (0 if lookahead else _lib.POTRF_NO_LOOKAHEAD) | (0 if fused else _lib.POTRF_UNFUSED)
+    _lib.check(
+        lib.gpar_logpdf_dense(
+            ctypes.byref(ck.fspec), ctypes.byref(ck.kspec), x.data_ptr(), n, _ld(x), y.data_ptr(), int(y.stride(0)), nptr, float(jitter),
+            z.data_ptr(), _ld(z), A.data_ptr(), _ld(A), words[1:].data_ptr(), info.data_ptr(), words.data_ptr(), flags,
+            stream_ptr(x.device),
+        ),
+        "gpar_logpdf_dense",
+    )
+    return words[0], words[1:], info, A
+
+
 def gram(ck, z1, z2=None, out=None, lower=False, diag_add=None, diag_const=0.0, row_scale=None):
     """K = k(z1, z2) (z2 None: symmetric, optionally lower-only, + diag_add + diag_const on the diagonal); with `row_scale`
     (n1 weights) row a is multiplied by row_scale[a]."""

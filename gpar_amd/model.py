@@ -226,7 +226,9 @@ class GPAR:
                 if pipe is not None:
                     if not only_last_layer or is_last:
                         with pipe.stage(stage, x, yi, wi):
-                            values.append(f.measure.logpdf(self._obs(x, x_ind, yi, wi, f, noise, complete=True)))
+                            obs = self._obs(x, x_ind, yi, wi, f, noise, complete=True)
+                            obs.transient = True   # nobody conditions on this layer: only its value is wanted
+                            values.append(f.measure.logpdf(obs))
                         stage += 1
                     if not is_last:
                         x = torch.cat([x, yi], dim=1)

@@ -180,6 +180,15 @@ int gpar_potrf(double* A, int N, int nf, int lda, double* logdet, int* info, voi
 #define GPAR_POTRF_UNFUSED 2
 int gpar_potrf_ex(double* A, int N, int nf, int lda, double* logdet, int* info, int flags, void* stream);
 
+/* One dense layer's log marginal likelihood, fused (features, Gram + noise_diag + jitter, observations into the augmented row,
+ * partial factorisation, value):  value[0] = log N(y; 0, k(x, x) + diag(noise_diag) + jitter I).  x: n x width (ldx); y: n values
+ * with stride incy; noise_diag: n values (or null); z: n x dz workspace (ldz); A: (n + 1) x (n + 1) workspace (lda), holds the
+ * factor, L^-1 y in row n and -|L^-1 y|^2 in the corner on exit; logdet / info / value: one word each, written (not accumulated).
+ * potrf_flags as for gpar_potrf_ex.  [f.measure.logpdf(Obs(f(x, noise / w), y)) for a prior process, gpar/model.py:226,289] */
+int gpar_logpdf_dense(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, const double* y, long incy,
+                      const double* noise_diag, double jitter, double* z, int ldz, double* A, int lda, double* logdet, int* info,
+                      double* value, int potrf_flags, void* stream);
+
 /* B <- B L^-T  (right side, lower, transposed: forward substitution on the rows of B; B is nrows x n).
  * [solve_triangular inside matrix.iqf_diag / PosteriorKernel, reached from gpar/model.py:226,264,298] */
 int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);

@@ -413,6 +413,34 @@ def test_chol_inverse(env, n):
     assert np.allclose(got[il], ref[il], rtol=1e-9, atol=1e-11 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n", [1, 77, 640, 1500])
+def test_fused_dense_logpdf_entry_point(env, n):
+    """gpar_logpdf_dense: features, Gram + noise + jitter, observations, partial factorisation and value in one call equal the
+    numpy / scipy evaluation of log N(y; 0, K + D + eps I); the buffer it leaves holds the factor and L^-1 y."""
+    import scipy.linalg as sla
+
+    from gpar_amd.kernels import EQ, Linear, compile_kernel
+
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    x = rng.uniform(0, 1, (n, 3))
+    y = rng.standard_normal(n)
+    noise = rng.uniform(0.05, 0.2, n)
+    kernel = 1.3 * EQ().stretch(np.array([0.4, 0.7])).select([0, 1]) + Linear().stretch(np.array([2.0])).select([2])
+    ck = compile_kernel(kernel, 3)
+    value, logdet, info, A = hip.logpdf_dense(ck, to_dev(x), to_dev(y[:, None])[:, 0], to_dev(noise[:, None])[:, 0], 1e-10)
+    assert int(info.item()) == 0
+    d2 = ((x[:, None, :2] - x[None, :, :2]) ** 2 / np.array([0.4, 0.7]) ** 2).sum(-1)
+    K = 1.3 * np.exp(-0.5 * d2) + np.outer(x[:, 2], x[:, 2]) / 4.0 + np.diag(noise) + 1e-10 * np.eye(n)
+    L = np.linalg.cholesky(K)
+    zr = sla.solve_triangular(L, y, lower=True)
+    ref = -0.5 * (2 * np.log(np.diag(L)).sum() + n * np.log(2 * np.pi) + zr @ zr)
+    assert abs(float(value) - ref) <= 1e-10 * max(1.0, abs(ref))
+    got = A.cpu().numpy()
+    assert np.allclose(np.tril(got[:n, :n]), L, rtol=1e-9, atol=1e-11)
+    assert np.allclose(got[n, :n], zr, rtol=1e-8, atol=1e-10)
+
+
 @pytest.mark.parametrize("n", [384, 1024, 1300])
 def test_gemm_triangular_aware_k_ranges(env, n):
     """K_FROM_ROW (upper-triangular op(A), zeros stored left of its diagonal) and K_TO_COL (upper-triangular op(B), zeros stored
