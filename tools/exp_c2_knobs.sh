@@ -1,16 +1,13 @@
 #!/bin/bash
-# C2 (n = 4096, p = 4; four factorisations in flight): tile / panel-width knobs, same session
+# C2 (n = 4096, p = 4): pipeline depth / look-ahead / half tiles after the host-side changes, same session
 cd "$(dirname "$0")/.."
-run() { python tools/run_config.py $CFG --evals 8 $EXTRA 2>&1 | python -c "
+run() { python tools/run_config.py C2 --evals 10 --warmup 3 2>&1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$CFG $EXTRA $1', 'ms', [round(x, 2) for x in d['ms']])"; }
-for CFG in C2 C5; do
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); ms = sorted(d['ms']); print('$1', 'median', round(ms[len(ms)//2], 2), 'min', round(ms[0], 2))"; }
 run default
-GPAR_POTRF_NBO=1024 run nbo1024
-GPAR_POTRF_NBO=768 run nbo768
-EXTRA=--serial run default
-EXTRA=--serial GPAR_POTRF_NBO=1024 run nbo1024
-EXTRA=
-done
-python tools/time_potrf.py 2048 4096 8192 2>&1 | grep potrf
-GPAR_POTRF_NBO=1024 python tools/time_potrf.py 2048 4096 8192 2>&1 | grep potrf
+GPAR_LAYER_PIPELINE=3 run pipe3
+GPAR_LAYER_PIPELINE=2 run pipe2
+GPAR_POTRF_LOOKAHEAD=1 run lookahead_forced
+GPAR_GEMM_HALF_TILES=600 run half600
+GPAR_POTRF_NBO=256 run nbo256
+run default
