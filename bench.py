@@ -396,10 +396,12 @@ def cpu_baseline_leg(x_np, y_np, m, p, n_star=2048, num_samples=100, budget_s=30
         "cores": threads,
         "kind": "port",
         "backend": "torch-CPU fp64 (torch.linalg.cholesky / solve_triangular / exp / matmul: the operators the reference's "
-                   "lab.torch backend dispatches to), torch.set_num_threads(all host cores)",
+                   "lab.torch backend dispatches to), one torch thread per CPU the container may use",
+        "host_logical_cpus": os.cpu_count(),
+        "cgroup_cpu_quota": tc.cpu_quota(),
         "sample": f"{len(measured)} of the p={p} layers of the same full-size workload (n={n}; from the last, widest layer "
                   f"downwards, {spent:.1f} s of CPU work), mean per layer x p; host has {os.cpu_count()} logical CPUs, "
-                  f"{threads} torch threads",
+                  f"the container's CPU quota is {tc.cpu_quota()}, {threads} torch threads",
         "per_layer_s": per_layer,
         "gram_s": float(np.mean([s["gram_s"] for s in measured])),
         "potrf_s": float(np.mean([s["potrf_s"] for s in measured])),

@@ -18,16 +18,39 @@ import time
 import numpy as np
 import torch
 
-__all__ = ["set_threads", "gram", "layer_logpdf", "layer_objective_and_gradient", "layer_posterior_sample"]
+__all__ = ["set_threads", "cpu_quota", "gram", "layer_logpdf", "layer_objective_and_gradient", "layer_posterior_sample"]
 
 EPSILON = 1e-12  # lab's B.epsilon
 
 
+def cpu_quota():
+    """CPUs the container may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota), or None without a limit."""
+    import math
+
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else max(1, math.ceil(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else max(1, math.ceil(quota / period))
+    except (OSError, ValueError):
+        return None
+
+
 def set_threads(threads=None):
+    """All the CPUs this process may actually use: the host's logical CPUs, capped by the container's CPU quota (more
+    threads than that only get the process throttled: the worker threads of every parallel region spin)."""
     import os
 
-    threads = int(threads or os.cpu_count() or 1)
-    torch.set_num_threads(threads)
+    if not threads:
+        threads = os.cpu_count() or 1
+        quota = cpu_quota()
+        if quota:
+            threads = min(threads, quota)
+    torch.set_num_threads(int(threads))
     return torch.get_num_threads()
 
 
