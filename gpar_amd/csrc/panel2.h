@@ -884,6 +884,123 @@ static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nro
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The mirrored task: one 64-row block of B carried through the S column blocks [c0, c0 + 64 S) of the BACKWARD solve
+// X L = B  (gpar_trsm_rln, many rows: the W_fu L_z^-1 of the inducing-point gradient), last column block first:
+//     acc  = sum_{u>c} X[rb][u] L[u][c]        the L tile enters UNTRANSPOSED: the A fragment of column m and K index k is
+//                                              L[u][c][k][m], a transposed read of the LDS tile
+//     X    = (B[rb][c] - acc) L[c][c]^-1       16 x 16 blocks from the last to the first:  x_j = W_j^T-applied, then
+//                                              T_j' -= L[j][j']^T-products for j' < j - the chain of p2_strip run backwards
+// Same T layout, same LDS tiles, same register-to-operand chaining.
+__device__ __forceinline__ void p2_chunk_back(const double* __restrict__ Ls, const double* __restrict__ Xs, pan_d4 (&acc)[4], int w,
+                                              int l15, int lk) {
+    double a0[4], a1[4], b0, b1;
+    auto frag = [&](int kk, double (&a)[4], double& b) {
+        b = Xs[(16 * w + l15) * PNL_LD + kk];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a[mi] = Ls[kk * PNL_LD + 16 * mi + l15];
+    };
+    frag(lk, a0, b0);
+#pragma unroll
+    for (int k4 = 0; k4 < 16; k4 += 2) {
+        frag(4 * (k4 + 1) + lk, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[mi], b0, acc[mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k4 + 2 < 16) frag(4 * (k4 + 2) + lk, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[mi], b1, acc[mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// T (this wave's 16 rows x 64 columns, T layout) <- X^T with X L = T, L the lower-triangular tile in Cs whose diagonal
+// 16 x 16 blocks have their inverses at p2_wblock().
+__device__ __forceinline__ void p2_strip_back(const double* __restrict__ Cs, pan_d4 (&T)[4], int l15, int lk) {
+#pragma unroll
+    for (int jb = 3; jb >= 0; --jb) {
+        const double* W = Cs + p2_wblock(jb);
+        pan_d4 x = pan_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)   // x^T = W^T t^T:  A[m][k] = W[k][m]
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(W[(4 * k4 + lk) * PNL_LD + l15], T[jb][k4], x, 0, 0, 0);
+        T[jb] = x;
+#pragma unroll
+        for (int j2 = jb - 1; j2 >= 0; --j2) {
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)   // t_j2^T -= L[jb][j2]^T x^T:  A[m][k] = L[16 jb + k][16 j2 + m]
+                T[j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Cs[(16 * jb + 4 * k4 + lk) * PNL_LD + 16 * j2 + l15], x[k4], T[j2], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void p2_row_block_back(const double* __restrict__ L, int ldl, int lrows, int c0, double* __restrict__ B, int ldb,
+                                                  int brows, int r0, int ncol, double* __restrict__ psm) {
+    double* Cs = psm;
+    double* Xs = psm + PNL_TILE;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    for (int c = ncol - 1; c >= 0; --c) {
+        pan_d4 acc[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi] = pan_d4{0.0, 0.0, 0.0, 0.0};
+        pan_d2 xa[8];   // the row block's own tile of column block u (operand of chunk u), finally of column block c itself
+        p2_gload(B, ldb, brows, r0, c0 + 64 * (ncol - 1), t, xa);
+        if (c < ncol - 1) {
+            pan_d2 la[8];
+            p2_gload(L, ldl, lrows, c0 + 64 * (ncol - 1), c0 + 64 * c, t, la);
+            for (int u = ncol - 1; u > c; --u) {
+                __syncthreads();   // the previous chunk's operand reads are done
+                p2_sstore(Cs, t, la);
+                p2_sstore(Xs, t, xa);
+                __syncthreads();
+                // next chunk's tiles in flight under this chunk's products; after the last chunk the row block's tile of
+                // column block c arrives the same way (the L index is clamped: a harmless repeat)
+                p2_gload(L, ldl, lrows, c0 + 64 * max(u - 1, c + 1), c0 + 64 * c, t, la);
+                p2_gload(B, ldb, brows, r0, c0 + 64 * (u - 1), t, xa);
+                __builtin_amdgcn_sched_barrier(0);
+                p2_chunk_back(Cs, Xs, acc, w, l15, lk);
+            }
+        }
+        __syncthreads();
+        p2_sstore(Xs, t, xa);
+        {
+            pan_d2 lt[8];
+            p2_gload(L, ldl, lrows, c0 + 64 * c, c0 + 64 * c, t, lt);
+            p2_sstore(Cs, t, lt);
+        }
+        __syncthreads();
+        pan_d4 T[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) T[mi][v] = Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] - acc[mi][v];
+        p2_inverse_blocks(Cs, w, lane);
+        __syncthreads();
+        p2_strip_back(Cs, T, l15, lk);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] = T[mi][v];
+        __syncthreads();
+        p2_gstore(B, ldb, brows, r0, c0 + 64 * c, Xs, t, false);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void trsm_block2_back_kernel(TrsmBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    p2_row_block_back(a.L, a.ldl, a.n, a.c0, a.B, a.ldb, a.nrows, 64 * (int)blockIdx.x, a.S, psm);
+}
+
+static int trsm_block_back_fused2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, hipStream_t stream) {
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&trsm_block2_back_kernel), P2_LDS_BYTES));
+    TrsmBlockArgs a{L, n, ldl, B, nrows, ldb, c0, S, 0};
+    hipLaunchKernelGGL(trsm_block2_back_kernel, dim3(gpar_ceil_div(nrows, 64)), dim3(256), P2_LDS_BYTES, stream, a);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // X_bb = L_bb^-T for ALL 64 S-column diagonal blocks of a factor in one launch (X holds the identity on entry): the
 // triangular-solve row-block task on the identity, blockIdx.y = diagonal block.  Leaves of the recursive inversion in
 // chol_inverse_run (potrf.h).

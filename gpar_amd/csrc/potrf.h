@@ -368,6 +368,7 @@ static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nro
                              hipStream_t stream);
 static int env_int(const char* name, int dflt);
 static int trinv_blocks_fused2(const double* L, int n, int ldl, double* X, int ldx, int S, hipStream_t stream);
+static int trsm_block_back_fused2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, hipStream_t stream);
 
 static inline int potrf_panel_any(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed) {
     return env_int("GPAR_PANEL_V", 2) >= 2 ? potrf_panel_fused2(A, N, lda, k0, W, logdet, info, stream, prezeroed)
@@ -808,6 +809,33 @@ static int trsv_rln_run(const double* L, int n, int ldl, double* b, hipStream_t 
 static int trsm_rln_run(const double* L, int n, int ldl, double* B, int nrows, int ldb, hipStream_t stream) {
     if (nrows <= 0) return 0;
     if (nrows == 1 && n >= 128 && env_int("GPAR_TRSV", 1)) return trsv_rln_run(L, n, ldl, B, stream);
+    // Many rows and n >= 1024: 512-column blocks from the last to the first, each solved by the fused backward block kernel
+    // (panel2.h) and followed by ONE K = 512 NN update of everything to its left - instead of 64-column strips with a K = 64
+    // update each (16 + 16 launches per 1024 columns, the updates at a fifth of the rate).  A ragged tail (n not a multiple of
+    // 64) goes first, by the strip path.
+    const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && env_int("GPAR_PANEL_V", 2) >= 2 && n >= 1024 && nrows >= 64 && gpar_aligned16(L) &&
+                         gpar_aligned16(B) && (ldl % 2 == 0) && (ldb % 2 == 0);
+    int ntop = n;   // columns [0, ntop) still to be solved
+    if (fusable) {
+        const int rag = n % 64;
+        if (rag) {
+            const int c = n - rag;
+            launch_strip<false>(L + (size_t)c * ldl + c, ldl, rag, B + c, ldb, nrows, stream);
+            int rc = gemm_launch(0, 0, nrows, c, rag, -1.0, B + c, ldb, L + (size_t)c * ldl, ldl, 1.0, B, ldb, 0, stream);
+            if (rc) return rc;
+            ntop = c;
+        }
+        while (ntop > 0) {
+            const int w = ntop % 512 ? ntop % 512 : 512;   // the (possibly short) last block first: the others are whole
+            const int c0 = ntop - w;
+            int rc = trsm_block_back_fused2(L, n, ldl, B, nrows, ldb, c0, w / 64, stream);
+            if (!rc && c0 > 0) rc = gemm_launch(0, 0, nrows, c0, w, -1.0, B + c0, ldb, L + (size_t)c0 * ldl, ldl, 1.0, B, ldb, 0, stream);
+            if (rc) return rc;
+            ntop = c0;
+        }
+        GPAR_LAUNCH_CHECK();
+        return 0;
+    }
     const int nblk = gpar_ceil_div(n, POTRF_NBI);
     for (int b = nblk - 1; b >= 0; --b) {
         const int c = b * POTRF_NBI;
