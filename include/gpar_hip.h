@@ -195,7 +195,8 @@ int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb
 /* B <- B L^-1  (right side, lower, not transposed: backward substitution on the rows of B). */
 int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);
 
-/* Kinv (lower triangle) <- (L L^T)^-1 given the Cholesky factor L; X is an n x n workspace (holds L^-T on exit).
+/* Kinv (lower triangle) <- (L L^T)^-1 given the Cholesky factor L; X is an n x n workspace (its upper triangle holds L^-T on
+ * exit; below the diagonal it is scratch).
  * Triangular-aware: 2 n^3 / 3 flops.  Kinv doubles as scratch while L^-T is formed (recursive blocked inversion for n a
  * multiple of 512, otherwise the solve of the identity).  [the K^-1 that the analytic gradient
  * 1/2 tr((aa^T - K^-1) dK) needs; replaces autograd through cholesky / solve_triangular, gpar/regression.py:459] */
