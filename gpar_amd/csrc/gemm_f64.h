@@ -32,6 +32,21 @@ constexpr int GEMM_LDKC = 18;
 constexpr int GEMM_LDMC = 144;
 constexpr int GEMM_TILE = 2304;  // doubles per operand stage (128*18 == 16*144)
 constexpr int GEMM_LDS_BYTES = 4 * GEMM_TILE * 8;
+// Build-time switches of the tile's tail (A/B'd with tools/time_gemm_phases.hip and tools/ab_variants.sh; round 2: the
+// epilogue's share of a K = 512 tile went from 12 to 5 us, most of which the co-resident workgroup's K loop takes back -
+// a compute unit finishes two tiles per ~125 us either way, against 109 us of pure MFMA issue):
+//   EPI_PRIO     issue priority of a wave in its epilogue (the K loop's MFMA phase runs at 1)
+//   NT_STORE     the tile of C is written with non-temporal stores (it is next read a whole trailing update later)
+//   PRELOAD_C    interior tiles of C <- C -+ op(A) op(B) start their accumulators from C (see gemm_mainloop_pf2)
+#ifndef GPAR_GEMM_EPI_PRIO
+#define GPAR_GEMM_EPI_PRIO 3
+#endif
+#ifndef GPAR_GEMM_NT_STORE
+#define GPAR_GEMM_NT_STORE 1
+#endif
+#ifndef GPAR_GEMM_PRELOAD_C
+#define GPAR_GEMM_PRELOAD_C 1
+#endif
 constexpr int GEMM_LDT = 66;     // row pitch of the epilogue's transposition buffer: 16 x 66 doubles per wave
 
 struct GemmArgs {
@@ -209,7 +224,12 @@ __device__ __forceinline__ void gemm_stage(const GemmArgs& p, const double* __re
 // HBM, so with a one-stage distance a workgroup that is alone on its CU - every launch with fewer tiles than CUs: the
 // look-ahead slices and the whole tail of a factorisation - waited for memory in every stage.  Fast modes only (the
 // prefetch index is clamped to the last stage instead of being guarded, which needs branch-free loads).
-template <bool A_KC, bool B_KC, int FAST, int BM>
+//
+// PRELOAD (interior tiles of an update C <- C -+ op(A) op(B), i.e. beta = 1, alpha = -+1): the accumulators start from
+// alpha * C instead of zero - its 64 loads per lane, straight into the MFMA D layout (8-byte accesses in full 128-byte
+// runs), leave with the operand loads of the first two stages and share their round trip - and the epilogue only stores
+// alpha * acc: the tile's read of C is off the tail of the workgroup, where nothing covered it.
+template <bool A_KC, bool B_KC, int FAST, int BM, bool PRELOAD = false>
 __device__ __forceinline__ void gemm_mainloop_pf2(const GemmArgs& p, double* smem, gpar_d4 (&acc)[BM / 32][4], int m0, int n0,
                                                   int kbeg, int kend, int nk, int t, int lane, int wm, int wn) {
     static_assert(FAST != 0, "branch-free loads only");
@@ -222,6 +242,21 @@ __device__ __forceinline__ void gemm_mainloop_pf2(const GemmArgs& p, double* sme
     gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, kbeg, kend, false, t, rb0);
     gemm_gload<A_KC, FAST, BM>(p.A, p.lda, m0, p.m, min(kbeg + GEMM_BK, klast), kend, false, t, ra1);
     gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, min(kbeg + GEMM_BK, klast), kend, false, t, rb1);
+    if (PRELOAD) {
+        // wave-uniform base (scalar registers) + one 32-bit lane offset: no per-row address registers beside the accumulators
+        const int wmu = __builtin_amdgcn_readfirstlane(wm), wnu = __builtin_amdgcn_readfirstlane(wn);
+        const double* cw = p.C + (size_t)(m0 + wmu * (BM / 2)) * p.ldc + n0 + wnu * 64;
+        const unsigned voff = ((unsigned)(lane >> 4) * (unsigned)p.ldc + (unsigned)(lane & 15)) * 8u;   // bytes; < 2^32: 3 rows of C
+        const double sgn = p.alpha;   // +-1: alpha * C == C / alpha exactly
+#pragma unroll
+        for (int mi = 0; mi < BM / 32; ++mi)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const char* cr = reinterpret_cast<const char*>(cw + (size_t)(16 * mi + 4 * v) * p.ldc);
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) acc[mi][nj][v] = sgn * *reinterpret_cast<const double*>(cr + voff + 128 * nj);
+            }
+    }
     gemm_sstore<A_KC, BM>(buf0, t, ra0);
     gemm_sstore<B_KC>(buf0 + GEMM_TILE, t, rb0);
     __syncthreads();
@@ -243,6 +278,55 @@ __device__ __forceinline__ void gemm_mainloop_pf2(const GemmArgs& p, double* sme
         __syncthreads();
     }
     __syncthreads();   // the epilogue reuses the stage buffers
+}
+
+// Epilogue of an interior tile with a 16-byte aligned C: the accumulators go through LDS (the operand stages are dead after
+// the K loop; every wave owns a private slice, so no workgroup barrier is needed) so that each lane ends up with two
+// ADJACENT columns of one row: 16-byte accesses, two full 512-byte row segments per wave instruction, instead of 8-byte
+// accesses in 128-byte runs straight from the MFMA layout.  Four quarters of 16 rows (one mi each); the C values of quarter
+// h + 1 are requested before quarter h is processed.
+template <int MI, bool HAS_BETA>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, double* smem, gpar_d4 (&acc)[MI][4], int row0, int col0,
+                                                  double alpha, double beta, int w, int lane) {
+    const int l15 = lane & 15, lk = lane >> 4;
+    double* S = smem + w * GEMM_TILE;                     // [16][GEMM_LDT] doubles, private to this wave
+    const int rrow = lane >> 5, rcol = (lane & 31) * 2;   // read-back: row 2 q + rrow, columns rcol, rcol + 1
+    double* cbase = p.C + (size_t)(row0 + rrow) * p.ldc + col0 + rcol;
+    gpar_d2 cv[2][8];
+    if (HAS_BETA) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cv[0][q] = *reinterpret_cast<const gpar_d2*>(cbase + (size_t)(2 * q) * p.ldc);
+    }
+#pragma unroll
+    for (int h = 0; h < MI; ++h) {
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) S[(lk + 4 * v) * GEMM_LDT + 16 * nj + l15] = acc[h][nj][v];
+        if (HAS_BETA && h < MI - 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                cv[(h + 1) & 1][q] = *reinterpret_cast<const gpar_d2*>(cbase + (size_t)(16 * (h + 1) + 2 * q) * p.ldc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        gpar_d2 v2[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v2[q] = *reinterpret_cast<const gpar_d2*>(S + (2 * q + rrow) * GEMM_LDT + rcol);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the next quarter overwrites S
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            gpar_d2 o = v2[q] * alpha;
+            if (HAS_BETA) o = gpar_d2{fma(beta, cv[h & 1][q][0], o[0]), fma(beta, cv[h & 1][q][1], o[1])};
+#if GPAR_GEMM_NT_STORE
+            __builtin_nontemporal_store(o, reinterpret_cast<gpar_d2*>(cbase + (size_t)(16 * h + 2 * q) * p.ldc));
+#else
+            *reinterpret_cast<gpar_d2*>(cbase + (size_t)(16 * h + 2 * q) * p.ldc) = o;
+#endif
+        }
+    }
 }
 
 // TA: A stored k x m (op(A) = A^T);  TB: B stored n x k (op(B) = B^T).
@@ -330,61 +414,34 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
 
     const bool fastk = p.fastA && p.fastB && !a_lower && ((kend - kbeg) % GEMM_BK == 0);
     const bool inner = (m0 + BM <= p.m) && (n0 + GEMM_BN <= p.n);
-    if (fastk && inner) gemm_mainloop_pf2<A_KC, B_KC, 1, BM>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
+    // (see PRELOAD above; not with split-K, whose slabs are partial sums, nor for diagonal tiles of a lower-triangular C)
+    const bool c_lower = (p.flags & GPAR_GEMM_C_LOWER) != 0;
+    const bool preload = GPAR_GEMM_PRELOAD_C && fastk && inner && nk > 0 && p.ksplit <= 0 && p.beta == 1.0 &&
+                         (p.alpha == 1.0 || p.alpha == -1.0) && (!c_lower || n0 + GEMM_BN - 1 <= m0);
+    if (preload) gemm_mainloop_pf2<A_KC, B_KC, 1, BM, true>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
+    else if (fastk && inner) gemm_mainloop_pf2<A_KC, B_KC, 1, BM>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
     else if (fastk && A_KC && B_KC) gemm_mainloop_pf2<A_KC, B_KC, 2, BM>(p, smem, acc, m0, n0, kbeg, kend, nk, t, lane, wm, wn);
     else gemm_mainloop<A_KC, B_KC, 0, BM>(p, smem, acc, m0, n0, kbeg, kend, nk, a_lower, t, lane, wm, wn);
     const long long t_main = p.stamps ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+#if GPAR_GEMM_EPI_PRIO
+    __builtin_amdgcn_s_setprio(GPAR_GEMM_EPI_PRIO);
+#endif
     const int l15 = lane & 15, lk = lane >> 4;
 
     // epilogue: register v of acc[mi][nj] holds C[16 mi + (lane >> 4) + 4 v][16 nj + (lane & 15)] of the wave tile
-    const bool c_lower = (p.flags & GPAR_GEMM_C_LOWER) != 0;
     const int colw = n0 + wn * 64 + l15;
     const int roww = m0 + wm * (BM / 2) + lk;
-    const double alpha = p.alpha, beta = p.beta;
+    const double alpha = p.alpha, beta = preload ? 0.0 : p.beta;
     // Loads of C are never placed behind a per-element condition (hipcc would fence each with vmcnt(0): 64 serial
     // memory round trips per tile, measured as a fixed ~20 us per tile): interior tiles use plain loads/stores, edge
     // tiles load from clamped (always valid) addresses and only the stores are predicated.
     const bool interior = (m0 + BM <= p.m) && (n0 + GEMM_BN <= p.n) && (!c_lower || n0 + GEMM_BN - 1 <= m0);
     if (interior && p.fastC) {
-        // Interior tile, 16-byte aligned C: transpose the accumulators through LDS (the operand stages are dead
-        // after the K loop; every wave owns a private slice, so no workgroup barrier is needed) so that each lane ends
-        // up with two ADJACENT columns of one row: 16-byte accesses, two full 512-byte row segments per wave
-        // instruction, instead of 8-byte accesses in 128-byte runs straight from the MFMA layout.
-        double* S = smem + w * GEMM_TILE;                     // [16][GEMM_LDT] doubles, private to this wave
-        const int rrow = lane >> 5, rcol = (lane & 31) * 2;   // read-back: row 2 q + rrow, columns rcol, rcol + 1
-        double* cbase = p.C + (size_t)(m0 + wm * (BM / 2) + rrow) * p.ldc + n0 + wn * 64 + rcol;
-        // four quarters of 16 rows (one mi each); the C values of quarter h + 1 are requested before quarter h is processed
-        gpar_d2 cv[2][8];
-        if (beta != 0.0) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) cv[0][q] = *reinterpret_cast<const gpar_d2*>(cbase + (size_t)(2 * q) * p.ldc);
-        }
-#pragma unroll
-        for (int h = 0; h < MI; ++h) {
-#pragma unroll
-            for (int nj = 0; nj < 4; ++nj)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) S[(lk + 4 * v) * GEMM_LDT + 16 * nj + l15] = acc[h][nj][v];
-            if (h < MI - 1 && beta != 0.0) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    cv[(h + 1) & 1][q] = *reinterpret_cast<const gpar_d2*>(cbase + (size_t)(16 * (h + 1) + 2 * q) * p.ldc);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            gpar_d2 v2[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v2[q] = *reinterpret_cast<const gpar_d2*>(S + (2 * q + rrow) * GEMM_LDT + rcol);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();   // the next quarter overwrites S
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                gpar_d2 o = v2[q] * alpha;
-                if (beta != 0.0) o = gpar_d2{fma(beta, cv[h & 1][q][0], o[0]), fma(beta, cv[h & 1][q][1], o[1])};
-                *reinterpret_cast<gpar_d2*>(cbase + (size_t)(16 * h + 2 * q) * p.ldc) = o;
-            }
-        }
+        // (beta == 0 / != 0 are two instantiations: with the test inside, hipcc's counter bookkeeping assumed at every use of a
+        // prefetched C value that the NEXT quarter's loads might not have been issued and waited for those too - the prefetch
+        // bought nothing and each quarter exposed a trip to HBM: 12 us per tile, `profiles/r01_gemm_phases.txt`)
+        if (beta != 0.0) gemm_epilogue_lds<MI, true>(p, smem, acc, m0 + wm * (BM / 2), n0 + wn * 64, alpha, beta, w, lane);
+        else gemm_epilogue_lds<MI, false>(p, smem, acc, m0 + wm * (BM / 2), n0 + wn * 64, alpha, beta, w, lane);
     } else if (interior) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {

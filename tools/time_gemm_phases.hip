@@ -16,9 +16,14 @@ int main(int argc, char** argv) {
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, p.flags);
     hipMalloc(&st, sizeof(long long) * 4 * ntiles); p.stamps = st;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    for (int rep = 0; rep < 2; ++rep) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, 0);
         hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), dim3(ntiles), dim3(256), GEMM_LDS_BYTES, 0, p);
+        hipEventRecord(e1, 0);
         hipDeviceSynchronize();
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        printf("launch %.1f us (events)\n", 1000.0 * ms);
     }
     std::vector<long long> h(4 * (size_t)ntiles);
     hipMemcpy(h.data(), st, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
