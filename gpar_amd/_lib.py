@@ -96,6 +96,13 @@ SIGNATURES = {
         [ctypes.POINTER(FSpec), ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, ctypes.c_long, _ptr, _c_dbl, _ptr, _c_int, _ptr, _c_int,
          _ptr, _ptr, _ptr, _c_int, _ptr],
     ),
+    "gpar_logpdf_dense_build": (
+        _c_int,
+        [ctypes.POINTER(FSpec), ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, ctypes.c_long, _ptr, _c_dbl, _ptr, _c_int, _ptr, _c_int,
+         _ptr, _ptr, _ptr],
+    ),
+    "gpar_potrf_batch": (_c_int, [_ptr, _c_int, ctypes.c_longlong, _c_int, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr]),
+    "gpar_logpdf_dense_finish": (_c_int, [_ptr, _c_int, ctypes.c_longlong, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "gpar_potrf": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "gpar_potrf_ex": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr]),
     "gpar_trsm_rlt": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),

@@ -192,7 +192,10 @@ __global__ __launch_bounds__(256) void logpdf_prepare_kernel(const double* __res
 }
 
 __global__ void logpdf_value_kernel(const double* __restrict__ A, int lda, int n, double n_log_2pi, const double* __restrict__ logdet,
-                                    double* __restrict__ value) {
+                                    double* __restrict__ value, long long batch_a = 0) {
+    A += (size_t)blockIdx.x * batch_a;   // batched: one block per matrix, its words at logdet[b] / value[b]
+    logdet += blockIdx.x;
+    value += blockIdx.x;
     // the corner holds -|L^-1 y|^2 (potrf.h: the augmented row's Schur complement).  Two additions and an exact scaling, the
     // product n log 2 pi formed on the host: the same roundings as the host-side expression this replaces (a multiply next to
     // an add would be contracted into a fused multiply-add here), so that the fused and the separate paths return the same bits.
@@ -235,6 +238,38 @@ int gpar_logpdf_dense(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const doub
     if (rc) return rc;
     hipLaunchKernelGGL(logpdf_value_kernel, dim3(1), dim3(1), 0, st, (const double*)A, lda, n, (double)n * 1.8378770664093453,
                        (const double*)logdet, value);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_logpdf_dense_build(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, const double* y, long incy,
+                            const double* noise_diag, double jitter, double* z, int ldz, double* A, int lda, double* logdet, int* info,
+                            void* stream) {
+    GPAR_API_GUARD;
+    if (!fs || !ks || !A || !logdet || !info || (n > 0 && (!x || !y))) return GPAR_ARG_ERROR(1);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = featurize_launch(fs, x, n, ldx, z, ldz, st);
+    if (!rc && n > 0) rc = gram_launch(ks, z, n, ldz, z, n, ldz, fs->dz, A, lda, GPAR_GRAM_LOWER, noise_diag, jitter, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(logpdf_prepare_kernel, dim3(gpar_ceil_div(n + 1, 256)), dim3(256), 0, st, y, incy, n, A, lda, logdet, info);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_potrf_batch(double* A, int batch, long long stride_a, int N, int nf, int lda, double* logdet, int* info, int flags, void* stream) {
+    GPAR_API_GUARD;
+    if (N <= 0 || nf <= 0 || batch <= 0) return 0;
+    if (!A || !logdet || !info || stride_a < 0) return GPAR_ARG_ERROR(1);
+    return potrf_run_batch(A, batch, stride_a, N, nf, lda, logdet, info, (hipStream_t)stream, flags);
+}
+
+int gpar_logpdf_dense_finish(const double* A, int batch, long long stride_a, int n, int lda, const double* logdet, double* value,
+                             void* stream) {
+    GPAR_API_GUARD;
+    if (batch <= 0) return 0;
+    if (!A || !logdet || !value || n < 0) return GPAR_ARG_ERROR(1);
+    hipLaunchKernelGGL(logpdf_value_kernel, dim3(batch), dim3(1), 0, (hipStream_t)stream, A, lda, n, (double)n * 1.8378770664093453, logdet,
+                       value, stride_a);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

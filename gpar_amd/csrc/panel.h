@@ -42,6 +42,8 @@ struct PanelArgs {
     double* logdet;
     int* info;
     long long* stamps;   // dev aid (tools/time_panel.hip): cycle stamps of the critical chain, normally null
+    long long batch_a = 0;   // batched launch (panel2.h, gridDim.y matrices of the same shape): matrix y starts at A + y * batch_a,
+                             // its logdet / info words are logdet[y], info[y]
 };
 
 __device__ __forceinline__ unsigned long long* pnl_flag(const PanelArgs& p, int f) {
@@ -409,15 +411,16 @@ static int panel_grid_cap() {
 // gpar_potrf writes the strict upper triangle of a diagonal block before that block's own panel kernel does, and two
 // hipMemsetAsync per panel were ~12 us of idle chip on the serial chain (32 panels at n = 16384).
 constexpr int PNL_FLAG_ROWS = (PNL_MAX_S + PNL_MAX_S * PNL_MAX_S + PNL_FLAG_SLOTS - 1) / PNL_FLAG_SLOTS;
-__global__ __launch_bounds__(256) void potrf_zero_flags_kernel(double* __restrict__ A, int lda) {
+__global__ __launch_bounds__(256) void potrf_zero_flags_kernel(double* __restrict__ A, int lda, long long batch_a) {
+    A += (size_t)blockIdx.y * batch_a;
     const int k0 = blockIdx.x * 64;
     for (int i = threadIdx.x; i < PNL_FLAG_ROWS * PNL_FLAG_SLOTS; i += blockDim.x)
         A[(size_t)(k0 + i / PNL_FLAG_SLOTS) * lda + k0 + 8 + i % PNL_FLAG_SLOTS] = 0.0;
 }
 // true if the flags of a panel starting at k0 are covered by potrf_zero_flags(A, N, ...)
 static inline bool potrf_flags_prezeroed(int N, int k0) { return k0 % 64 == 0 && k0 + 64 <= N; }
-static void potrf_zero_flags(double* A, int N, int lda, hipStream_t stream) {
-    if (N >= 64) hipLaunchKernelGGL(potrf_zero_flags_kernel, dim3(N / 64), dim3(256), 0, stream, A, lda);
+static void potrf_zero_flags(double* A, int N, int lda, hipStream_t stream, int batch = 1, long long batch_a = 0) {
+    if (N >= 64) hipLaunchKernelGGL(potrf_zero_flags_kernel, dim3(N / 64, batch), dim3(256), 0, stream, A, lda, batch_a);
 }
 
 static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream,

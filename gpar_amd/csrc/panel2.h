@@ -836,6 +836,11 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
 // launch bounds (256, 2): at most 256 unified registers, so that a wave fits beside a trailing-update wave (see panel.h)
 __global__ __launch_bounds__(256, 2) void potrf_panel2_kernel(PanelArgs p) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
+    // batched launch: blockIdx.y picks the matrix.  Workgroups are dispatched x first, then y, and a row block only ever waits
+    // for row blocks with a smaller x of its own matrix, i.e. for workgroups dispatched before it: any number of matrices is safe.
+    p.A += (size_t)blockIdx.y * p.batch_a;
+    if (p.logdet) p.logdet += blockIdx.y;
+    if (p.info) p.info += blockIdx.y;
     const int rb = blockIdx.x;
     const int r0 = p.k0 + 64 * rb;
     if (rb < p.S) {
@@ -847,14 +852,16 @@ __global__ __launch_bounds__(256, 2) void potrf_panel2_kernel(PanelArgs p) {
 }
 
 static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream,
-                              bool prezeroed = false) {
+                              bool prezeroed = false, int batch, long long batch_a) {
     PanelArgs p{A, N, lda, k0, W / 64, logdet, info, nullptr};
+    p.batch_a = batch_a;
     if (p.S > PNL_MAX_S) return GPAR_ARG_ERROR(5);
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_panel2_kernel), P2_LDS_BYTES));
     if (!(prezeroed && potrf_flags_prezeroed(N, k0)))
-        GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)k0 * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream));
+        for (int b = 0; b < batch; ++b)
+            GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)b * batch_a + (size_t)k0 * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream));
     const int R = (N - k0 + 63) / 64;
-    hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R), dim3(256), P2_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R, batch), dim3(256), P2_LDS_BYTES, stream, p);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

@@ -112,6 +112,49 @@ def logpdf_dense(ck, x, y, noise_diag, jitter, lookahead=True, fused=True):
     return words[0], words[1:], info, A
 
 
+def logpdf_dense_batch(items, jitter, fused=True):
+    """log N(y_b; 0, k_b(x_b, x_b) + diag(noise_b) + jitter I) for layers b that share their number of rows and do not feed one
+    another: per layer one gpar_logpdf_dense_build, then ONE lock-step gpar_potrf_batch and one gpar_logpdf_dense_finish.
+    `items`: (compiled kernel, x, y, noise_diag or None) per layer.  Returns (values, info): `batch` device words each."""
+    lib = _lib.load()
+    batch = len(items)
+    x0 = items[0][1]
+    n, dev = x0.shape[0], x0.device
+    A = alloc_matrix(batch * (n + 1), n + 1, dev)   # matrix b = rows b (n + 1) ... of one buffer
+    lda = _ld(A)
+    stride = (n + 1) * lda          # lda is a multiple of 16: every matrix starts 128-byte aligned
+    words = torch.empty(2 * batch, dtype=torch.float64, device=dev)   # values, logdets
+    info = torch.empty(batch, dtype=torch.int32, device=dev)
+    st = stream_ptr(dev)
+    keep = []
+    for b, (ck, x, y, noise_diag) in enumerate(items):
+        _check_mat(x, "x")
+        y = y.reshape(-1)
+        if x.shape[0] != n or y.numel() != n or y.dtype != torch.float64 or not y.is_cuda:
+            raise ValueError("every layer of a batch must hold one fp64 device value per row, and the same number of rows")
+        nptr = None
+        if noise_diag is not None:
+            noise_diag = noise_diag.reshape(-1).contiguous()
+            if noise_diag.numel() != n:
+                raise ValueError("noise_diag must hold one value per row of x")
+            nptr = noise_diag.data_ptr()
+        z = alloc_matrix(n, max(ck.dz, 1), dev)
+        keep.append((z, y, noise_diag))
+        _lib.check(
+            lib.gpar_logpdf_dense_build(
+                ctypes.byref(ck.fspec), ctypes.byref(ck.kspec), x.data_ptr(), n, _ld(x), y.data_ptr(), int(y.stride(0)), nptr, float(jitter),
+                z.data_ptr(), _ld(z), A.data_ptr() + 8 * b * stride, lda, words.data_ptr() + 8 * (batch + b), info.data_ptr() + 4 * b, st,
+            ),
+            "gpar_logpdf_dense_build",
+        )
+    flags = 0 if fused else _lib.POTRF_UNFUSED
+    _lib.check(lib.gpar_potrf_batch(A.data_ptr(), batch, stride, n + 1, n, lda, words.data_ptr() + 8 * batch, info.data_ptr(), flags, st),
+               "gpar_potrf_batch")
+    _lib.check(lib.gpar_logpdf_dense_finish(A.data_ptr(), batch, stride, n, lda, words.data_ptr() + 8 * batch, words.data_ptr(), st),
+               "gpar_logpdf_dense_finish")
+    return words[:batch], info
+
+
 def gram(ck, z1, z2=None, out=None, lower=False, diag_add=None, diag_const=0.0, row_scale=None):
     """K = k(z1, z2) (z2 None: symmetric, optionally lower-only, + diag_add + diag_const on the diagonal); with `row_scale`
     (n1 weights) row a is multiplied by row_scale[a]."""
@@ -177,6 +220,25 @@ def potrf_(A, nf=None, logdet=None, info=None, lookahead=True, fused=True):
     flags = (0 if lookahead else _lib.POTRF_NO_LOOKAHEAD) | (0 if fused else _lib.POTRF_UNFUSED)
     _lib.check(
         lib.gpar_potrf_ex(A.data_ptr(), N, nf, _ld(A), logdet.data_ptr(), info.data_ptr(), flags, stream_ptr(A.device)), "gpar_potrf_ex"
+    )
+    return logdet, info
+
+
+def potrf_batch_(A, batch, nf=None, fused=True):
+    """In-place (partial) Cholesky of `batch` square N x N matrices stacked by rows in A ((batch N) x N, one leading
+    dimension), factored in lock-step (gpar_potrf_batch); returns (logdet, info): `batch` device words each."""
+    lib = _lib.load()
+    _check_mat(A, "A")
+    N = A.shape[1]
+    if A.shape[0] != batch * N:
+        raise ValueError("A must hold batch square matrices stacked by rows")
+    nf = N if nf is None else int(nf)
+    logdet = torch.zeros(batch, dtype=torch.float64, device=A.device)
+    info = torch.zeros(batch, dtype=torch.int32, device=A.device)
+    _lib.check(
+        lib.gpar_potrf_batch(A.data_ptr(), batch, N * _ld(A), N, nf, _ld(A), logdet.data_ptr(), info.data_ptr(),
+                             0 if fused else _lib.POTRF_UNFUSED, stream_ptr(A.device)),
+        "gpar_potrf_batch",
     )
     return logdet, info
 

@@ -119,6 +119,28 @@ def per_output(y, w=None, keep=False):
         y, w, available = y[mask], w[mask], available[mask]
 
 
+def _lockstep_values(eng, pending):
+    """Log marginal likelihoods of layers that do not feed one another and share their number of rows: one lock-step batch
+    (HipEngine.logpdf_dense_batch) when every one of them qualifies for the value-only path, one after the other otherwise."""
+    obs = [o for _, o in pending]
+    if len(obs) < 2 or not all(o._value_only() for o in obs) or len({int(o.fdd.n) for o in obs}) != 1:
+        return [f.measure.logpdf(o) for f, o in pending]
+    n = int(obs[0].fdd.n)
+    cap = max(1, eng.batch_bytes() // (8 * (n + 1) * (n + 17)))   # layers per batch within the workspace budget
+    values = []
+    for i in range(0, len(obs), cap):
+        chunk = obs[i:i + cap]
+        if len(chunk) < 2:
+            values.extend(pending[i + j][0].measure.logpdf(o) for j, o in enumerate(chunk))
+            continue
+        items = [(eng.compile(o.base.kernel, o.fdd.x.shape[1]), o.fdd.x, o.y, o.fdd.noise) for o in chunk]
+        vals, info = eng.logpdf_dense_batch(items, eng.epsilon)
+        for b in range(len(chunk)):
+            eng.check_info(info[b:b + 1])
+        values.extend(vals[b].detach() for b in range(len(chunk)))
+    return values
+
+
 class GPAR:
     """Gaussian process autoregressive model.
 
@@ -215,6 +237,9 @@ class GPAR:
         # layers that do not feed one another (observed data only) are spread over alternating streams
         pipe = eng.pipeline(rows=int(x.shape[0])) if self._independent(items) and not return_inputs else None
         values, stage = [], 0
+        # ... or, when they are small enough for a factorisation to be one latency-bound chain, factored together in lock-step
+        lockstep = pipe is not None and hasattr(eng, "logpdf_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
+        pending = []
         with eng.defer_checks(), _joining(pipe):  # streams are joined BEFORE the deferred info words are read
             for is_last, ((yi, wi, mask), model) in last(zip(items, self.layers), select=outputs):
                 complete = isinstance(mask, slice)
@@ -223,6 +248,14 @@ class GPAR:
                 if pipe is not None and _differentiable(f, noise):
                     pipe.join()
                     pipe = None  # an objective under autograd: keep everything on the caller's stream
+                if pipe is not None and lockstep:
+                    if not only_last_layer or is_last:
+                        obs = self._obs(x, x_ind, yi, wi, f, noise, complete=True)
+                        obs.transient = True
+                        pending.append((f, obs))
+                    if not is_last:
+                        x = torch.cat([x, yi], dim=1)
+                    continue
                 if pipe is not None:
                     if not only_last_layer or is_last:
                         with pipe.stage(stage, x, yi, wi):
@@ -246,6 +279,8 @@ class GPAR:
                     x, x_ind = self._update_inputs(x, x_ind, yi, f, obs, complete=complete)
             if pipe is not None:
                 pipe.join()
+            if pending:
+                values.extend(_lockstep_values(eng, pending))
             for v in values:
                 total = total + v
         if return_inputs:

@@ -189,6 +189,24 @@ int gpar_logpdf_dense(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const doub
                       const double* noise_diag, double jitter, double* z, int ldz, double* A, int lda, double* logdet, int* info,
                       double* value, int potrf_flags, void* stream);
 
+/* The same in three steps, for `batch` layers that do not feed one another and have the same number of rows (complete data:
+ * the design matrix of layer i is [x, y_<i], known up front - gpar/model.py:221-243 visits them in a loop all the same):
+ *   gpar_logpdf_dense_build   per layer: features, Gram + noise_diag + jitter and the observations into its (n + 1) x (n + 1)
+ *                             matrix A_b = A + b * stride_a, its logdet[b] / info[b] zeroed;
+ *   gpar_potrf_batch          the `batch` partial factorisations in LOCK-STEP - one panel launch and one batched trailing update
+ *                             per 512 columns.  At the sizes where a factorisation is a chain of latency-bound panel kernels
+ *                             (n <= ~4608) several of them on separate streams contend for compute-unit slots; in lock-step the
+ *                             chain is paid once and every launch carries `batch` times the parallel work;
+ *   gpar_logpdf_dense_finish  value[b] from the corner of A_b and logdet[b].
+ * Arguments as for gpar_logpdf_dense / gpar_potrf_ex; stride_a (elements, even) separates consecutive matrices; logdet / info /
+ * value hold `batch` words.  [sum over layers of f.measure.logpdf(obs), gpar/model.py:221-243] */
+int gpar_logpdf_dense_build(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, const double* y, long incy,
+                            const double* noise_diag, double jitter, double* z, int ldz, double* A, int lda, double* logdet, int* info,
+                            void* stream);
+int gpar_potrf_batch(double* A, int batch, long long stride_a, int N, int nf, int lda, double* logdet, int* info, int flags, void* stream);
+int gpar_logpdf_dense_finish(const double* A, int batch, long long stride_a, int n, int lda, const double* logdet, double* value,
+                             void* stream);
+
 /* B <- B L^-T  (right side, lower, transposed: forward substitution on the rows of B; B is nrows x n).
  * [solve_triangular inside matrix.iqf_diag / PosteriorKernel, reached from gpar/model.py:226,264,298] */
 int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);

@@ -442,6 +442,75 @@ def test_fused_dense_logpdf_entry_point(env, n):
     assert np.allclose(got[n, :n], zr, rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("N,nf,batch", [(1024, 1024, 3), (1601, 1600, 4), (700, 700, 2), (1100, 1038, 3), (100, 100, 2), (2048, 1024, 5)])
+def test_lockstep_batch_factorisation_equals_one_at_a_time(env, N, nf, batch):
+    """gpar_potrf_batch: `batch` (partial) factorisations in lock-step - one panel launch and one batched trailing update per 512
+    columns - leave in every matrix what gpar_potrf leaves in it alone (factor, Schur complement, logdet, info), and one
+    indefinite matrix in the batch is reported in its own info word without disturbing the others."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(N + batch)
+    mats = []
+    for b in range(batch):
+        G = rng.standard_normal((N, N + 8))
+        mats.append(G @ G.T / N + (0.5 + b) * np.eye(N))
+    stacked = hip.alloc_matrix(batch * N, N, dev)
+    stacked.copy_(to_dev(np.concatenate(mats, axis=0)))
+    logdet, info = hip.potrf_batch_(stacked, batch, nf)
+    assert info.cpu().tolist() == [0] * batch
+    got = stacked.cpu().numpy()
+    for b in range(batch):
+        single = to_dev(mats[b]).clone()
+        ld1, info1 = hip.potrf_(single, nf)
+        assert int(info1.item()) == 0
+        ref = single.cpu().numpy()
+        blk = got[b * N:(b + 1) * N]
+        assert np.allclose(np.tril(blk)[:, :nf], np.tril(ref)[:, :nf], rtol=1e-12, atol=1e-13)
+        assert np.allclose(np.tril(blk[nf:, nf:]), np.tril(ref[nf:, nf:]), rtol=1e-10, atol=1e-12)
+        assert abs(float(logdet[b]) - float(ld1)) <= 1e-11 * max(1.0, abs(float(ld1)))
+    # one indefinite member
+    bad = [m.copy() for m in mats]
+    j = min(nf - 1, 70)
+    bad[1][j, j] = -1.0
+    stacked.copy_(to_dev(np.concatenate(bad, axis=0)))
+    logdet, info = hip.potrf_batch_(stacked, batch, nf)
+    flags = info.cpu().tolist()
+    assert flags[1] == j + 1 and all(v == 0 for i, v in enumerate(flags) if i != 1)
+    got = stacked.cpu().numpy()
+    L0 = np.linalg.cholesky(mats[0])
+    assert np.allclose(np.tril(got[:N])[:, :nf], L0[:, :nf], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("n,batch", [(640, 3), (1500, 4), (77, 2)])
+def test_lockstep_dense_logpdf_equals_layer_by_layer(env, n, batch):
+    """hip.logpdf_dense_batch (build per layer, one lock-step factorisation, one finishing launch) returns per layer what
+    gpar_logpdf_dense returns for it alone; the layers have different kernels and input widths, as GPAR's layers do."""
+    from gpar_amd.kernels import EQ, Linear, compile_kernel
+
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    items, ref = [], []
+    for b in range(batch):
+        width = 2 + b
+        x = to_dev(rng.uniform(0, 1, (n, width)))
+        y = to_dev(rng.standard_normal((n, 1)))[:, 0]
+        noise = to_dev(rng.uniform(0.05, 0.2, (n, 1)))[:, 0] if b % 2 == 0 else None
+        kernel = (1.0 + 0.3 * b) * EQ().stretch(np.full(width - 1, 0.5)).select(list(range(width - 1))) + \
+            Linear().stretch(np.array([2.0])).select([width - 1])
+        ck = compile_kernel(kernel, width)
+        items.append((ck, x, y, noise))
+        value, _, info, _ = hip.logpdf_dense(ck, x, y, noise, 1e-8 if noise is not None else 1e-2)
+        assert int(info.item()) == 0
+        ref.append(float(value))
+    # the jitter is one number per call: evaluate the two groups of layers that share it
+    for group, jitter in (([b for b in range(batch) if b % 2 == 0], 1e-8), ([b for b in range(batch) if b % 2 == 1], 1e-2)):
+        if not group:
+            continue
+        vals, info = hip.logpdf_dense_batch([items[b] for b in group], jitter)
+        assert info.cpu().tolist() == [0] * len(group)
+        for v, b in zip(vals.cpu().tolist(), group):
+            assert abs(v - ref[b]) <= 1e-11 * max(1.0, abs(ref[b]))
+
+
 @pytest.mark.parametrize("n", [384, 1024, 1300])
 def test_gemm_triangular_aware_k_ranges(env, n):
     """K_FROM_ROW (upper-triangular op(A), zeros stored left of its diagonal) and K_TO_COL (upper-triangular op(B), zeros stored

@@ -176,6 +176,39 @@ def test_layer_pipeline_is_bit_identical_to_serial_evaluation(monkeypatch):
     assert got["sharded0"] == got["sharded2"] == got["0"], got
 
 
+@pytest.mark.parametrize("n,p", [(2100, 4), (512, 3), (4096, 2), (5000, 3)])
+def test_lockstep_layers_equal_layer_by_layer_evaluation(monkeypatch, n, p):
+    """Small independent layers are factored together in lock-step (HipEngine.logpdf_dense_batch, up to GPAR_LAYER_BATCH_ROWS
+    rows) instead of on separate streams: the same log marginal likelihood as the pipelined and the serial evaluation, and as
+    the oracle where that is cheap."""
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(n, 2, p, seed=n)
+
+    def run():
+        reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1)
+        out = {}
+        out["lockstep"] = float(reg.logpdf(x, y))
+        monkeypatch.setenv("GPAR_LAYER_BATCH_BYTES", str(8 * (n + 1) * (n + 17) * 2))   # two layers per batch (a last one alone)
+        out["lockstep_chunks"] = float(reg.logpdf(x, y))
+        monkeypatch.delenv("GPAR_LAYER_BATCH_BYTES")
+        monkeypatch.setenv("GPAR_LAYER_BATCH_ROWS", "0")
+        out["streams"] = float(reg.logpdf(x, y))
+        monkeypatch.setenv("GPAR_LAYER_PIPELINE", "0")
+        out["serial"] = float(reg.logpdf(x, y))
+        monkeypatch.delenv("GPAR_LAYER_PIPELINE")
+        monkeypatch.delenv("GPAR_LAYER_BATCH_ROWS")
+        return out
+
+    got = _on("hip", run)
+    assert got["streams"] == got["serial"], got
+    assert abs(got["lockstep"] - got["serial"]) <= 1e-11 * abs(got["serial"]), got
+    assert abs(got["lockstep_chunks"] - got["serial"]) <= 1e-11 * abs(got["serial"]), got
+    if n <= 600:
+        ref = _on("oracle", lambda: float(GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1).logpdf(x, y)))
+        assert abs(got["lockstep"] - ref) <= 1e-9 * abs(ref), (got, ref)
+
+
 def test_concurrent_layer_training_equals_serial_training(monkeypatch):
     """fit(fix=True) on observed data trains independent layers from two host threads on two streams; every objective
     evaluation is the same deterministic device computation, so the trained hyper-parameters are those of the serial
