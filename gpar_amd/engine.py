@@ -366,11 +366,12 @@ class HipEngine:
 
     @staticmethod
     def _raise_for(info):
-        code = int(info.item())
-        if code < 0:
-            raise HandOffTimeoutError(code)
-        if code != 0:
-            raise NotPositiveDefiniteError(code)
+        """`info`: one word or several (a lock-step batch, the words gathered over an evaluation): the first failure is reported."""
+        for code in info.reshape(-1).tolist():
+            if code < 0:
+                raise HandOffTimeoutError(int(code))
+            if code != 0:
+                raise NotPositiveDefiniteError(int(code))
 
 
 _STREAMS = {}  # device -> extra streams, shared by every engine of the process (the library pairs each caller stream
@@ -448,7 +449,10 @@ class _Deferred:
     def __exit__(self, exc_type, exc, tb):
         if self.outer is None:
             pending, self.eng._deferred = self.eng._deferred, None
-            if exc_type is None:
+            if exc_type is None and pending:
+                # one device-to-host copy for the whole evaluation (each read of a word is a synchronising copy of its own)
+                if len(pending) > 1 and all(isinstance(i, torch.Tensor) and i.is_cuda and i.dtype == pending[0].dtype for i in pending):
+                    pending = [torch.cat([i.reshape(-1) for i in pending])]
                 for info in pending:
                     self.eng._raise_for(info)
         return False

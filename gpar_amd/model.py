@@ -135,8 +135,7 @@ def _lockstep_values(eng, pending):
             continue
         items = [(eng.compile(o.base.kernel, o.fdd.x.shape[1]), o.fdd.x, o.y, o.fdd.noise) for o in chunk]
         vals, info = eng.logpdf_dense_batch(items, eng.epsilon)
-        for b in range(len(chunk)):
-            eng.check_info(info[b:b + 1])
+        eng.check_info(info)
         values.extend(vals[b].detach() for b in range(len(chunk)))
     return values
 
