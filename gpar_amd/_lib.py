@@ -112,6 +112,11 @@ SIGNATURES = {
         _c_int,
         [_c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _ptr, _c_int, _ptr, _c_int, _c_dbl, _ptr, _c_int, _c_int, _ptr],
     ),
+    "gpar_gemm_batch": (
+        _c_int,
+        [_c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _ptr, _c_int, ctypes.c_longlong, _ptr, _c_int, ctypes.c_longlong, _c_dbl, _ptr,
+         _c_int, ctypes.c_longlong, _c_int, _c_int, _ptr],
+    ),
     "gpar_gemm_splitk": (
         _c_int,
         [_c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _ptr, _c_int, _ptr, _c_int, _c_dbl, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr],
@@ -124,6 +129,11 @@ SIGNATURES = {
     "gpar_workspace_doubles": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
     "gpar_randn": (_c_int, [_u64, _u64, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "gpar_trmv_lower": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr]),
+    "gpar_trmv_lower_batch": (
+        _c_int,
+        [_ptr, _c_int, ctypes.c_longlong, _c_int, _c_int, _ptr, _c_int, ctypes.c_longlong, _ptr, _c_int, ctypes.c_longlong, _ptr, _c_int,
+         ctypes.c_longlong, _ptr],
+    ),
     "gpar_sample_stats": (
         _c_int,
         [_ptr, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_dbl, _c_int, _c_dbl, _ptr, _ptr, _ptr, _ptr],

@@ -76,6 +76,30 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restric
     if (lane == 0) y[(size_t)row * incy] = s;
 }
 
+// ---- the same for `batch` matrices and one vector each (gridDim.y = batch): y_b = L_b x_b (+ add_b)
+__global__ __launch_bounds__(256) void trmv_lower_batch_kernel(const double* __restrict__ L, long long stride_l, int n, int ldl,
+                                                               const double* __restrict__ x, int incx, long long stride_x,
+                                                               const double* __restrict__ add, int inca, long long stride_add,
+                                                               double* __restrict__ y, int incy, long long stride_y) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const size_t b = blockIdx.y;
+    const double* Lr = L + b * stride_l + (size_t)row * ldl;
+    const double* xb = x + b * stride_x;
+    double a0 = 0.0, a1 = 0.0;
+    int j = lane;
+    for (; j + 64 <= row; j += 128) {
+        a0 = fma(Lr[j], xb[(size_t)j * incx], a0);
+        a1 = fma(Lr[j + 64], xb[(size_t)(j + 64) * incx], a1);
+    }
+    if (j <= row) a0 = fma(Lr[j], xb[(size_t)j * incx], a0);
+    double s = a0 + a1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) y[b * stride_y + (size_t)row * incy] = add ? s + add[b * stride_add + (size_t)row * inca] : s;
+}
+
 // ---- Monte-Carlo reduction over posterior samples (reference regression.py:589-595)
 __device__ __forceinline__ double np_lerp(double a, double b, double t) {
     // numpy's _lerp: a + (b - a) t, replaced by b - (b - a)(1 - t) when t >= 0.5; numpy rounds the product and the
@@ -402,6 +426,14 @@ int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A
     return gemm_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, (hipStream_t)stream);
 }
 
+int gpar_gemm_batch(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, long long stride_a, const double* B,
+                    int ldb, long long stride_b, double beta, double* C, int ldc, long long stride_c, int flags, int batch, void* stream) {
+    GPAR_API_GUARD;
+    if (batch <= 0) return 0;
+    if (stride_a < 0 || stride_b < 0 || stride_c < 0) return GPAR_ARG_ERROR(9);
+    return gemm_launch(ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, flags, (hipStream_t)stream, 0, batch, stride_a, stride_b, stride_c);
+}
+
 int gpar_gemm_splitk(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B, int ldb,
                      double beta, double* C, int ldc, int flags, int splits, double* workspace, void* stream) {
     GPAR_API_GUARD;
@@ -473,6 +505,17 @@ int gpar_trmv_lower(const double* L, int n, int ldl, const double* x, int incx, 
     GPAR_API_GUARD;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, L, n, ldl, x, incx, y, incy);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_trmv_lower_batch(const double* L, int batch, long long stride_l, int n, int ldl, const double* x, int incx, long long stride_x,
+                          const double* add, int inca, long long stride_add, double* y, int incy, long long stride_y, void* stream) {
+    GPAR_API_GUARD;
+    if (n <= 0 || batch <= 0) return 0;
+    if (!L || !x || !y) return GPAR_ARG_ERROR(2);
+    hipLaunchKernelGGL(trmv_lower_batch_kernel, dim3((unsigned)((n + 3) / 4), (unsigned)batch), dim3(256), 0, (hipStream_t)stream, L, stride_l,
+                       n, ldl, x, incx, stride_x, add, inca, stride_add, y, incy, stride_y);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

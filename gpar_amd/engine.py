@@ -115,6 +115,16 @@ class HipEngine:
         safe = getattr(self._tls, "safe", False)
         return hip.potrf_(A, nf=nf, lookahead=not safe and getattr(self._tls, "pipe_depth", 0) < 3, fused=not safe)
 
+    def potrf_batch_(self, A, batch):
+        """`batch` square matrices stacked by rows in A, factored in lock-step (logdets, info words)."""
+        return hip.potrf_batch_(A, batch, fused=not getattr(self._tls, "safe", False))
+
+    def trmv_lower_batch_(self, Ls, batch, X, out, add=None):
+        return hip.trmv_lower_batch_(Ls, batch, X, out, add=add)
+
+    def gemm_batch_(self, A, B, out, batch, ta=False, tb=False, alpha=1.0, beta=0.0, c_lower=False):
+        return hip.gemm_batch_(A, B, out, batch, ta=ta, tb=tb, alpha=alpha, beta=beta, c_lower=c_lower)
+
     def logpdf_dense(self, ck, x, y, noise_diag, jitter):
         """One dense layer's log marginal likelihood in one library call (value as a 0-d device tensor, info word)."""
         safe = getattr(self._tls, "safe", False)

@@ -646,20 +646,25 @@ class Obs:
         if self.fdd.n == 0:
             return [torch.zeros(k, 1, dtype=torch.float64, device=z.device) for k in sizes]
         B = eng.new_matrix(sum(sizes), self.fdd.n)
-        r = 0
-        for x_s, k in zip(xs, sizes):
-            eng.gram(ck, eng.features(ck, _as_matrix(eng, x_s)), z, out=B[r : r + k])
-            r += k
+        eng.gram(ck, eng.features(ck, torch.cat([_as_matrix(eng, x_s) for x_s in xs], dim=0)), z, out=B)   # one launch each
         means = eng.gemm(B, fac.alpha(), tb=True)
         return list(torch.split(means, sizes, dim=0))
 
-    def _stacked_V(self, zss, ns):
-        """Rows [k ns, (k + 1) ns): V_k = K(x_k, X) L^-T for every feature set in zss - ONE triangular solve."""
+    def _stacked_features(self, xs):
+        """Features of several input sets of one size in ONE launch: (the stacked matrix, its per-set row views)."""
+        eng = self.eng
+        ck, _ = self.fdd.features()
+        ns = int(xs[0].shape[0])
+        z_all = eng.features(ck, torch.cat([_as_matrix(eng, x_s) for x_s in xs], dim=0))
+        return z_all, [z_all[k * ns : (k + 1) * ns] for k in range(len(xs))]
+
+    def _stacked_V(self, z_all):
+        """Rows [k ns, (k + 1) ns): V_k = K(x_k, X) L^-T for every feature set stacked in z_all - ONE cross-Gram launch, ONE
+        triangular solve."""
         eng, fac = self.eng, self.factor()
         ck, z = self.fdd.features()
-        B = eng.new_matrix(len(zss) * ns, self.fdd.n)
-        for k, zs in enumerate(zss):
-            eng.gram(ck, zs, z, out=B[k * ns : (k + 1) * ns])
+        B = eng.new_matrix(z_all.shape[0], self.fdd.n)
+        eng.gram(ck, z_all, z, out=B)
         eng.trsm_rlt_(fac.L, B)
         return B
 
@@ -678,10 +683,10 @@ class Obs:
         chunk = self._chunk(ns)
         for s0 in range(0, S, chunk):
             s1 = min(S, s0 + chunk)
-            zss = [eng.features(ck, _as_matrix(eng, xs[s])) for s in range(s0, s1)]
-            kd = torch.stack([eng.gram_diag(ck, zs) for zs in zss], dim=1)
+            z_all, zss = self._stacked_features(xs[s0:s1])
+            kd = eng.gram_diag(ck, z_all).reshape(s1 - s0, ns).T
             if n > 0:
-                B = self._stacked_V(zss, ns)
+                B = self._stacked_V(z_all)
                 mean[:, s0:s1] = eng.gemm(B, fac.zrow, tb=True).reshape(s1 - s0, ns).T
                 kd = kd - eng.rownorm2(B).reshape(s1 - s0, ns).T
             var[:, s0:s1] = kd
@@ -700,13 +705,27 @@ class Obs:
         chunk = self._chunk(ns)
         for s0 in range(0, S, chunk):
             s1 = min(S, s0 + chunk)
-            zss = [eng.features(ck, _as_matrix(eng, xs[s])) for s in range(s0, s1)]
+            z_all, zss = self._stacked_features(xs[s0:s1])
             B = means = None
             if n > 0:
-                B = self._stacked_V(zss, ns)  # every V_s = K(x_s, X) L^-T in one solve
+                B = self._stacked_V(z_all)  # every V_s = K(x_s, X) L^-T in one solve
                 means = eng.gemm(B, fac.zrow, tb=True)
-            # the per-sample blocks (Gram, SYRK downdate, an n* x n* factorisation, one matvec) are independent: a small
-            # factorisation is a latency-bound chain, so they are dealt over a few streams and checked once at the end
+            # the per-sample blocks (Gram, SYRK downdate, an n* x n* factorisation, one matvec) are independent and of one
+            # shape.  Up to HipEngine.batch_rows() points they go through ONE batched downdate and ONE lock-step
+            # factorisation (gpar_gemm_batch, gpar_potrf_batch: a small factorisation is a latency-bound chain, `count` of
+            # them in step cost little more than one) ...
+            K = s1 - s0
+            if K > 1 and hasattr(eng, "potrf_batch_") and ns <= eng.batch_rows() and not getattr(eng._tls, "safe", False):
+                covs = eng.new_matrix(K * ns, ns)
+                for k, zs in enumerate(zss):
+                    eng.gram(ck, zs, lower=True, diag_add=noise_vec, diag_const=eng.epsilon, out=covs[k * ns : (k + 1) * ns])
+                if n > 0:
+                    eng.gemm_batch_(B, B, covs, K, tb=True, alpha=-1.0, beta=1.0, c_lower=True)
+                _, info = eng.potrf_batch_(covs, K)
+                eng.check_info(info)
+                eng.trmv_lower_batch_(covs, K, zr[:, s0:s1], out[:, s0:s1], add=means)   # mean_s + chol(cov_s) z_s, all s
+                continue
+            # ... larger ones are dealt over a few streams and checked once at the end
             pipe = eng.pipeline(min(4, s1 - s0)) if s1 - s0 > 1 else None
             with eng.defer_checks(), joining(pipe):  # streams are joined BEFORE the deferred info words are read
                 for k, zs in enumerate(zss):

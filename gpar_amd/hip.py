@@ -378,6 +378,28 @@ def randn(seed, offset, rows, cols, device):
     return out
 
 
+def gemm_batch_(A, B, out, batch, ta=False, tb=False, alpha=1.0, beta=0.0, c_lower=False):
+    """out_b <- alpha op(A_b) op(B_b) + beta out_b for `batch` problems of one shape whose operands are stacked by rows in A, B
+    and out (block b = rows [b R, (b + 1) R) with R = rows / batch): one launch (gpar_gemm_batch)."""
+    lib = _lib.load()
+    for name, t in (("A", A), ("B", B), ("out", out)):
+        _check_mat(t, name)
+        if t.shape[0] % batch:
+            raise ValueError(f"{name}: rows must be a multiple of the batch size")
+    ra, rb, rc = A.shape[0] // batch, B.shape[0] // batch, out.shape[0] // batch
+    m, k = (A.shape[1], ra) if ta else (ra, A.shape[1])
+    n, kb = (rb, B.shape[1]) if tb else (B.shape[1], rb)
+    if k != kb or rc != m or out.shape[1] != n:
+        raise ValueError("shapes of a batched product do not match")
+    _lib.check(
+        lib.gpar_gemm_batch(int(ta), int(tb), m, n, k, float(alpha), A.data_ptr(), _ld(A), ra * _ld(A), B.data_ptr(), _ld(B), rb * _ld(B),
+                            float(beta), out.data_ptr(), _ld(out), rc * _ld(out), _lib.GEMM_C_LOWER if c_lower else 0, batch,
+                            stream_ptr(out.device)),
+        "gpar_gemm_batch",
+    )
+    return out
+
+
 def trmv_lower(L, x):
     """L x for the lower triangle of the square matrix L and one column x (n x 1, any row stride); new n x 1 tensor."""
     lib = _lib.load()
@@ -389,6 +411,28 @@ def trmv_lower(L, x):
     _lib.check(lib.gpar_trmv_lower(L.data_ptr(), n, _ld(L), x.data_ptr(), int(x.stride(0)), y.data_ptr(), 1, stream_ptr(L.device)),
                "gpar_trmv_lower")
     return y
+
+
+def trmv_lower_batch_(Ls, batch, X, out, add=None):
+    """Column b of `out` (n x batch) <- L_b X[:, b] (+ add[b n : (b + 1) n]) for the `batch` lower-triangular n x n matrices
+    stacked by rows in Ls; X: n x batch (any strides), add: (batch n) x 1 or None.  One launch."""
+    lib = _lib.load()
+    _check_mat(Ls, "Ls")
+    n = Ls.shape[1]
+    if Ls.shape[0] != batch * n or X.shape != (n, batch) or out.shape != (n, batch) or X.dtype != torch.float64 or out.dtype != torch.float64:
+        raise ValueError("shapes of a batched triangular product do not match")
+    aptr, inca, stride_add = None, 0, 0
+    if add is not None:
+        if add.numel() != batch * n or add.dtype != torch.float64:
+            raise ValueError("add must hold one value per row and matrix")
+        add = add.reshape(batch * n, -1)
+        aptr, inca, stride_add = add.data_ptr(), int(add.stride(0)), n * int(add.stride(0))
+    _lib.check(
+        lib.gpar_trmv_lower_batch(Ls.data_ptr(), batch, n * _ld(Ls), n, _ld(Ls), X.data_ptr(), int(X.stride(0)), int(X.stride(1)), aptr, inca,
+                                  stride_add, out.data_ptr(), int(out.stride(0)), int(out.stride(1)), stream_ptr(Ls.device)),
+        "gpar_trmv_lower_batch",
+    )
+    return out
 
 
 def percentile_index(num, q):

@@ -226,6 +226,12 @@ int gpar_chol_inverse(const double* L, int n, int ldl, double* X, int ldx, doubl
 int gpar_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
               int ldb, double beta, double* C, int ldc, int flags, void* stream);
 
+/* `batch` products of one shape in one launch: problem b reads A + b * stride_a, B + b * stride_b and writes C + b * stride_c
+ * (elements).  [the per-sample downdates K(x_s, x_s) - V_s V_s^T of ancestral sampling, gpar/regression.py:559-563 run for all
+ * samples of a layer at once] */
+int gpar_gemm_batch(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, long long stride_a, const double* B,
+                    int ldb, long long stride_b, double beta, double* C, int ldc, long long stride_c, int flags, int batch, void* stream);
+
 /* As gpar_gemm, with the K range cut into `splits` slices whose partial products go to `workspace`
  * (splits * m * n doubles) and are summed in slice order by a second kernel: for outputs with few 128 x 128 tiles and
  * a very long K (the inducing-point matrix B D^-1 B^T: M x M from K = n).  Deterministic.  A_LOWER / K_FROM_ROW / K_TO_COL
@@ -268,6 +274,11 @@ int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, 
  * is not read).  [the chol(cov) * z product of Normal.sample for a single draw; a 128-wide GEMM tile for one column is
  * all latency] */
 int gpar_trmv_lower(const double* L, int n, int ldl, const double* x, int incx, double* y, int incy, void* stream);
+/* The same for `batch` lower-triangular matrices with one vector each, in one launch: y_b = L_b x_b (+ add_b if add is non-null),
+ * matrix / vector b at L + b * stride_l, x + b * stride_x, add + b * stride_add, y + b * stride_y (elements).  [the draws of all
+ * posterior samples of a layer: mean_s + chol(cov_s) z_s, gpar/regression.py:559-563] */
+int gpar_trmv_lower_batch(const double* L, int batch, long long stride_l, int n, int ldl, const double* x, int incx, long long stride_x,
+                          const double* add, int inca, long long stride_add, double* y, int incy, long long stride_y, void* stream);
 
 /* Monte-Carlo reduction of predict [gpar/regression.py:589-595: np.mean / np.percentile over the sample axis]:
  * samples[s * stride + e], s < S, e < count.  mean[e] = (sum over s, in order) / S.  If lo / hi are non-null they

@@ -480,6 +480,40 @@ def test_lockstep_batch_factorisation_equals_one_at_a_time(env, N, nf, batch):
     assert np.allclose(np.tril(got[:N])[:, :nf], L0[:, :nf], rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("ns,n,batch", [(200, 333, 5), (512, 1024, 3), (65, 10, 2)])
+def test_batched_downdate_and_draws(env, ns, n, batch):
+    """gpar_gemm_batch (C_b -= V_b V_b^T, lower) and gpar_trmv_lower_batch (y_b = L_b z_b + m_b): the per-sample steps of
+    ancestral sampling for all samples of a layer in one launch each, equal to the per-sample calls."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(ns + n)
+    V = rng.standard_normal((batch * ns, n)) / np.sqrt(n)
+    C = rng.standard_normal((batch * ns, ns))
+    dV, dC = to_dev(V), to_dev(C)
+    ref = []
+    for b in range(batch):
+        blk = dC[b * ns:(b + 1) * ns].clone()
+        hip.gemm(dV[b * ns:(b + 1) * ns], dV[b * ns:(b + 1) * ns], tb=True, alpha=-1.0, beta=1.0, out=blk, c_lower=True)
+        ref.append(np.tril(blk.cpu().numpy()))
+    hip.gemm_batch_(dV, dV, dC, batch, tb=True, alpha=-1.0, beta=1.0, c_lower=True)
+    got = dC.cpu().numpy()
+    for b in range(batch):
+        assert np.array_equal(np.tril(got[b * ns:(b + 1) * ns]), ref[b])
+        assert np.allclose(ref[b], np.tril(C[b * ns:(b + 1) * ns] - V[b * ns:(b + 1) * ns] @ V[b * ns:(b + 1) * ns].T), rtol=1e-12, atol=1e-12)
+    Ls = np.tril(rng.standard_normal((batch * ns, ns)))
+    Z = rng.standard_normal((ns, batch))
+    M = rng.standard_normal((batch * ns, 1))
+    dL, dZ, dM = to_dev(Ls), to_dev(Z), to_dev(M)
+    out = torch.empty(ns, batch, dtype=torch.float64, device=dev)
+    hip.trmv_lower_batch_(dL, batch, dZ, out, add=dM)
+    plain = torch.empty(ns, batch, dtype=torch.float64, device=dev)
+    hip.trmv_lower_batch_(dL, batch, dZ, plain)
+    for b in range(batch):
+        single = hip.trmv_lower(dL[b * ns:(b + 1) * ns], dZ[:, b:b + 1])
+        assert torch.equal(plain[:, b:b + 1], single)
+        assert torch.equal(out[:, b:b + 1], single + dM[b * ns:(b + 1) * ns])
+        assert np.allclose(single.cpu().numpy()[:, 0], np.tril(Ls[b * ns:(b + 1) * ns]) @ Z[:, b], rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize("n,batch", [(640, 3), (1500, 4), (77, 2)])
 def test_lockstep_dense_logpdf_equals_layer_by_layer(env, n, batch):
     """hip.logpdf_dense_batch (build per layer, one lock-step factorisation, one finishing launch) returns per layer what
