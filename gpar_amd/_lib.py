@@ -75,6 +75,11 @@ SIGNATURES = {
         _c_int,
         [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr, _c_dbl, _ptr, _ptr],
     ),
+    "gpar_gram_batch": (
+        _c_int,
+        [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, ctypes.c_longlong, _c_int, _ptr, _c_int, ctypes.c_longlong, _c_int, _ptr, _c_dbl, _c_int,
+         _ptr],
+    ),
     "gpar_gram_diag": (_c_int, [ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "gpar_featurize_dfreq": (_c_int, [ctypes.POINTER(FSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "gpar_grad_nacc": (_c_int, []),

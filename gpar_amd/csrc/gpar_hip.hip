@@ -186,7 +186,8 @@ static int featurize_launch(const gpar_fspec_t* fs, const double* x, int n, int 
 }
 
 static int gram_launch(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz, double* K,
-                       int ldk, int flags, const double* diag_add, double diag_const, const double* row_scale, hipStream_t stream) {
+                       int ldk, int flags, const double* diag_add, double diag_const, const double* row_scale, hipStream_t stream,
+                       int batch = 1, long long batch_z = 0, long long batch_k = 0) {
     if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS)
         return GPAR_ARG_ERROR(3);
     if (dz < 0 || dz > GPAR_MAX_DIMS) return GPAR_ARG_ERROR(4);
@@ -195,10 +196,10 @@ static int gram_launch(const gpar_kspec_t* ks, const double* z1, int n1, int ldz
     if ((flags & GPAR_GRAM_LOWER) && !sym) return GPAR_ARG_ERROR(5);
     const size_t lds = (size_t)2 * (dz > 0 ? dz : 1) * GRAM_LD * sizeof(double);
     const int nt1 = gpar_ceil_div(n1, GRAM_T), nt2 = gpar_ceil_div(n2, GRAM_T);
-    dim3 grid(nt2, nt1);
-    if (flags & GPAR_GRAM_LOWER) grid = dim3((unsigned)((long long)nt1 * (nt1 + 1) / 2), 1);
+    dim3 grid(nt2, nt1, batch);
+    if (flags & GPAR_GRAM_LOWER) grid = dim3((unsigned)((long long)nt1 * (nt1 + 1) / 2), 1, batch);
     hipLaunchKernelGGL(gram_kernel, grid, dim3(256), lds, stream, *ks, z1, n1, ldz1, z2, n2, ldz2, dz, K, ldk, flags, diag_add,
-                       diag_const, row_scale, sym);
+                       diag_const, row_scale, sym, batch_z, batch_k);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
@@ -264,6 +265,14 @@ int gpar_logpdf_dense(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const doub
                        (const double*)logdet, value);
     GPAR_LAUNCH_CHECK();
     return 0;
+}
+
+int gpar_gram_batch(const gpar_kspec_t* ks, const double* z, int n, int ldz, long long stride_z, int dz, double* K, int ldk,
+                    long long stride_k, int flags, const double* diag_add, double diag_const, int batch, void* stream) {
+    GPAR_API_GUARD;
+    if (batch <= 0) return 0;
+    if (stride_z < 0 || stride_k < 0) return GPAR_ARG_ERROR(9);
+    return gram_launch(ks, z, n, ldz, z, n, ldz, dz, K, ldk, flags, diag_add, diag_const, nullptr, (hipStream_t)stream, batch, stride_z, stride_k);
 }
 
 int gpar_logpdf_dense_build(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, const double* y, long incy,

@@ -115,8 +115,13 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
                                                    const double* __restrict__ z2, int n2, int ldz2, int dz,
                                                    double* __restrict__ K, int ldk, int flags,
                                                    const double* __restrict__ diag_add, double diag_const,
-                                                   const double* __restrict__ row_scale, int sym) {
+                                                   const double* __restrict__ row_scale, int sym, long long batch_z = 0,
+                                                   long long batch_k = 0) {
     extern __shared__ __attribute__((aligned(32))) double gsm[];
+    // batched launch (gpar_gram_batch): blockIdx.z picks one of several input sets of one size and its output matrix
+    z1 += (size_t)blockIdx.z * batch_z;
+    z2 += (size_t)blockIdx.z * batch_z;
+    K += (size_t)blockIdx.z * batch_k;
     int bm = blockIdx.y, bn = blockIdx.x;
     if (flags & GPAR_GRAM_LOWER) {
         // 1-D grid over the tiles of the lower triangle (a 2-D grid would launch as many empty workgroups again)

@@ -119,6 +119,9 @@ class HipEngine:
         """`batch` square matrices stacked by rows in A, factored in lock-step (logdets, info words)."""
         return hip.potrf_batch_(A, batch, fused=not getattr(self._tls, "safe", False))
 
+    def gram_batch_(self, ck, z_all, batch, out, lower=False, diag_add=None, diag_const=0.0):
+        return hip.gram_batch_(ck, z_all, batch, out, lower=lower, diag_add=diag_add, diag_const=diag_const)
+
     def trmv_lower_batch_(self, Ls, batch, X, out, add=None):
         return hip.trmv_lower_batch_(Ls, batch, X, out, add=add)
 

@@ -410,6 +410,43 @@ class GP:
         return self(x).marginals()
 
 
+class Stacked:
+    """`count` input sets of `rows` points each, stacked by rows in ONE matrix: what ancestral sampling hands from layer to layer
+    (each sample's design matrix differs in its last columns).  Behaves like the list of its blocks; the batched posterior
+    routines take the matrix as it is (one featurize / cross-Gram launch) instead of concatenating a list again."""
+
+    def __init__(self, matrix, count):
+        self.matrix, self.count = matrix, int(count)
+        self.rows = int(matrix.shape[0]) // max(self.count, 1)
+
+    @classmethod
+    def repeat(cls, x, count):
+        return cls(x.repeat(count, 1), count)
+
+    def __len__(self):
+        return self.count
+
+    def __getitem__(self, s):
+        if isinstance(s, slice):
+            a, b, step = s.indices(self.count)
+            if step != 1:
+                raise IndexError("contiguous slices only")
+            return Stacked(self.matrix[a * self.rows : b * self.rows], max(b - a, 0))
+        if s < 0:
+            s += self.count
+        return self.matrix[s * self.rows : (s + 1) * self.rows]
+
+    def __iter__(self):
+        return (self[s] for s in range(self.count))
+
+    def with_columns(self, cols):
+        """A new stack with `cols` appended to every set: rows x count (column s goes to set s) or already stacked
+        ((count rows) x k)."""
+        if cols.shape[0] == self.rows and cols.shape[0] != self.matrix.shape[0]:
+            cols = cols.T.reshape(-1, 1)
+        return Stacked(torch.cat([self.matrix, cols], dim=1), self.count)
+
+
 class FDD:
     """`f(x, noise)`: the process at the rows of x, plus independent noise (scalar or per-row vector)."""
 
@@ -646,7 +683,8 @@ class Obs:
         if self.fdd.n == 0:
             return [torch.zeros(k, 1, dtype=torch.float64, device=z.device) for k in sizes]
         B = eng.new_matrix(sum(sizes), self.fdd.n)
-        eng.gram(ck, eng.features(ck, torch.cat([_as_matrix(eng, x_s) for x_s in xs], dim=0)), z, out=B)   # one launch each
+        stacked = xs.matrix if isinstance(xs, Stacked) else torch.cat([_as_matrix(eng, x_s) for x_s in xs], dim=0)
+        eng.gram(ck, eng.features(ck, _as_matrix(eng, stacked)), z, out=B)   # one launch each
         means = eng.gemm(B, fac.alpha(), tb=True)
         return list(torch.split(means, sizes, dim=0))
 
@@ -655,7 +693,8 @@ class Obs:
         eng = self.eng
         ck, _ = self.fdd.features()
         ns = int(xs[0].shape[0])
-        z_all = eng.features(ck, torch.cat([_as_matrix(eng, x_s) for x_s in xs], dim=0))
+        stacked = xs.matrix if isinstance(xs, Stacked) else torch.cat([_as_matrix(eng, x_s) for x_s in xs], dim=0)
+        z_all = eng.features(ck, _as_matrix(eng, stacked))
         return z_all, [z_all[k * ns : (k + 1) * ns] for k in range(len(xs))]
 
     def _stacked_V(self, z_all):
@@ -717,8 +756,7 @@ class Obs:
             K = s1 - s0
             if K > 1 and hasattr(eng, "potrf_batch_") and ns <= eng.batch_rows() and not getattr(eng._tls, "safe", False):
                 covs = eng.new_matrix(K * ns, ns)
-                for k, zs in enumerate(zss):
-                    eng.gram(ck, zs, lower=True, diag_add=noise_vec, diag_const=eng.epsilon, out=covs[k * ns : (k + 1) * ns])
+                eng.gram_batch_(ck, z_all, K, covs, lower=True, diag_add=noise_vec, diag_const=eng.epsilon)
                 if n > 0:
                     eng.gemm_batch_(B, B, covs, K, tb=True, alpha=-1.0, beta=1.0, c_lower=True)
                 _, info = eng.potrf_batch_(covs, K)

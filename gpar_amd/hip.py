@@ -192,6 +192,29 @@ def gram(ck, z1, z2=None, out=None, lower=False, diag_add=None, diag_const=0.0, 
     return out
 
 
+def gram_batch_(ck, z_all, batch, out, lower=False, diag_add=None, diag_const=0.0):
+    """out block b ((batch n) x n, stacked by rows) <- k(z_b, z_b) + diag(diag_add) + diag_const I for the `batch` input sets
+    stacked by rows in z_all: one launch (gpar_gram_batch)."""
+    lib = _lib.load()
+    _check_mat(z_all, "z_all")
+    _check_mat(out, "out")
+    n = out.shape[1]
+    if z_all.shape[0] != batch * n or out.shape[0] != batch * n:
+        raise ValueError("shapes of a batched Gram matrix do not match")
+    dptr = None
+    if diag_add is not None:
+        diag_add = diag_add.reshape(-1).contiguous()
+        if diag_add.numel() != n:
+            raise ValueError("diag_add must hold one value per row")
+        dptr = diag_add.data_ptr()
+    _lib.check(
+        lib.gpar_gram_batch(ctypes.byref(ck.kspec), z_all.data_ptr(), n, _ld(z_all), n * _ld(z_all), ck.dz, out.data_ptr(), _ld(out),
+                            n * _ld(out), _lib.GRAM_LOWER if lower else 0, dptr, float(diag_const), batch, stream_ptr(out.device)),
+        "gpar_gram_batch",
+    )
+    return out
+
+
 def gram_diag(ck, z):
     lib = _lib.load()
     _check_mat(z, "z")

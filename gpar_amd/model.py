@@ -14,7 +14,7 @@ import torch
 
 from .engine import get_engine
 from .engine import joining as _joining
-from .gp import Obs, PseudoObs, PseudoObsDTC, PseudoObsFITC
+from .gp import Obs, PseudoObs, PseudoObsDTC, PseudoObsFITC, Stacked
 
 __all__ = ["GPAR", "merge", "construct_model", "last", "per_output"]
 
@@ -367,12 +367,12 @@ class GPAR:
                 if shared:
                     x = torch.cat([x, f.mean(x)], dim=1)
                 else:
-                    xs = [torch.cat([x_s, m_s], dim=1) for x_s, m_s in zip(xs, f.mean_batch(xs))]
+                    xs = xs.with_columns(torch.cat(list(f.mean_batch(xs)), dim=0))
             elif shared:
-                xs = [torch.cat([x, fed[:, s : s + 1]], dim=1) for s in range(S)]
+                xs = Stacked.repeat(x, S).with_columns(fed)   # from here on every sample has a design matrix of its own
                 shared = False
             else:
-                xs = [torch.cat([x_s, fed[:, s : s + 1]], dim=1) for s, x_s in enumerate(xs)]
+                xs = xs.with_columns(fed)
         return [torch.stack([c[:, s] for c in columns], dim=1) for s in range(S)]
 
     # ---- helpers -----------------------------------------------------------------------------------

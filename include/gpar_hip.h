@@ -118,6 +118,11 @@ int gpar_featurize(const gpar_fspec_t* fs, const double* x, int n, int ldx, doub
 int gpar_gram(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2,
               int dz, double* K, int ldk, int flags, const double* diag_add, double diag_const, const double* row_scale,
               void* stream);
+/* `batch` symmetric Gram matrices of one size in one launch: K_b = k(z_b, z_b) + diag(diag_add) + diag_const I with input set b at
+ * z + b * stride_z and its matrix at K + b * stride_k (elements); diag_add (n values or null) is shared by the batch.
+ * [the prior covariances K(x_s, x_s) of all posterior samples of a layer, gpar/model.py:264,270 via regression.py:559-563] */
+int gpar_gram_batch(const gpar_kspec_t* ks, const double* z, int n, int ldz, long long stride_z, int dz, double* K, int ldk,
+                    long long stride_k, int flags, const double* diag_add, double diag_const, int batch, void* stream);
 
 /* out[a] = k(z[a], z[a])   [kernel diagonal; VFE trace term, posterior marginal variances] */
 int gpar_gram_diag(const gpar_kspec_t* ks, const double* z, int n, int ldz, int dz, double* out, void* stream);

@@ -499,6 +499,18 @@ def test_batched_downdate_and_draws(env, ns, n, batch):
     for b in range(batch):
         assert np.array_equal(np.tril(got[b * ns:(b + 1) * ns]), ref[b])
         assert np.allclose(ref[b], np.tril(C[b * ns:(b + 1) * ns] - V[b * ns:(b + 1) * ns] @ V[b * ns:(b + 1) * ns].T), rtol=1e-12, atol=1e-12)
+    # gpar_gram_batch: the prior covariances of all samples in one launch
+    from gpar_amd.kernels import EQ, Linear, compile_kernel
+
+    ck = compile_kernel(0.7 * EQ().stretch(np.array([0.5, 0.8])).select([0, 1]) + Linear().stretch(np.array([3.0])).select([2]), 3)
+    xs = to_dev(rng.uniform(0, 1, (batch * ns, 3)))
+    z_all = hip.featurize(ck, xs)
+    noise = to_dev(rng.uniform(0.1, 0.2, (ns, 1)))[:, 0]
+    Ks = hip.alloc_matrix(batch * ns, ns, dev)
+    hip.gram_batch_(ck, z_all, batch, Ks, lower=True, diag_add=noise, diag_const=1e-9)
+    for b in range(batch):
+        one = hip.gram(ck, z_all[b * ns:(b + 1) * ns], lower=True, diag_add=noise, diag_const=1e-9)
+        assert torch.equal(torch.tril(Ks[b * ns:(b + 1) * ns]), torch.tril(one))
     Ls = np.tril(rng.standard_normal((batch * ns, ns)))
     Z = rng.standard_normal((ns, batch))
     M = rng.standard_normal((batch * ns, 1))
