@@ -140,6 +140,11 @@ class HipEngine:
         safe = getattr(self._tls, "safe", False)
         return hip.logpdf_dense_batch([(ck, self._mat(x), y, nd) for ck, x, y, nd in items], jitter, fused=not safe)
 
+    def factor_dense_batch(self, items, jitter):
+        """The lock-step factorisations alone: (buffer of the `batch` augmented factors, logdets, info words)."""
+        safe = getattr(self._tls, "safe", False)
+        return hip.factor_dense_batch([(ck, self._mat(x), y, nd) for ck, x, y, nd in items], jitter, fused=not safe)
+
     def batch_rows(self):
         """Layers with at most this many rows are factored in lock-step rather than on separate streams (GPAR_LAYER_BATCH_ROWS;
         0 = never): below ~4600 rows a factorisation is a chain of latency-bound panel kernels (no look-ahead, no grouping), and

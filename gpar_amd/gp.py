@@ -114,6 +114,20 @@ class _Factor:
         self._alpha = None
 
     @classmethod
+    def from_batch(cls, eng, n, A, logdet):
+        """The factor of one layer out of a lock-step batch (HipEngine.factor_dense_batch): `A` its (n + 1) x (n + 1) block,
+        `logdet` its word."""
+        self = cls.__new__(cls)
+        self.eng, self.n = eng, n
+        self.A = A
+        self.L = A[:n, :n]
+        self.zrow = A[n : n + 1, :n]
+        self.logdet = logdet
+        self.quad = -A[n, n]
+        self._alpha = None
+        return self
+
+    @classmethod
     def placeholder(cls, eng, n):
         """Buffers of a factor that another process computes (parallel.sharded_condition receives into `A`)."""
         self = cls.__new__(cls)
@@ -623,6 +637,14 @@ class Obs:
         """Install an empty factor whose buffer the caller fills (a factor computed by another rank)."""
         self._fac = _Factor.placeholder(self.eng, self.fdd.n)
         return self._fac
+
+    def _batchable(self):
+        """This observation's factor may come out of a lock-step batch: a prior process (zero mean: the right-hand side is y
+        itself), nothing factored yet, checks deferred, no retry ladder to climb."""
+        eng = self.eng
+        return (self._fac is None and not self.base.is_posterior and self.fdd.n > 0 and hasattr(eng, "factor_dense_batch")
+                and getattr(eng, "_deferred", None) is not None and getattr(eng, "cholesky_retry_factor", 1.0) <= 1.0
+                and isinstance(self.y, torch.Tensor) and self.y.is_cuda)
 
     def factor(self):
         """Cholesky of cov(f(X)) + D + eps I under the observed process and L^-1 (y - mean(X))."""

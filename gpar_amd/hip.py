@@ -112,10 +112,11 @@ def logpdf_dense(ck, x, y, noise_diag, jitter, lookahead=True, fused=True):
     return words[0], words[1:], info, A
 
 
-def logpdf_dense_batch(items, jitter, fused=True):
-    """log N(y_b; 0, k_b(x_b, x_b) + diag(noise_b) + jitter I) for layers b that share their number of rows and do not feed one
-    another: per layer one gpar_logpdf_dense_build, then ONE lock-step gpar_potrf_batch and one gpar_logpdf_dense_finish.
-    `items`: (compiled kernel, x, y, noise_diag or None) per layer.  Returns (values, info): `batch` device words each."""
+def factor_dense_batch(items, jitter, fused=True):
+    """Augmented matrices [[k_b(x_b, x_b) + diag(noise_b) + jitter I, .], [y_b^T, 0]] of layers b that share their number of rows,
+    built per layer (gpar_logpdf_dense_build) into one buffer and factored in lock-step (gpar_potrf_batch).
+    `items`: (compiled kernel, x, y, noise_diag or None) per layer.  Returns (A, logdet, info): A is the (batch (n + 1)) x (n + 1)
+    buffer - block b holds L_b, (L_b^-1 y_b)^T in its last row and -|L_b^-1 y_b|^2 in its corner - logdet / info `batch` words."""
     lib = _lib.load()
     batch = len(items)
     x0 = items[0][1]
@@ -123,7 +124,7 @@ def logpdf_dense_batch(items, jitter, fused=True):
     A = alloc_matrix(batch * (n + 1), n + 1, dev)   # matrix b = rows b (n + 1) ... of one buffer
     lda = _ld(A)
     stride = (n + 1) * lda          # lda is a multiple of 16: every matrix starts 128-byte aligned
-    words = torch.empty(2 * batch, dtype=torch.float64, device=dev)   # values, logdets
+    logdet = torch.empty(batch, dtype=torch.float64, device=dev)
     info = torch.empty(batch, dtype=torch.int32, device=dev)
     st = stream_ptr(dev)
     keep = []
@@ -143,16 +144,26 @@ def logpdf_dense_batch(items, jitter, fused=True):
         _lib.check(
             lib.gpar_logpdf_dense_build(
                 ctypes.byref(ck.fspec), ctypes.byref(ck.kspec), x.data_ptr(), n, _ld(x), y.data_ptr(), int(y.stride(0)), nptr, float(jitter),
-                z.data_ptr(), _ld(z), A.data_ptr() + 8 * b * stride, lda, words.data_ptr() + 8 * (batch + b), info.data_ptr() + 4 * b, st,
+                z.data_ptr(), _ld(z), A.data_ptr() + 8 * b * stride, lda, logdet.data_ptr() + 8 * b, info.data_ptr() + 4 * b, st,
             ),
             "gpar_logpdf_dense_build",
         )
     flags = 0 if fused else _lib.POTRF_UNFUSED
-    _lib.check(lib.gpar_potrf_batch(A.data_ptr(), batch, stride, n + 1, n, lda, words.data_ptr() + 8 * batch, info.data_ptr(), flags, st),
-               "gpar_potrf_batch")
-    _lib.check(lib.gpar_logpdf_dense_finish(A.data_ptr(), batch, stride, n, lda, words.data_ptr() + 8 * batch, words.data_ptr(), st),
-               "gpar_logpdf_dense_finish")
-    return words[:batch], info
+    _lib.check(lib.gpar_potrf_batch(A.data_ptr(), batch, stride, n + 1, n, lda, logdet.data_ptr(), info.data_ptr(), flags, st), "gpar_potrf_batch")
+    return A, logdet, info
+
+
+def logpdf_dense_batch(items, jitter, fused=True):
+    """log N(y_b; 0, k_b(x_b, x_b) + diag(noise_b) + jitter I) for layers b that share their number of rows and do not feed one
+    another: factor_dense_batch, then one gpar_logpdf_dense_finish.  Returns (values, info): `batch` device words each."""
+    lib = _lib.load()
+    A, logdet, info = factor_dense_batch(items, jitter, fused=fused)
+    batch = len(items)
+    n = A.shape[1] - 1
+    values = torch.empty(batch, dtype=torch.float64, device=A.device)
+    _lib.check(lib.gpar_logpdf_dense_finish(A.data_ptr(), batch, (n + 1) * _ld(A), n, _ld(A), logdet.data_ptr(), values.data_ptr(),
+                                            stream_ptr(A.device)), "gpar_logpdf_dense_finish")
+    return values, info
 
 
 def gram(ck, z1, z2=None, out=None, lower=False, diag_add=None, diag_const=0.0, row_scale=None):

@@ -140,6 +140,28 @@ def _lockstep_values(eng, pending):
     return values
 
 
+def _lockstep_factors(eng, obs):
+    """Factor the observations of layers that do not feed one another in lock-step batches (HipEngine.factor_dense_batch) and
+    hand each its factor; whatever does not qualify is factored on its own."""
+    from .gp import _Factor
+
+    todo = [o for o in obs if o._fac is None]
+    if len(todo) >= 2 and all(o._batchable() for o in todo) and len({int(o.fdd.n) for o in todo}) == 1:
+        n = int(todo[0].fdd.n)
+        cap = max(1, eng.batch_bytes() // (8 * (n + 1) * (n + 17)))
+        for i in range(0, len(todo), cap):
+            chunk = todo[i:i + cap]
+            if len(chunk) < 2:
+                break
+            items = [(eng.compile(o.base.kernel, o.fdd.x.shape[1]), o.fdd.x, o.y, o.fdd.noise) for o in chunk]
+            A, logdet, info = eng.factor_dense_batch(items, eng.epsilon)
+            eng.check_info(info)
+            for b, o in enumerate(chunk):
+                o._fac = _Factor.from_batch(eng, n, A[b * (n + 1):(b + 1) * (n + 1)], logdet[b:b + 1])
+    for o in obs:
+        o.factor()
+
+
 class GPAR:
     """Gaussian process autoregressive model.
 
@@ -200,12 +222,18 @@ class GPAR:
         # Observed data only: no layer needs another's posterior, so the factorisations (otherwise done lazily, one
         # after the other, when the posterior is first used) are issued now on alternating streams.
         pipe = eng.pipeline(rows=int(x.shape[0])) if self._independent(items) else None
+        # ... or, when they are small, together in lock-step
+        lockstep = pipe is not None and hasattr(eng, "factor_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
+        pending = []
         with eng.defer_checks(), _joining(pipe):  # streams are joined BEFORE the deferred info words are read
             for stage, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, self.layers))):
                 complete = isinstance(mask, slice)
                 x = x[mask]
                 f, noise = model()
-                if pipe is not None and not _differentiable(f, noise):
+                if pipe is not None and lockstep and not _differentiable(f, noise):
+                    obs = self._obs(x, x_ind, yi, wi, f, noise, complete=True)
+                    pending.append(obs)
+                elif pipe is not None and not _differentiable(f, noise):
                     with pipe.stage(stage, x, yi, wi):
                         obs = self._obs(x, x_ind, yi, wi, f, noise, complete=True)
                         obs.factor()
@@ -216,6 +244,7 @@ class GPAR:
                     x, x_ind = self._update_inputs(x, x_ind, yi, f, obs, complete=complete)
             if pipe is not None:
                 pipe.join()
+            _lockstep_factors(eng, pending)
         return post
 
     # ---- log marginal likelihood -------------------------------------------------------------------

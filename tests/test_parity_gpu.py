@@ -209,6 +209,39 @@ def test_lockstep_layers_equal_layer_by_layer_evaluation(monkeypatch, n, p):
         assert abs(got["lockstep"] - ref) <= 1e-9 * abs(ref), (got, ref)
 
 
+@pytest.mark.parametrize("n,p", [(1500, 4), (300, 3)])
+def test_lockstep_conditioning_equals_layer_by_layer(monkeypatch, n, p):
+    """Conditioning on complete data factors the (independent) layers in lock-step (HipEngine.factor_dense_batch): the posterior
+    it yields - read through the posterior log-density of held-out data and a posterior sample with a fixed seed - is the one
+    the layer-by-layer factorisations yield."""
+    from gpar_amd.engine import get_engine
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(n + 200, 2, p, seed=n)
+    xt, yt, xh, yh = x[:n], y[:n], x[n:], y[n:]
+
+    def run():
+        out = {}
+        for mode in ["lockstep", "streams", "serial"]:
+            if mode == "streams":
+                monkeypatch.setenv("GPAR_LAYER_BATCH_ROWS", "0")
+            if mode == "serial":
+                monkeypatch.setenv("GPAR_LAYER_PIPELINE", "0")
+            reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1)
+            reg.condition(xt, yt)
+            out[mode] = float(reg.logpdf(xh, yh, posterior=True))
+            get_engine().seed(5)
+            out[mode + "_sample"] = np.asarray(reg.sample(xh[:50], posterior=True, latent=True))
+        monkeypatch.delenv("GPAR_LAYER_PIPELINE")
+        monkeypatch.delenv("GPAR_LAYER_BATCH_ROWS")
+        return out
+
+    got = _on("hip", run)
+    assert got["streams"] == got["serial"], got
+    assert abs(got["lockstep"] - got["serial"]) <= 1e-10 * abs(got["serial"]), got
+    np.testing.assert_allclose(got["lockstep_sample"], got["serial_sample"], rtol=1e-7, atol=1e-8)
+
+
 def test_concurrent_layer_training_equals_serial_training(monkeypatch):
     """fit(fix=True) on observed data trains independent layers from two host threads on two streams; every objective
     evaluation is the same deterministic device computation, so the trained hyper-parameters are those of the serial
