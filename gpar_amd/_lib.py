@@ -24,7 +24,7 @@ POTRF_UNFUSED = 2
 WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE, WS_INPUT_GRAD = 1, 2, 3, 4, 5
 GRAD_NACC = GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 LIB_NAME = "libgpar_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -179,6 +179,8 @@ def load():
         raise HipLibraryError(f"ABI version mismatch: library {lib.gpar_abi_version()}, binding {ABI_VERSION}")
     if lib.gpar_sizeof_fspec() != ctypes.sizeof(FSpec) or lib.gpar_sizeof_kspec() != ctypes.sizeof(KSpec):
         raise HipLibraryError("struct layout mismatch between include/gpar_hip.h and gpar_amd/_lib.py")
+    if lib.gpar_grad_nacc() != GRAD_NACC:
+        raise HipLibraryError(f"gradient accumulator layout mismatch: library {lib.gpar_grad_nacc()}, binding {GRAD_NACC}")
     _lib = lib
     return lib
 

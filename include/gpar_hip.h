@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPAR_ABI_VERSION 2
+#define GPAR_ABI_VERSION 3
 
 /* ---- kernel specification -------------------------------------------------------------------
  * A GPAR layer kernel (gpar/regression.py:92-180) is a sum of products of elementary kernels applied

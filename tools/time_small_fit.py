@@ -1,0 +1,38 @@
+"""fit(iters=20) at small sizes: wall-clock, objective evaluations, host share (python tools/time_small_fit.py [n:p ...])."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from bench import synthetic
+from gpar_amd.engine import HipEngine, set_engine
+from gpar_amd.regression import GPARRegressor
+from gpar_amd import optimise
+
+eng = HipEngine(seed=1)
+set_engine(eng)
+cases = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(400, 3), (2048, 4)]
+for n, p in cases:
+    x, y = synthetic(n, 2, p)
+    for rep in range(2):
+        reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reg.fit(x, y, iters=20)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    evals = getattr(optimise, "LAST_EVALUATIONS", None)
+    print(f"n={n} p={p}: fit(iters=20) {1e3 * dt:.1f} ms  evaluations {evals}")
+    if os.environ.get("PROFILE"):
+        os.environ["GPAR_FIT_THREADS"] = "1"
+        reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False)
+        prof = cProfile.Profile()
+        prof.enable()
+        reg.fit(x, y, iters=20)
+        prof.disable()
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(40)
