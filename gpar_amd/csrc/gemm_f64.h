@@ -63,6 +63,7 @@ struct GemmArgs {
     long long part_stride;   // elements between consecutive partial slabs of C (split-K)
     long long batch_a, batch_b, batch_c;   // blockIdx.z selects problem z of a batch: operands advance by these many elements
     long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memrealtime stamps + hardware ids, normally null
+    long long* stage_stamps;   // dev aid (tools/time_gemm_stages.hip, compiled with GPAR_GEMM_STAGE_STAMPS): 3 stamps per K stage
 };
 
 typedef double gpar_d2 __attribute__((ext_vector_type(2)));
@@ -209,8 +210,9 @@ __device__ __forceinline__ void gemm_stage(const GemmArgs& p, const double* __re
 #pragma unroll
         for (int mi = 0; mi < BM / 32; ++mi)
 #pragma unroll
-            for (int nj = 0; nj < 4; ++nj)
+            for (int nj = 0; nj < 4; ++nj) {
                 acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+            }
         if (k4 == 0) {
             gemm_gload<A_KC, FAST, BM>(p.A, p.lda, m0, p.m, knext, kend, false, t, ra);
             gemm_gload<B_KC, FAST>(p.B, p.ldb, n0, p.n, knext, kend, false, t, rb);
@@ -261,20 +263,36 @@ __device__ __forceinline__ void gemm_mainloop_pf2(const GemmArgs& p, double* sme
     gemm_sstore<B_KC>(buf0 + GEMM_TILE, t, rb0);
     __syncthreads();
     const int l15 = lane & 15, lk = lane >> 4;
+#ifdef GPAR_GEMM_STAGE_STAMPS
+#define GEMM_STAGE_STAMP(stage, which)                                                                                     \
+    do {                                                                                                                   \
+        if (p.stage_stamps && t == 0 && blockIdx.x >= 1024 && blockIdx.x < 1088 && (stage) < 40)                           \
+            p.stage_stamps[((size_t)(blockIdx.x - 1024) * 40 + (stage)) * 3 + (which)] =                                     \
+                (GPAR_GEMM_STAGE_STAMPS == 2) ? (long long)__builtin_amdgcn_s_memtime() : (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GEMM_STAGE_STAMP(stage, which) do {} while (0)
+#endif
     for (int kt = 0; kt < nk; kt += 2) {
         // even stage: compute buf0; (ra1, rb1) carry stage kt + 1; stage kt + 2 is requested into (ra0, rb0)
+        GEMM_STAGE_STAMP(kt, 0);
         gemm_stage<A_KC, B_KC, FAST, BM>(p, buf0, buf0 + GEMM_TILE, acc, m0, n0, min(kbeg + (kt + 2) * GEMM_BK, klast), kend, t, l15,
                                      lk, wm, wn, ra0, rb0);
+        GEMM_STAGE_STAMP(kt, 1);
         if (kt + 1 >= nk) break;
         gemm_sstore<A_KC, BM>(buf1, t, ra1);
         gemm_sstore<B_KC>(buf1 + GEMM_TILE, t, rb1);
+        GEMM_STAGE_STAMP(kt, 2);
         __syncthreads();
         // odd stage: compute buf1; (ra0, rb0) carry stage kt + 2; stage kt + 3 is requested into (ra1, rb1)
+        GEMM_STAGE_STAMP(kt + 1, 0);
         gemm_stage<A_KC, B_KC, FAST, BM>(p, buf1, buf1 + GEMM_TILE, acc, m0, n0, min(kbeg + (kt + 3) * GEMM_BK, klast), kend, t, l15,
                                      lk, wm, wn, ra1, rb1);
+        GEMM_STAGE_STAMP(kt + 1, 1);
         if (kt + 2 >= nk) break;
         gemm_sstore<A_KC, BM>(buf0, t, ra0);
         gemm_sstore<B_KC>(buf0 + GEMM_TILE, t, rb0);
+        GEMM_STAGE_STAMP(kt + 1, 2);
         __syncthreads();
     }
     __syncthreads();   // the epilogue reuses the stage buffers
@@ -528,7 +546,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     p.fastA = gpar_aligned16(A) && (lda % 2 == 0);
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
     p.fastC = gpar_aligned16(C) && (ldc % 2 == 0);
-    p.stamps = nullptr;
+    p.stamps = nullptr; p.stage_stamps = nullptr;
     p.ksplit = 0;
     p.part_stride = 0;
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
@@ -589,7 +607,7 @@ static int gemm_splitk_launch(int ta, int tb, int m, int n, int k, double alpha,
     p.fastA = gpar_aligned16(A) && (lda % 2 == 0);
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
     p.fastC = gpar_aligned16(workspace) && (n % 2 == 0) && (((long long)m * n) % 2 == 0);
-    p.stamps = nullptr;
+    p.stamps = nullptr; p.stage_stamps = nullptr;
     const int len = gpar_ceil_div(gpar_ceil_div(k, splits), GEMM_BK) * GEMM_BK;
     p.ksplit = len;
     p.part_stride = (long long)m * n;
