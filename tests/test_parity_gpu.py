@@ -232,6 +232,8 @@ def test_lockstep_conditioning_equals_layer_by_layer(monkeypatch, n, p):
             out[mode] = float(reg.logpdf(xh, yh, posterior=True))
             get_engine().seed(5)
             out[mode + "_sample"] = np.asarray(reg.sample(xh[:50], posterior=True, latent=True))
+            get_engine().seed(6)   # several samples: the per-sample blocks of every layer go through the batched kernels
+            out[mode + "_samples"] = np.stack([np.asarray(v) for v in reg.sample(xh[:130], posterior=True, num_samples=5)])
         monkeypatch.delenv("GPAR_LAYER_PIPELINE")
         monkeypatch.delenv("GPAR_LAYER_BATCH_ROWS")
         return out
@@ -240,6 +242,8 @@ def test_lockstep_conditioning_equals_layer_by_layer(monkeypatch, n, p):
     assert got["streams"] == got["serial"], got
     assert abs(got["lockstep"] - got["serial"]) <= 1e-10 * abs(got["serial"]), got
     np.testing.assert_allclose(got["lockstep_sample"], got["serial_sample"], rtol=1e-7, atol=1e-8)
+    assert got["lockstep_samples"].shape == (5, 130, p)
+    np.testing.assert_allclose(got["lockstep_samples"], got["serial_samples"], rtol=1e-6, atol=1e-7)
 
 
 def test_concurrent_layer_training_equals_serial_training(monkeypatch):
