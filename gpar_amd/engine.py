@@ -150,9 +150,8 @@ class HipEngine:
         0 = never): below ~4600 rows a factorisation is a chain of latency-bound panel kernels (no look-ahead, no grouping), and
         several chains on separate streams fight for compute-unit slots.  Measured per evaluation, streams -> lock-step: four layers
         at n = 512 0.94 -> 0.61 ms, 2048 1.81 -> 1.34, 4096 (C2) 4.2 -> 3.3; eight at 2048 3.06 -> 1.86; sixteen at 8192 (C5) 65.0 -> 60.2;
-        eight at 16384 (C3) 195.9 -> 195.7, where the evaluation is bound by the rate of the trailing updates either way and the
-        batch would hold 17 GB - hence the default of 9216 rows."""
-        return int(os.environ.get("GPAR_LAYER_BATCH_ROWS", "9216"))
+        eight at 16384 (C3: a 17 GB batch) 195.5 -> 188.0.  Not measured above 16384 rows: the default stops at 20480."""
+        return int(os.environ.get("GPAR_LAYER_BATCH_ROWS", "20480"))
 
     def batch_bytes(self):
         """Workspace budget of one lock-step batch (GPAR_LAYER_BATCH_BYTES, default 24 GiB): more layers than fit are factored in

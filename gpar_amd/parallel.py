@@ -64,11 +64,15 @@ def sharded_logpdf(gpar, x, y, w, group=None, timing=None):
 
 
 def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
-    from .model import _differentiable, _joining
+    from .model import _differentiable, _joining, _lockstep_values
 
     items = list(per_output(y, w, keep=gpar.impute))
-    # this rank's layers alternate over two streams when no layer feeds another (see HipEngine.pipeline)
-    pipe = get_engine().pipeline(rows=int(x.shape[0])) if gpar._independent(items) else None
+    eng = get_engine()
+    # this rank's layers alternate over two streams when no layer feeds another (see HipEngine.pipeline) ...
+    pipe = eng.pipeline(rows=int(x.shape[0])) if gpar._independent(items) else None
+    # ... or are factored together in lock-step
+    lockstep = pipe is not None and hasattr(eng, "logpdf_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
+    pending = []
     values, stage = [], 0
     with _joining(pipe):
         for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, gpar.layers))):
@@ -81,7 +85,11 @@ def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
                 if pipe is not None and _differentiable(f, noise):
                     pipe.join()
                     pipe = None
-                if pipe is not None:
+                if pipe is not None and lockstep:
+                    obs = gpar._obs(x, x_ind, yi, wi, f, noise, complete=True)
+                    obs.transient = True
+                    pending.append((f, obs))
+                elif pipe is not None:
                     with pipe.stage(stage, x, yi, wi):
                         values.append(f.measure.logpdf(gpar._obs(x, x_ind, yi, wi, f, noise, complete=True)))
                     stage += 1
@@ -111,6 +119,8 @@ def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
                 x_ind = torch.cat([x_ind, ind_col], dim=1)
     if pipe is not None:
         pipe.join()
+    if pending:
+        values.extend(_lockstep_values(eng, pending))
     for v in values:
         local = local + v
     return local, x, x_ind
