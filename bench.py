@@ -169,12 +169,13 @@ def main():
         "per_rank_busy_ms": busy_ms,
     }
     if launches.value > 0 and busy.value > 0:
-        # Independent layers are pipelined over two streams, so two trailing updates (of different layers) are often in
-        # flight at once and each one's own duration covers work of both.  The kernel's rate is therefore taken over the
-        # UNION of the launch intervals: flops / busy time = per-launch flops / (average launch duration / concurrency).
+        # The layers of an evaluation are factored in lock-step (one batched launch per trailing update); the narrow
+        # look-ahead update of step k + 1 and the rest of step k's run on two streams, so more than one launch is often in
+        # flight and each one's own duration covers work of the other.  The kernel's rate is therefore taken over the UNION
+        # of the launch intervals: flops / busy time = per-launch flops / (average launch duration / concurrency).
         achieved = flops.value / (busy.value * 1e-3) * 1e-12
         out["roofline"] = {
-            "kernel": "gpar::gemm_f64_kernel<false, true, 1, 128> and its half-tile form <false, true, 1, 64> for launches of at most 256 tiles (every trailing-update launch of gpar_potrf: rank-512 / rank-1024 SYRK of the rest of the matrix and the narrow look-ahead slices; v_mfma_f64_16x16x4)",
+            "kernel": "gpar::gemm_f64_kernel<false, true, 1, 128> and its half-tile form <false, true, 1, 64> for launches of at most 256 tiles (every trailing-update launch of gpar_potrf_batch: rank-512 / rank-1536 SYRK of the rest of the matrix and the narrow look-ahead slices, batched over the layers of the evaluation, blockIdx.z = layer; v_mfma_f64_16x16x4)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MATRIX_PEAK_TFLOPS,
@@ -191,8 +192,7 @@ def main():
         }
 
     # The timed region overlaps the trailing SYRK of panel k with the fused factorisation of panel k+1 (look-ahead on a
-    # second stream) and with the other stream's layer, so the live number above is the kernel's rate WHILE SHARING the
-    # chip.  One extra, untimed evaluation with look-ahead and layer pipelining switched off gives the same kernel's
+    # second stream), so the live number above is the kernel's rate WHILE SHARING the chip.  One extra, untimed evaluation with look-ahead and layer pipelining switched off gives the same kernel's
     # per-launch rate when it has the GPU to itself (concurrency 1: flops per launch / average launch duration).
     if True:  # every rank takes part (the evaluation contains a collective), whether or not it owns a layer
         os.environ["GPAR_POTRF_LOOKAHEAD"] = "0"
@@ -210,14 +210,15 @@ def main():
                 out["roofline"]["isolated"] = {"achieved": iso, "frac": iso / FP64_MATRIX_PEAK_TFLOPS, "launches": l2.value,
                                                "avg_launch_ms": ms2.value / l2.value,
                                                "note": "same kernel, one untimed evaluation with GPAR_POTRF_LOOKAHEAD=0 "
-                                                       "GPAR_LAYER_PIPELINE=0 (nothing co-running): flops per launch / average launch duration"}
+                                                       "GPAR_LAYER_PIPELINE=0 (layer after layer, nothing co-running): flops per launch / average launch duration"}
         finally:
             del os.environ["GPAR_POTRF_LOOKAHEAD"]
             del os.environ["GPAR_LAYER_PIPELINE"]
         if "roofline" in out:
             out["roofline"]["note"] = ("live value, measured inside the timed region with hipEvents on the launch streams: flops of all "
-                                       "launches / union of their intervals (`concurrency` launches are in flight on average because "
-                                       "independent layers run on two streams, and each co-runs with the next panel's factorisation); "
+                                       "launches / union of their intervals (`concurrency` launches are in flight on average: the narrow look-ahead "
+                                       "update overlaps the rest of the previous one, and both co-run with the next panel's factorisation; "
+                                       "a launch is batched over the layers of the lock-step evaluation); "
                                        "`avg_launch_ms` is the plain per-launch average that `rocprofv3 --stats` reports; see `isolated` "
                                        "for the kernel alone")
 

@@ -17,23 +17,31 @@ def read(dirname, counter):
     import glob
 
     path = sorted(glob.glob(dirname + "/**/*counter_collection.csv", recursive=True))[0]
-    rows = list(csv.DictReader(open(path)))
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Dispatch_Id"]))
     return [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and KERNEL in r["Kernel_Name"]]
 
 
 def main():
     fetch, write = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
     assert len(fetch) == len(write) and fetch, (len(fetch), len(write))
+    # the command runs ONE timed evaluation (lock-step: batched launches) and then bench.py's untimed `isolated` evaluation (layer
+    # after layer: `iso` launches, argv[3]); the per-launch figure is taken over the timed evaluation's launches only, like
+    # roofline.achieved / flop_per_launch
+    iso = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    if 0 < iso < len(fetch):
+        fetch, write = fetch[:-iso], write[:-iso]
     n = len(fetch)
     fetch_b = 2.0 * 1024.0 * sum(fetch) / n
     write_b = 1024.0 * sum(write) / n
     print(json.dumps({
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 0 --no-extras --no-cpu`",
-        "kernel": "gpar::gemm_f64_kernel<false, true, 1, 128> + <false, true, 1, 64> (all trailing-update launches of gpar_potrf)",
+        "kernel": "gpar::gemm_f64_kernel<false, true, 1, 128> + <false, true, 1, 64> (all trailing-update launches of the timed, lock-step evaluation: gpar_potrf_batch)",
         "launches": n,
         "fetch_bytes_per_launch_x2_corrected": fetch_b, "fetch_bytes_per_launch_raw": fetch_b / 2,
         "write_bytes_per_launch": write_b,
         "traffic_bytes_per_launch": fetch_b + write_b,
+        "traffic_bytes_per_evaluation": (fetch_b + write_b) * n,
+        "isolated_launches_excluded": iso,
         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (calibrated for 16-byte coalesced streams, which operands and C now both are), WRITE_SIZE as reported",
     }, indent=1))
 
