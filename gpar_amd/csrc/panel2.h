@@ -836,12 +836,25 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
 // launch bounds (256, 2): at most 256 unified registers, so that a wave fits beside a trailing-update wave (see panel.h)
 __global__ __launch_bounds__(256, 2) void potrf_panel2_kernel(PanelArgs p) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
-    // batched launch: blockIdx.y picks the matrix.  Workgroups are dispatched x first, then y, and a row block only ever waits
-    // for row blocks with a smaller x of its own matrix, i.e. for workgroups dispatched before it: any number of matrices is safe.
-    p.A += (size_t)blockIdx.y * p.batch_a;
-    if (p.logdet) p.logdet += blockIdx.y;
-    if (p.info) p.info += blockIdx.y;
-    const int rb = blockIdx.x;
+    // Batched launch (gridDim.y matrices).  Workgroups are dispatched x first, then y; the linear dispatch index is dealt so that
+    // the TEAMS of all matrices come first (team row rb of matrix b at index rb * batch + b), then the bulk row blocks, matrices
+    // interleaved: every chain starts at once instead of one matrix's bulk rows holding the slots the next matrix's team needs
+    // (same-box A/B: C3 189.8 -> 187.9 ms, C5 60.4 -> 59.7 ms per evaluation).  A row block still only waits for team rows of its
+    // own matrix with a smaller row index, i.e. a smaller dispatch index: any number of matrices is safe.
+    const int batch = gridDim.y, R = gridDim.x;
+    const int lin = blockIdx.x + R * blockIdx.y;
+    int rb, b;
+    if (lin < p.S * batch) {
+        rb = lin / batch;
+        b = lin - rb * batch;
+    } else {
+        const int idx = lin - p.S * batch;
+        rb = p.S + idx / batch;
+        b = idx % batch;
+    }
+    p.A += (size_t)b * p.batch_a;
+    if (p.logdet) p.logdet += b;
+    if (p.info) p.info += b;
     const int r0 = p.k0 + 64 * rb;
     if (rb < p.S) {
         __builtin_amdgcn_s_setprio(3);   // the chain: never lose an issue arbitration to bulk work on the same compute unit
