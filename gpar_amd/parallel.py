@@ -196,16 +196,23 @@ def sharded_condition(reg, group=None):
         return gpar | (reg.x, reg.y, reg.w)
     from .engine import joining
 
+    from .model import _lockstep_factors
+
     post = gpar.copy()
     pipe = eng.pipeline(rows=int(x.shape[0]))
-    factors = []
+    # this rank's layers: in lock-step when they are small enough, else over its streams
+    lockstep = pipe is not None and hasattr(eng, "factor_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
+    factors, mine = [], []
     with eng.defer_checks(), joining(pipe):
         for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, gpar.layers))):
             x = x[mask]
             f, noise = model()
             obs = gpar._obs(x, None, yi, wi, f, noise, complete=True)
             if i % size == rank:
-                if pipe is not None:
+                if lockstep:
+                    mine.append((i, obs))
+                    factors.append(None)
+                elif pipe is not None:
                     with pipe.stage(i // size, x, yi, wi):
                         factors.append(obs.factor())
                 else:
@@ -215,6 +222,10 @@ def sharded_condition(reg, group=None):
             post.layers.append(construct_model(f | obs, noise))
             if not is_last:
                 x = torch.cat([x, yi], dim=1)
+        if mine:
+            _lockstep_factors(eng, [o for _, o in mine])
+            for i, o in mine:
+                factors[i] = o.factor()
     # The exchange step: layer i's factor (L and the row L^-1 y: the lower triangle of the (n + 1) x (n + 1) buffer) lives on
     # rank i mod G.  Round k all-gathers layers k G .. k G + G - 1 in PACKED form - (n + 1)(n + 2) / 2 doubles each, half the
     # bytes of the padded square buffers and one collective over all xGMI links per round instead of one broadcast (one
