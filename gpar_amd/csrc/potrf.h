@@ -630,20 +630,27 @@ static int trsm_rlt_run2(const double* L, int n, int ldl, double* B, int nrows, 
     // launch 20.6 - the flops are the same and the block kernel runs them at the same ~55 % of the matrix-core rate.)
     const int NB = env_int("GPAR_TRSM_NB", n >= 1024 ? 512 : 64);
     const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && NB > 64 && gpar_aligned16(L) && gpar_aligned16(B) && (ldl % 2 == 0) && (ldb % 2 == 0);
-    // As in gpar_potrf, while many columns remain two blocks are solved back to back (the second after a narrow update of
-    // its own columns by the first) and everything to the right then gets ONE rank-2*NB update instead of two rank-NB ones.
+    // As in gpar_potrf, while many columns remain G blocks are solved back to back (each after a narrow update of its own
+    // columns by the ones before it) and everything to the right then gets ONE rank-G*NB update instead of G rank-NB ones.
     const int pair_cols = env_int("GPAR_TRSM_PAIR_COLS", 4096);
+    const int G = env_int("GPAR_TRSM_GROUP", 4);   // blocks per group (2 / 3 / 4 at n = 16384, 204800 rows: 69.6 / 70.4 / 70.9 TFLOP/s; n = 4096, 65536 rows: 63.7 / - / 65.3)
     for (int c0 = 0, c1 = 0; c0 < n; c0 = c1) {
-        const bool pair = fusable && NB == 512 && c0 + 2 * NB < n && (n - c0) >= pair_cols;
-        if (pair) {
-            const int cm = c0 + NB;
-            c1 = c0 + 2 * NB;
-            const int rows_a = upper_tri ? (nrows < cm ? nrows : cm) : nrows;
-            const int rows = upper_tri ? (nrows < c1 ? nrows : c1) : nrows;   // rows beyond rows_a are still zero in block A
-            int rc = trsm_block_any(L, n, ldl, B, rows_a, ldb, c0, NB / 64, upper_tri, stream);
-            if (!rc) rc = gemm_launch(0, 1, rows_a, NB, NB, -1.0, B + c0, ldb, L + (size_t)cm * ldl + c0, ldl, 1.0, B + cm, ldb, 0, stream);
-            if (!rc) rc = trsm_block_any(L, n, ldl, B, rows, ldb, cm, NB / 64, upper_tri, stream);
-            if (!rc) rc = gemm_launch(0, 1, rows, n - c1, 2 * NB, -1.0, B + c0, ldb, L + (size_t)c1 * ldl + c0, ldl, 1.0, B + c1, ldb, 0, stream);
+        const bool group = fusable && G > 1 && NB == 512 && c0 + G * NB < n && (n - c0) >= pair_cols;
+        if (group) {
+            c1 = c0 + G * NB;
+            int rc = 0;
+            for (int i = 0; i < G && !rc; ++i) {
+                const int ci = c0 + i * NB;
+                // an upper-triangular right-hand side (upper_tri): row r is zero left of column r, so rows >= ci contribute
+                // nothing to the narrow update of block i and rows >= ci + NB have nothing in it to solve
+                const int rows_upd = upper_tri ? (nrows < ci ? nrows : ci) : nrows;
+                const int rows_blk = upper_tri ? (nrows < ci + NB ? nrows : ci + NB) : nrows;
+                if (i > 0)   // block i's columns: one update by the i blocks of the group solved so far
+                    rc = gemm_launch(0, 1, rows_upd, NB, i * NB, -1.0, B + c0, ldb, L + (size_t)ci * ldl + c0, ldl, 1.0, B + ci, ldb, 0, stream);
+                if (!rc) rc = trsm_block_any(L, n, ldl, B, rows_blk, ldb, ci, NB / 64, upper_tri, stream);
+            }
+            const int rows = upper_tri ? (nrows < c1 ? nrows : c1) : nrows;
+            if (!rc) rc = gemm_launch(0, 1, rows, n - c1, G * NB, -1.0, B + c0, ldb, L + (size_t)c1 * ldl + c0, ldl, 1.0, B + c1, ldb, 0, stream);
             if (rc) return rc;
             continue;
         }
