@@ -402,7 +402,8 @@ class GPAR:
                 shared = False
             else:
                 xs = xs.with_columns(fed)
-        return [torch.stack([c[:, s] for c in columns], dim=1) for s in range(S)]
+        # one stack (n* x S x p) and S views of it, instead of S stacks of p columns each
+        return list(torch.stack(columns, dim=2).permute(1, 0, 2).unbind(0))
 
     # ---- helpers -----------------------------------------------------------------------------------
     @staticmethod
