@@ -730,8 +730,10 @@ class Obs:
         return B
 
     def _chunk(self, ns):
-        """Samples per stacked right-hand side: S n* x n doubles bounded to ~16 GB of the 288 GB HBM."""
-        return max(1, int(16e9 // max(1, ns * max(self.fdd.n, 1) * 8)))
+        """Samples per chunk: the stacked right-hand side (S n* x n doubles) and the stacked per-sample covariances
+        (S n* x n*) are each bounded to ~16 GB of the 288 GB HBM; at most 16384 samples at a time (the batched launches
+        carry the sample index in a grid dimension, limit 65535)."""
+        return max(1, min(16384, int(16e9 // max(1, ns * max(self.fdd.n, ns, 1) * 8))))
 
     def posterior_marginals_batch(self, xs):
         """(means, variances), each n* x S: column s holds the posterior mean / marginal variance (no noise) at xs[s]."""
