@@ -156,3 +156,38 @@ def test_inducing_point_approximations(engine, method):
             fd[i] += sgn * float(reg.logpdf(x, y)) / 2e-5
     reg.vs.set_vector(x0, names)
     np.testing.assert_allclose(grad, fd, rtol=2e-5, atol=1e-6 * np.max(np.abs(fd)))
+
+
+def test_stacked_input_sets_behave_like_the_list_of_their_blocks():
+    """gp.Stacked (the per-sample design matrices of ancestral sampling, kept in one matrix from layer to layer): length,
+    indexing, contiguous slices, iteration and appended columns agree with the list-of-matrices form it replaces."""
+    import torch
+
+    from gpar_amd.gp import Stacked
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(7, 2, generator=g, dtype=torch.float64)
+    S = 4
+    st = Stacked.repeat(x, S)
+    assert len(st) == S and st.rows == 7 and all(torch.equal(b, x) for b in st)
+    fed = torch.rand(7, S, generator=g, dtype=torch.float64)
+    st2 = st.with_columns(fed)
+    as_list = [torch.cat([x, fed[:, s : s + 1]], dim=1) for s in range(S)]
+    assert st2.matrix.shape == (7 * S, 3)
+    for s in range(S):
+        assert torch.equal(st2[s], as_list[s])
+    assert torch.equal(st2[-1], as_list[-1])
+    part = st2[1:3]
+    assert len(part) == 2 and torch.equal(part[0], as_list[1]) and torch.equal(part[1], as_list[2])
+    means = torch.rand(7 * S, 1, generator=g, dtype=torch.float64)   # already stacked: one column per set, set-major
+    st3 = st2.with_columns(means)
+    for s in range(S):
+        assert torch.equal(st3[s], torch.cat([as_list[s], means[7 * s : 7 * (s + 1)]], dim=1))
+    one = Stacked.repeat(x, 1).with_columns(fed[:, :1])
+    assert len(one) == 1 and torch.equal(one[0], as_list[0])
+    try:
+        st2[::2]
+    except IndexError:
+        pass
+    else:
+        raise AssertionError("strided slices must be rejected")
