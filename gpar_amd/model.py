@@ -134,7 +134,12 @@ def _lockstep_values(eng, pending):
             values.extend(pending[i + j][0].measure.logpdf(o) for j, o in enumerate(chunk))
             continue
         items = [(eng.compile(o.base.kernel, o.fdd.x.shape[1]), o.fdd.x, o.y, o.fdd.noise) for o in chunk]
-        vals, info = eng.logpdf_dense_batch(items, eng.epsilon)
+        try:
+            vals, info = eng.logpdf_dense_batch(items, eng.epsilon)
+        except torch.cuda.OutOfMemoryError:   # the batch buffer did not fit beside what the caller holds: one layer at a time
+            torch.cuda.empty_cache()
+            values.extend(pending[i + j][0].measure.logpdf(o) for j, o in enumerate(chunk))
+            continue
         eng.check_info(info)
         values.extend(vals[b].detach() for b in range(len(chunk)))
     return values
@@ -154,7 +159,11 @@ def _lockstep_factors(eng, obs):
             if len(chunk) < 2:
                 break
             items = [(eng.compile(o.base.kernel, o.fdd.x.shape[1]), o.fdd.x, o.y, o.fdd.noise) for o in chunk]
-            A, logdet, info = eng.factor_dense_batch(items, eng.epsilon)
+            try:
+                A, logdet, info = eng.factor_dense_batch(items, eng.epsilon)
+            except torch.cuda.OutOfMemoryError:   # no room for the batch buffer: the loop below factors them one at a time
+                torch.cuda.empty_cache()
+                break
             eng.check_info(info)
             for b, o in enumerate(chunk):
                 o._fac = _Factor.from_batch(eng, n, A[b * (n + 1):(b + 1) * (n + 1)], logdet[b:b + 1])
