@@ -66,14 +66,60 @@ def main():
     ap.add_argument("--extras-timeout", type=float, default=600.0,
                     help="seconds the fit + predict / CPU-baseline / teardown part may take before every rank exits (rank 0 prints the line first)")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work the bounded torch-CPU baseline may spend on full-size layers")
+    ap.add_argument("--init-timeout", type=float, default=300.0,
+                    help="seconds the process group may take to form (and the first collective to return) before every rank gives up")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="form the process group (gloo, no GPU needed), all-reduce one word, print a JSON line and exit: exercises the launcher")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver calls it: this process becomes the launcher of N ranks (one per GPU) on a free
+        # local port; every rank re-enters main() with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and rank 0 prints the line
+        relaunch(args.gpus)
+
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # read by the HIP runtime when it initialises (see gpar_amd.engine._hardware_queues)
+    import threading
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, or without a "
+                         f"launcher: `python bench.py --gpus {args.gpus}` starts the ranks itself)")
+
+    # From here until the process group has formed and answered one collective, a watchdog: a rank that cannot reach its peers
+    # (RCCL initialisation failure, a peer that died at start-up) would otherwise hang in the first collective.
+    def init_failed():
+        if rank == 0:
+            print(json.dumps({"metric": "logpdf_per_s", "value": None, "n_gpus": world,
+                              "error": f"process group of {world} ranks did not form within {args.init_timeout} s"}), flush=True)
+        os._exit(3)
+
+    init_watchdog = threading.Timer(args.init_timeout, init_failed)
+    init_watchdog.daemon = True
+    if world > 1:
+        init_watchdog.start()
+
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.init_timeout))
+            word = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(word)
+            dist.barrier()
+        else:
+            word = torch.tensor([1.0], dtype=torch.float64)
+        init_watchdog.cancel()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "sum_of_ranks_plus_one": float(word[0])}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     # development aid: GPAR_BENCH_ONE_GPU=1 lets several ranks share GPU 0 over gloo, to exercise the multi-rank control flow
     # (collectives, sharded fit / predict) on a one-GPU box; timings of such a run mean nothing
     one_gpu_dev = os.environ.get("GPAR_BENCH_ONE_GPU") == "1"
@@ -84,11 +130,18 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        limit = datetime.timedelta(seconds=args.init_timeout)
         if one_gpu_dev:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=limit, device_id=torch.device(f"cuda:{local_rank}"))
+        # the first collective forms the communicator: do it here, under the start-up watchdog, not inside the first warm-up step
+        hello = torch.ones(1, dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(hello)
+        torch.cuda.synchronize()
+        if int(hello.item()) != world:
+            raise SystemExit(f"bench.py: first all-reduce returned {hello.item()} on {world} ranks")
+    init_watchdog.cancel()
 
     from gpar_amd import _lib
     from gpar_amd.engine import HipEngine, set_engine
@@ -225,8 +278,6 @@ def main():
     # The headline is measured by now.  Everything below (the fit + predict leg with its collectives, the CPU baseline, the
     # process-group teardown) runs under a watchdog: should a peer die or a collective hang, every rank leaves after
     # `--extras-timeout` seconds and rank 0 still prints the one JSON line, with the leg marked as timed out.
-    import threading
-
     printed = []
 
     def emit():
@@ -257,6 +308,23 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     watchdog.cancel()
+
+
+def relaunch(gpus):
+    """Replace this process by `python -m torch.distributed.run` with `gpus` ranks of this very command on 127.0.0.1 and a free
+    port (the form the round-end driver uses for N > 1; here for the plain `python bench.py --gpus N` call)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")             # (torchrun would set it, with a warning)
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
 
 
 def pmc_traffic(n, m, p):

@@ -7,15 +7,11 @@ libgpar_hip.so or the GPU is missing: there is no CPU fallback).
 """
 __version__ = "0.2.0"
 
-import os as _os
+# (Nothing process-wide is changed by importing the package.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+# queues - 4 by default - and streams that share a queue serialise; `HipEngine` asks for 8 when it is created before the
+# process has touched the GPU and otherwise works with what the runtime already has: see engine._hardware_queues.)
 
-# The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue
-# serialise.  Independent layers run on up to four streams beside the caller's, each factorisation may add a look-ahead side
-# stream: with four queues the fourth layer stream silently ran behind the first (C2: 5.4 ms, 4.85 with eight queues).  Read
-# by the runtime when it initialises, i.e. at the first GPU call of the process - a value set by the user wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-from .regression import GPARRegressor, log_transform, squishing_transform  # noqa: E402,F401
-from .model import GPAR  # noqa: E402,F401
+from .regression import GPARRegressor, log_transform, squishing_transform  # noqa: F401
+from .model import GPAR  # noqa: F401
 
 __all__ = ["GPARRegressor", "GPAR", "log_transform", "squishing_transform"]

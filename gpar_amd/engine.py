@@ -53,11 +53,35 @@ class HandOffTimeoutError(ArithmeticError):
         self.code = code
 
 
+_HW_QUEUES = None
+
+
+def _hardware_queues():
+    """Hardware queues the HIP runtime of this process maps streams onto (GPU_MAX_HW_QUEUES; the runtime's default is 4 and it
+    reads the variable once, when it initialises).  Independent layers run on up to four streams beside the caller's and each
+    factorisation may add a look-ahead side stream; with four queues the fourth layer stream silently runs behind the first
+    (C2: 5.4 ms instead of 4.85).  So: a value the user exported always wins; if there is none and this process has not used
+    the GPU through torch yet, 8 is exported here (engine creation, not package import) and assumed to take effect; if the
+    GPU is already in use, the runtime's default is assumed and the layer pipeline stays at three streams."""
+    global _HW_QUEUES
+    if _HW_QUEUES is None:
+        env = os.environ.get("GPU_MAX_HW_QUEUES")
+        if env is not None:
+            _HW_QUEUES = int(env)
+        elif not torch.cuda.is_initialized():
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
+            _HW_QUEUES = 8
+        else:
+            _HW_QUEUES = 4
+    return _HW_QUEUES
+
+
 class HipEngine:
     name = "hip"
 
     def __init__(self, device=None, seed=0, epsilon=1e-12):
         _lib.load()  # raises HipLibraryError if libgpar_hip.so is missing: no fallback
+        self.hw_queues = _hardware_queues()  # before the first GPU call below
         if not torch.cuda.is_available():
             raise RuntimeError(
                 "gpar_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is False and there is no CPU fallback"
@@ -93,12 +117,17 @@ class HipEngine:
 
     # ---- kernels ---------------------------------------------------------------------------------
     def compile(self, kernel, width):
-        # (kernel objects are immutable expression trees: a layer constructor memoised by the variable store hands the same
-        # object to every evaluation, and its device specification with it)
+        # A kernel object is an immutable expression tree, but its hyper-parameters may be torch tensors that the caller
+        # updates IN PLACE (an optimiser step, `t.fill_()`): the compiled specification bakes their values, so it is cached
+        # per (width, identity and version counter of every tensor parameter) - a stale specification is never returned.
+        # (The layer constructors memoised by the variable store hand the same object to every evaluation of an epoch.)
         cache = kernel.__dict__.setdefault("_compiled", {})
-        ck = cache.get(width)
-        if ck is None:
-            ck = cache[width] = compile_kernel(kernel, width)
+        stamp = kernel.stamp()
+        hit = cache.get(width)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        ck = compile_kernel(kernel, width)
+        cache[width] = (stamp, ck)
         return ck
 
     def features(self, ck, x):
@@ -263,6 +292,14 @@ class HipEngine:
         raw = raw + hip.gram_grad_cross(ck, fx, dx, fx, dx, wdiag.contiguous(), hip.GRAD_DIAG)
         return self._grads_from_moments(ck, raw.cpu().numpy(), 1.0)
 
+    def kernel_grads_diag(self, ck, x, wdiag):
+        """sum_a wdiag[a] dk(x_a, x_a) for every kernel parameter (one device pass over the n diagonal pairs)."""
+        x = self._mat(x)
+        fx = hip.featurize(ck, x)
+        dx = hip.featurize_dfreq(ck, x) if self._periodic(ck) else None
+        raw = hip.gram_grad_cross(ck, fx, dx, fx, dx, wdiag.contiguous(), hip.GRAD_DIAG)
+        return self._grads_from_moments(ck, raw.cpu().numpy(), 1.0)
+
     def kernel_input_grads(self, ck, x1, x2, W, sym=False):
         """d / d x1 of  sum_ab W_ab k(x1_a, x2_b)  as an n1 x width matrix (x2 held fixed).  `sym`: x2 is x1, W is symmetric
         and given by its lower triangle, and BOTH arguments move: d / d x of sum_ab W_ab k(x_a, x_b) = 2 sum_b W_ab d_1 k.
@@ -343,7 +380,7 @@ class HipEngine:
         if (env is not None and int(env) < 2) or getattr(self._tls, "safe", False) or self.cholesky_retry_factor > 1:
             return None
         if depth is None:
-            depth = int(env) if env is not None else (4 if rows is not None and rows < 9216 else 2)
+            depth = int(env) if env is not None else ((4 if self.hw_queues >= 8 else 3) if rows is not None and rows < 9216 else 2)
         if depth < 2:
             return None
         return _LayerPipeline(self, _device_streams(self.device, depth))

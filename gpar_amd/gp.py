@@ -255,6 +255,10 @@ class _LogMarginal(torch.autograd.Function):
             gX, gZ = obs.input_gradients(ctx.needs_input_grad[2], ctx.needs_input_grad[3])
             gX = None if gX is None else gX * gval
             gZ = None if gZ is None else gZ * gval
+        # the weights of the backward pass (n x n for dense observations: 2 GB at n = 16384) are not needed again
+        for name in ("_W", "_weights"):
+            if hasattr(obs, name):
+                delattr(obs, name)
         return (None, out_noise, gX, gZ, *_param_grads(obs._params, ctx.shapes, grads, gval))
 
 
@@ -859,7 +863,8 @@ class PseudoObs:
             # the effective noise needs q_aa = |B_:a|^2 before anything can be scaled by it: one more pass over n x M
             Bs = base._cross(px, pz)
             eng.trsm_rlt_(Lz, Bs)
-            d = d + torch.clamp(kdiag - eng.rownorm2(Bs), min=0.0)
+            excess = kdiag - eng.rownorm2(Bs)  # k_aa - q_aa >= 0 up to rounding
+            d = d + torch.clamp(excess, min=0.0)
             rs = torch.rsqrt(d)
             Bs.mul_(rs[:, None])
         else:
@@ -879,7 +884,9 @@ class PseudoObs:
 
         def fill(block, scale):
             block.copy_(G)
-            block.diagonal().add_(1.0)
+            # (first attempt: A as it is - its diagonal is >= 1; a retry of lab's ladder adds the grown part of the jitter,
+            # so that every rung factors a different matrix)
+            block.diagonal().add_(1.0 + (scale - 1.0) * eng.epsilon)
 
         facA = _Factor(eng, M, fill, c)
         elbo = -0.5 * (trace_term + torch.sum(torch.log(d)) + n * _LOG_2PI + facA.logdet[0] + yDy - facA.quad)
@@ -888,7 +895,8 @@ class PseudoObs:
         eng.trsm_rln_(Lz, v)
         deferring = getattr(eng, "_deferred", None) is not None
         self._state = {"Lz": Lz, "La": facA.L, "v": v, "elbo": elbo.detach() if deferring else elbo.detach().cpu(),
-                       "Bs": Bs, "G": G, "facA": facA, "kdiag": kdiag, "ys": ys, "d": d}
+                       "Bs": Bs, "G": G, "facA": facA, "kdiag": kdiag, "ys": ys, "d": d,
+                       "moves": (excess > 0).to(d.dtype) if self.method == "fitc" else None}
         return self._state
 
     def _value(self):
@@ -922,13 +930,11 @@ class PseudoObs:
             (S^-1)_aa = 1/d_a - |L_A^-1 B_:a|^2 / d_a^2.
         The forward pass keeps Bs = D^-1/2 B^T, so B^T = D^1/2 Bs throughout.  The three weighted sums over kernel
         derivatives are one fused device pass each (`kernel_grads_vfe`)."""
-        if self.method == "fitc":
-            raise NotImplementedError("training through the FITC approximation is not implemented (use VFE or DTC)")
-        vfe = self.method == "vfe"
+        vfe, fitc = self.method == "vfe", self.method == "fitc"
         eng = self.eng
         st = self._compute()
         n, M = self.fdd.n, self.u.n
-        d = self.fdd.noise
+        d = st["d"]  # the observation noise; FITC: the effective noise d + k_aa - q_aa
         rs = torch.rsqrt(d)
         Bs, facA, Lz, G = st["Bs"], st["facA"], st["Lz"], st["G"]
         a = facA.alpha()  # (A^-1 B D^-1 y)^T, 1 x M
@@ -945,19 +951,6 @@ class PseudoObs:
         eng.gemm(Bs, Ainv_full, alpha=-1.0, beta=1.0, out=T)  # Bs (I - A^-1)   [DTC: -Bs A^-1]
         T.mul_(rs[:, None])  # D^-1 B^T (I - A^-1)
         T.add_(alpha[:, None] * beta)
-        eng.trsm_rln_(Lz, T)  # ... L_z^-1
-        # W_uu
-        S = eng.new_matrix(M, M)
-        S.copy_(beta.reshape(M, 1) * beta + Ainv_full)
-        if vfe:
-            S.add_(torch.tril(G) + torch.tril(G, -1).T)  # B D^-1 B^T = A - I (the trace term's share)
-        S.diagonal().sub_(1.0)
-        eng.trsm_rln_(Lz, S)  # S L_z^-1
-        St = eng.new_matrix(M, M)
-        St.copy_(S.T)
-        eng.trsm_rln_(Lz, St)  # L_z^-T S L_z^-1 (symmetric)
-        Wuu = eng.new_matrix(M, M)
-        Wuu.copy_(-0.25 * (St + St.T))
         # per-point terms: |L_A^-1 B_:a|^2 / d_a^2 = |Es_a|^2 / d_a with Es = Bs L_A^-T, and q_aa / d_a^2 = |Bs_a|^2 / d_a
         E = eng.new_matrix(n, M)
         E.copy_(Bs)
@@ -968,6 +961,31 @@ class PseudoObs:
         else:
             noise_grad = 0.5 * (alpha * alpha - 1.0 / d + eng.rownorm2(E) / d)
             wdiag = torch.zeros_like(d)
+        del E
+        S = eng.new_matrix(M, M)
+        S.copy_(beta.reshape(M, 1) * beta + Ainv_full)
+        if vfe:
+            S.add_(torch.tril(G) + torch.tril(G, -1).T)  # B D^-1 B^T = A - I (the trace term's share)
+        S.diagonal().sub_(1.0)
+        if fitc:
+            # FITC is the DTC objective at the effective noise e_a = d_a + k_aa - q_aa, q_aa = K_az K_zz^-1 K_za, which moves with
+            # the kernel: with g_a = dF / de_a (the DTC noise gradient above), sum_a g_a de_a adds
+            #   g_a dk_aa                      -> wdiag = g,
+            #   -2 g_a [K_az K_zz^-1] dK_za    -> W_fu -= 2 diag(g) B^T L_z^-1          (B^T = D^1/2 Bs),
+            #   +g_a [P dK_zz P^T]_aa          -> W_uu += P diag(g) P^T, i.e. S -= 2 B diag(g) B^T
+            # (points whose k_aa - q_aa was clamped at zero do not move).
+            chain = noise_grad * st["moves"]
+            wdiag = chain
+            T.sub_((2.0 * chain / rs)[:, None] * Bs)
+            eng.gemm(Bs * (chain * d)[:, None], Bs, ta=True, alpha=-2.0, beta=1.0, out=S)
+        eng.trsm_rln_(Lz, T)  # ... L_z^-1
+        # W_uu
+        eng.trsm_rln_(Lz, S)  # S L_z^-1
+        St = eng.new_matrix(M, M)
+        St.copy_(S.T)
+        eng.trsm_rln_(Lz, St)  # L_z^-T S L_z^-1 (symmetric)
+        Wuu = eng.new_matrix(M, M)
+        Wuu.copy_(-0.25 * (St + St.T))
         ck = self.fdd.pts().ck
         grads = eng.kernel_grads_vfe(ck, self.fdd.x.detach(), self.u.x.detach(), T, Wuu, wdiag)
         self._weights = (T, Wuu, wdiag)
@@ -994,14 +1012,13 @@ class PseudoObs:
         With h = Sigma^-1 K(Z, xs) g, p = K_xz v (the mean at X) and q = K_xz h:
             d = sum (g v^T) dK(xs, Z) + sum W_fu dK(X, Z) + sum W_uu dK(Z, Z) - sum_a q_a (y_a - p_a) / d_a^2 dd_a,
             W_fu = ((y - p) / d) h^T - (q / d) v^T,     W_uu = -1/2 (h v^T + v h^T).
-        (VFE / DTC: the effective noise is the observation noise; FITC's depends on the kernel and is not covered.)"""
-        if self.method == "fitc":
-            raise NotImplementedError("differentiating the posterior mean of the FITC approximation is not implemented")
+        FITC: d is the effective noise e_a = d_a + k_aa - q_aa; the term sum_a n_a de_a (n_a = the noise gradient above) adds
+        n_a dk_aa - 2 n_a [K_az K_zz^-1] dK_za + n_a [P dK_zz P^T]_aa to the three weighted sums, as in `gradients`."""
         eng, st = self.eng, self._compute()
         ck = self.fdd.pts().ck
         X, Z = self.fdd.x.detach(), self.u.x.detach()
         n, M = self.fdd.n, self.u.n
-        d = self.fdd.noise
+        d = st["d"]  # FITC: the effective noise (its own dependence on the kernel is chained in below)
         v = st["v"].reshape(-1)
         pxs = self.base._pts(xs)
         Ksz = eng.gram(ck, pxs.z, self.u.pts().z)  # n* x M
@@ -1021,13 +1038,27 @@ class PseudoObs:
         W_fu.copy_((resid / d)[:, None] * h[None, :] - (q_ / d)[:, None] * v[None, :])
         W_uu = eng.new_matrix(M, M)
         W_uu.copy_(-0.5 * (h[:, None] * v[None, :] + v[:, None] * h[None, :]))
+        noise_grad = -q_ * resid / (d * d)
+        chain = None
+        if self.method == "fitc":
+            chain = noise_grad * st["moves"]
+            Pt = eng.new_matrix(n, M)
+            Pt.copy_(st["Bs"] * torch.sqrt(d)[:, None])
+            eng.trsm_rln_(st["Lz"], Pt)  # K_xz K_zz^-1
+            W_fu.sub_(2.0 * chain[:, None] * Pt)
+            eng.gemm(Pt * chain[:, None], Pt, ta=True, alpha=1.0, beta=1.0, out=W_uu)
+            del Pt
         params = _add_grads(eng.kernel_grads_weighted(ck, xs, Z, W_sz), eng.kernel_grads_weighted(ck, X, Z, W_fu))
         params = _add_grads(params, eng.kernel_grads_weighted(ck, Z, None, W_uu, sym=True))
-        out = {"params": params, "noise": -q_ * resid / (d * d)}
+        if chain is not None:
+            params = _add_grads(params, eng.kernel_grads_diag(ck, X, chain))
+        out = {"params": params, "noise": noise_grad}
         if want_xs:
             out["xs"] = eng.kernel_input_grads(ck, xs, Z, W_sz)
         if want_x:
             out["x"] = eng.kernel_input_grads(ck, X, Z, W_fu)
+            if chain is not None:
+                out["x"] = out["x"] + eng.kernel_diag_input_grads(ck, X, chain)
         if want_z:
             A_ = eng.new_matrix(M, xs.shape[0])
             A_.copy_(W_sz.T)

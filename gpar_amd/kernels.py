@@ -88,6 +88,17 @@ def _scalar_like(x):
     return isinstance(x, (int, float, np.floating, np.integer)) or (hasattr(x, "shape") and tuple(x.shape) in ((), (1,)))
 
 
+def _times(a, b):
+    """a * b for coefficients, handing a tensor through untouched when the other side is the float 1 (the elementary kernels'
+    own coefficient): `var * EQ()` then holds `var` ITSELF, so an in-place update of `var` is seen by the next compilation.
+    (A product of two tensors is a new tensor, evaluated when the kernel is built - as in any torch expression.)"""
+    if isinstance(a, float) and a == 1.0:
+        return b
+    if isinstance(b, float) and b == 1.0:
+        return a
+    return a * b
+
+
 class Kernel:
     """A kernel in sum-of-products normal form."""
 
@@ -107,10 +118,10 @@ class Kernel:
     def __mul__(self, other):
         if isinstance(other, Kernel):
             return Kernel(
-                [Term(a.coef * b.coef, a.factors + b.factors) for a in self.terms for b in other.terms]
+                [Term(_times(a.coef, b.coef), a.factors + b.factors) for a in self.terms for b in other.terms]
             )
         if _scalar_like(other):
-            return Kernel([Term(other * t.coef, t.factors) for t in self.terms])
+            return Kernel([Term(_times(other, t.coef), t.factors) for t in self.terms])
         return NotImplemented
 
     __rmul__ = __mul__
@@ -156,6 +167,19 @@ class Kernel:
     @property
     def is_zero(self):
         return len(self.terms) == 0
+
+    def stamp(self):
+        """Cheap fingerprint of the hyper-parameter VALUES the kernel currently holds: (identity, in-place version counter)
+        of every torch tensor, the bytes of every numpy array.  Floats are immutable and the tree itself never changes, so an
+        equal stamp means `compile_kernel` would produce the same device specification."""
+        out = []
+        for t in self.terms:
+            for v in [t.coef] + [x for f in t.factors for x in (f.scales, f.periods, f.alpha)]:
+                if hasattr(v, "_version"):
+                    out.append((id(v), v._version))
+                elif isinstance(v, np.ndarray):
+                    out.append(v.tobytes())
+        return tuple(out)
 
     def hyperparameters(self):
         """Every torch-tensor hyper-parameter the kernel holds (for autograd plumbing), in a fixed order."""

@@ -71,18 +71,29 @@ def last(xs, select=None):
         yield True, current
 
 
-def _retry_unfused(evaluate):
+def _retry_unfused(evaluate, layers=(), inputs=(), rewind=False):
     """evaluate(); should a hand-off inside a persistent panel kernel have timed out (device-side info < 0: results
-    invalid), once more with the engine in safe mode - separate leaf kernels, no look-ahead, no layer pipelining.  An
-    objective under autograd is not retried here: the optimiser treats the error as a failed evaluation."""
+    invalid), once more with the engine in safe mode - separate leaf kernels, no look-ahead, no layer pipelining.  Whether
+    the retry is allowed is read off the actual graph, not off the global grad mode (which is on by default on every
+    inference path): an evaluation none of whose layers carries trainable tensors and none of whose inputs requires grad is
+    not part of an objective and is simply repeated; an objective under autograd is not retried here - the optimiser treats
+    the error as a failed evaluation."""
     from .engine import HandOffTimeoutError
 
+    calls = getattr(get_engine(), "_calls", None) if rewind else None
     try:
         return evaluate()
     except HandOffTimeoutError:
         eng = get_engine()
-        if torch.is_grad_enabled() or not hasattr(eng, "safe_mode"):
+        if not hasattr(eng, "safe_mode"):
             raise
+        if calls is not None:
+            eng._calls = calls  # `rewind`: the repetition draws the same random numbers as the failed attempt
+        if torch.is_grad_enabled():
+            if any(_is_torch(t) and t.requires_grad for t in inputs):
+                raise
+            if any(_differentiable(*model()) for model in layers):
+                raise
         with eng.safe_mode():
             return evaluate()
 
@@ -220,7 +231,7 @@ class GPAR:
     # ---- conditioning ----------------------------------------------------------------------------
     def __or__(self, x_y_w):
         """Posterior GPAR given data (x, y, w)."""
-        return _retry_unfused(lambda: self._condition(x_y_w))
+        return _retry_unfused(lambda: self._condition(x_y_w), self.layers, x_y_w)
 
     def _condition(self, x_y_w):
         x, y, w = self._prep(*x_y_w)
@@ -263,7 +274,8 @@ class GPAR:
         `outputs` restricts the layers visited, `x_ind` resumes a computation and `return_inputs` returns the
         design matrix (and inducing inputs) reached after the last visited layer instead of the value — the
         three together let `fit` precompute the inputs of a layer once (reference: model.py:178-243)."""
-        return _retry_unfused(lambda: self._logpdf(x, y, w, only_last_layer, sample_missing, return_inputs, x_ind, outputs))
+        return _retry_unfused(lambda: self._logpdf(x, y, w, only_last_layer, sample_missing, return_inputs, x_ind, outputs),
+                              self.layers, (x, y, w, x_ind))
 
     def _logpdf(self, x, y, w, only_last_layer, sample_missing, return_inputs, x_ind, outputs):
         x, y, w = self._prep(x, y, w)
@@ -336,6 +348,9 @@ class GPAR:
     def sample(self, x, w, latent=False):
         """One ancestral sample, n x p (reference: model.py:245-277).  With `latent` the noise-free function
         values are returned while the noisy values are what is fed to the next layer."""
+        return _retry_unfused(lambda: self._sample(x, w, latent), self.layers, (x, w), rewind=True)
+
+    def _sample(self, x, w, latent):
         eng = get_engine()
         x = eng.tensor(x)
         if x.dim() == 1:
@@ -371,6 +386,9 @@ class GPAR:
         does not, so `sample` keeps the joint sampler.  No n* x n* covariance is built or factored."""
         if num_samples == 1 and not marginal:
             return [self.sample(x, w, latent=latent)]
+        return _retry_unfused(lambda: self._sample_many(x, w, num_samples, latent, marginal), self.layers, (x, w), rewind=True)
+
+    def _sample_many(self, x, w, num_samples, latent, marginal):
         eng = get_engine()
         x = eng.tensor(x)
         if x.dim() == 1:

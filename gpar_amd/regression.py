@@ -157,7 +157,7 @@ def _default_weights(rows, cols):
 def _init_weights(w, y, attribute=False):
     if w is None:
         # (`condition` keeps the reference's attribute: a host tensor, made once)
-        return torch.ones(*y.shape, dtype=torch.float64) if attribute else _default_weights(*y.shape)
+        return torch.from_numpy(np.ones(tuple(y.shape), dtype=np.float64)) if attribute else _default_weights(*y.shape)
     return _uprank(_to_torch(w))
 
 
@@ -199,6 +199,8 @@ class GPARRegressor:
                  linear_scale=100.0, nonlinear=False, nonlinear_scale=1.0, rq=False, markov=None, noise=0.1,
                  x_ind=None, normalise_y=True, transform_y=(lambda x: x, lambda x: x), sparse_method="vfe"):
         self.replace = replace
+        if sparse_method not in ("vfe", "fitc", "dtc"):
+            raise ValueError('sparse_method must be "vfe", "fitc" or "dtc"')
         self.sparse_method = sparse_method  # an addition behind the reference's keywords: "vfe" | "fitc" | "dtc"
         self.impute = impute
         self.sparse = x_ind is not None
@@ -223,39 +225,35 @@ class GPARRegressor:
 
     def condition(self, x, y, w=None):
         """Store (and transform / normalise) the training data without training (reference regression.py:339-389)."""
-        # The attributes are host tensors, as in the reference, and the few element-wise passes over them run on ONE host
-        # thread: with the default thread count each pass opens an OpenMP region whose workers (one per core) spin afterwards,
-        # which in a container with a CPU quota throttles the evaluations that follow (fit(iters=3) at n = 8192: 0.68 -> 0.60 s).
-        threads = torch.get_num_threads()
-        torch.set_num_threads(1)
-        try:
-            self._condition(x, y, w)
-        finally:
-            torch.set_num_threads(threads)
-
-    def _condition(self, x, y, w):
+        # The attributes are host tensors, as in the reference.  The element-wise passes over them (mask, mean, standard
+        # deviation, normalisation) go through numpy, which runs them on the calling thread: a torch CPU operator on 32768 or
+        # more elements opens an OpenMP region whose workers (one per core) spin afterwards, which in a container with a CPU
+        # quota throttles the evaluations that follow (fit(iters=3) at n = 8192: 0.68 -> 0.60 s) - and changing torch's
+        # global thread count around the call instead would be visible to other threads of the process.
         self.x = _uprank(_to_torch(x))
         self.y = self._transform_y(_uprank(_to_torch(y)))
         self.w = _init_weights(w, self.y, attribute=True)
         self.n, self.m = self.x.shape
         self.p = self.y.shape[1]
         if self.normalise_y:
-            means, stds = [], []
+            y_np = self.y.detach().numpy()
+            means = np.empty((1, self.p), dtype=y_np.dtype)
+            stds = np.empty((1, self.p), dtype=y_np.dtype)
             for i in range(self.p):
-                y_i = self.y[~torch.isnan(self.y[:, i]), i]
-                means.append(torch.mean(y_i))
-                std = torch.std(y_i, unbiased=False)  # population std, as lab's B.std
-                stds.append(std if std > 0 else torch.ones_like(std))
-            means, stds = torch.stack(means)[None, :], torch.stack(stds)[None, :]
+                y_i = y_np[~np.isnan(y_np[:, i]), i]
+                means[0, i] = np.mean(y_i)
+                std = np.std(y_i)  # population std, as lab's B.std
+                stds[0, i] = std if std > 0 else 1.0
+            means_t, stds_t = torch.from_numpy(means), torch.from_numpy(stds)
 
             def normalise_y(y_):
-                return (y_ - means.to(y_.device)) / stds.to(y_.device)
+                return (y_ - means_t.to(y_.device)) / stds_t.to(y_.device)
 
             def unnormalise_y(y_):
-                return y_ * stds.to(y_.device) + means.to(y_.device)
+                return y_ * stds_t.to(y_.device) + means_t.to(y_.device)
 
             self._normalise_y, self._unnormalise_y = normalise_y, unnormalise_y
-            self.y = normalise_y(self.y)
+            self.y = torch.from_numpy((y_np - means) / stds)
         self.is_conditioned = True
 
     def fit(self, x, y, w=None, greedy=False, fix=True, optimise_x_ind=False, **kw_args):

@@ -146,6 +146,14 @@ class OracleEngine:
             out["factors"].append([{k: (None if v is None else 2.0 * np.asarray(v)) for k, v in g.items()} for g in fgrads])
         return out
 
+    def kernel_grads_diag(self, ck, x, wdiag):
+        """sum_a wdiag[a] dk(x_a, x_a) for every kernel parameter (the symmetric routine returns half the sum)."""
+        half = ok.kernel_grads(ck.spec, _np(x), np.diag(_np(wdiag).reshape(-1)))
+        out = {"coef": [2.0 * c for c in half["coef"]], "factors": []}
+        for fgrads in half["factors"]:
+            out["factors"].append([{k: (None if v is None else 2.0 * np.asarray(v)) for k, v in g.items()} for g in fgrads])
+        return out
+
     # ---- factorisations ----------------------------------------------------------------------------
     def potrf_(self, A, nf=None):
         a = A.numpy()

@@ -4,6 +4,10 @@ import sys
 import numpy as np
 import pytest
 
+# the product asks for 8 hardware queues when its engine is created before the GPU is touched; the test session touches the GPU
+# earlier (torch.cuda.is_available() below), so the request is made here, as an application would export it
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

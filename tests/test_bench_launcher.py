@@ -1,0 +1,64 @@
+"""The entry point the round-end driver uses for N > 1: `python bench.py --gpus N` with no launcher around it must start the
+N ranks itself (one process per GPU, 127.0.0.1, a free port), and `python -m torch.distributed.run ... bench.py --gpus N` must
+keep working.  `--launch-check` stops after the process group has formed and answered one collective (gloo: no GPU needed),
+so the launcher is exercised here on the CPU; the timed path behind it needs the MI355X."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def _last_json(stdout):
+    lines = [line for line in stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, stdout  # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 4])
+def test_plain_invocation_starts_its_own_ranks(gpus):
+    out = subprocess.run([sys.executable, BENCH, "--gpus", str(gpus), "--launch-check"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = _last_json(out.stdout)
+    assert line["n_gpus"] == gpus and line["sum_of_ranks_plus_one"] == gpus * (gpus + 1) / 2
+
+
+def test_invocation_under_torchrun_as_the_driver_does_it():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--launch-check"]
+    out = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert _last_json(out.stdout)["n_gpus"] == 2
+
+
+def test_world_size_that_contradicts_the_flag_is_refused():
+    env = dict(_env(), WORLD_SIZE="3", RANK="0")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=3" in (out.stderr + out.stdout)
+
+
+def test_start_up_watchdog_ends_a_rank_whose_peers_never_arrive():
+    """Rank 0 of a 2-rank group whose second rank does not exist: the process must leave by itself (exit code 3 and an error
+    line instead of a hang)."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check", "--init-timeout", "5"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 3, (out.returncode, out.stderr[-1000:])
+    assert "did not form" in _last_json(out.stdout)["error"]

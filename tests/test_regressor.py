@@ -389,6 +389,8 @@ def test_paper_workload_stand_ins(engine, name, size):
     (dict(impute=False, replace=False, x_ind=np.linspace(0, 1, 7)), False),          # inducing inputs extended by posterior means
     (dict(impute=True, replace=True, x_ind=np.linspace(0, 1, 7)), True),             # examples/paper/air_temp.py
     (dict(impute=True, replace=True, x_ind=np.linspace(0, 1, 7), sparse_method="dtc", rq=True), True),
+    (dict(impute=True, replace=True, x_ind=np.linspace(0, 1, 7), sparse_method="fitc", rq=True), True),   # effective noise moves with the kernel
+    (dict(impute=False, replace=False, x_ind=np.linspace(0, 1, 7), sparse_method="fitc", per=True), False),
 ])
 def test_joint_gradient_is_exact_through_forwarded_posterior_means(engine, kw, missing):
     """fit(fix=False) differentiates the JOINT objective (reference gpar/regression.py:447-456): when imputation, `replace` or
@@ -422,6 +424,20 @@ def test_joint_gradient_is_exact_through_forwarded_posterior_means(engine, kw, m
             fd[i] += sgn * float(reg.logpdf(x, y)) / 2e-5
     reg.vs.set_vector(x0, names)
     np.testing.assert_allclose(grad, fd, rtol=5e-5, atol=2e-6 * np.max(np.abs(fd)))
+
+
+def test_fitc_trains(engine):
+    """`sparse_method="fitc"` through `fit` (round 2 raised from inside the first backward pass): the objective rises, with the
+    layers trained one at a time and jointly, and the inducing inputs can be trained along."""
+    rng = np.random.default_rng(3)
+    x = np.sort(rng.uniform(0, 1, 60))
+    y = np.stack([np.sin(7 * x), np.cos(5 * x) * x], axis=1) + 0.05 * rng.standard_normal((60, 2))
+    for fix, opt_z in [(True, False), (False, False), (True, True)]:
+        reg = GPARRegressor(x_ind=np.linspace(0, 1, 9), scale=0.3, linear=True, nonlinear=True, noise=0.1, sparse_method="fitc")
+        reg.condition(x, y)
+        before = float(reg.logpdf(x, y))
+        reg.fit(x, y, iters=8, fix=fix, optimise_x_ind=opt_z)
+        assert float(reg.logpdf(x, y)) > before + 1.0
 
 
 def test_inducing_inputs_can_be_optimised(engine):
