@@ -54,11 +54,18 @@ def layer_spec(hypers, m, pi, config):
     return {"terms": terms}, float(g(f"{pi}/noise"))
 
 
-def gpar_logpdf(x, y, w, hypers, config, impute=False, replace=False, eps=1e-12, x_ind=None):
+def gpar_logpdf(x, y, w, hypers, config, impute=False, replace=False, eps=1e-12, x_ind=None, sample_missing=False, seed=0):
     """Sum over layers of log N(y_i; 0, K_i([x, y_<i]) + noise_i / w_i) - with `x_ind`, of the VFE bounds - with the
     reference's missing-data rules (model.py:178-243, 279-322): rows kept per layer (`per_output`), observations filtered
     (`_obs`), the next input column = observed values, imputed / replaced by posterior means (`_update_inputs`), and the
-    inducing inputs extended by the posterior mean at the inducing inputs."""
+    inducing inputs extended by the posterior mean at the inducing inputs.
+
+    `sample_missing` (model.py:229-237): before the inputs are updated, the missing entries of the column are drawn from
+    the layer's posterior at their inputs, `mean + chol(cov + diag(noise / w) + eps I) z`; the normals z come from the
+    counter-based stream the product uses (oracle/philox.py: call k of a computation uses offset k), so that a product run
+    with the same seed draws the same imputations and the two values can be compared to rounding."""
+    from . import philox
+
     x = np.asarray(x, dtype=np.float64)
     x = x[:, None] if x.ndim == 1 else x
     y = np.asarray(y, dtype=np.float64)
@@ -70,9 +77,10 @@ def gpar_logpdf(x, y, w, hypers, config, impute=False, replace=False, eps=1e-12,
     m, p = x.shape[1], y.shape[1]
     available = ~np.isnan(y)
     total = 0.0
+    calls = 0
     for i in range(p):
         mask = available[:, i].copy()
-        if impute and i < p - 1:
+        if (impute or sample_missing) and i < p - 1:
             mask |= available[:, i + 1 :].any(axis=1)
         x, yi, wi = x[mask], y[mask, i], w[mask, i]
         y, w, available = y[mask], w[mask], available[mask]
@@ -90,12 +98,23 @@ def gpar_logpdf(x, y, w, hypers, config, impute=False, replace=False, eps=1e-12,
                 return gp_ref.posterior(spec, x[have], yi[have], noise / wi[have], points, eps=eps)[0]
 
             col = yi.copy()
-            if (impute and (~have).any()) or (replace and have.any()):
+            seen = have  # `available` as `_update_inputs` sees it: after the draws below, nothing is missing any more
+            if sample_missing and (~have).any():
+                if sparse:
+                    mean, cov = gp_ref.vfe_posterior(spec, x[have], yi[have], noise / wi[have], x_ind, x[~have], eps=eps)
+                else:
+                    mean, cov = gp_ref.posterior(spec, x[have], yi[have], noise / wi[have], x[~have], eps=eps)
+                S = cov + np.diag(noise / wi[~have] + eps)
+                z = philox.randn(seed, calls, int((~have).sum()), 1)[:, 0]
+                calls += 1
+                col[~have] = mean + np.linalg.cholesky(S) @ z
+                seen = np.ones_like(have)
+            if (impute and (~seen).any()) or (replace and seen.any()):
                 mean = estimate(x)
                 if impute:
-                    col[~have] = mean[~have]
+                    col[~seen] = mean[~seen]
                 if replace:
-                    col[have] = mean[have]
+                    col[seen] = mean[seen]
             if sparse:
                 x_ind = np.concatenate([x_ind, estimate(x_ind)[:, None]], axis=1)
             x = np.concatenate([x, col[:, None]], axis=1)

@@ -142,6 +142,62 @@ def test_logpdf_condition_predict_match_oracle(name):
     np.testing.assert_allclose(got[2], ref[2], rtol=1e-6, atol=atol)
 
 
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_logpdf_matches_the_independent_oracle_route(name, hip):
+    """HIP against `oracle.gpar_ref.gpar_logpdf` directly: that restatement shares NOTHING with the product - its own layer
+    kernels from the hyper-parameter dictionary, its own missing-data bookkeeping, slogdet + solve instead of a Cholesky of an
+    augmented matrix - whereas the test above runs the product's host algebra on both engines.  (Before round 3 this route
+    reached the HIP path only through the golden vectors, at n <= 30.)"""
+    from gpar_amd.regression import GPARRegressor
+    from oracle import gpar_ref
+
+    kw, n, m, p, missing = CONFIGS[name]
+    x, y = _problem(n, m, p, seed=len(name), missing=missing)
+    reg = GPARRegressor(**dict(kw, normalise_y=False))
+    got = float(reg.logpdf(x, y))
+    want = gpar_ref.gpar_logpdf(x, y, None, reg.get_variables(), reg.model_config, impute=reg.impute, replace=reg.replace,
+                                x_ind=kw.get("x_ind"))
+    tol = 1e-10 if kw.get("x_ind") is None else 1e-8  # inducing-point chains go through K_zz^-1 (jitter-conditioned)
+    assert abs(got - want) <= tol * abs(want), (got, want)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(impute=True),
+    dict(impute=False),
+    dict(impute=True, replace=True),
+    dict(impute=True, x_ind=np.random.default_rng(4).uniform(0, 1, (40, 2))),
+], ids=["impute", "no-impute", "replace", "inducing"])
+def test_sampled_imputations_match_the_oracle_on_a_shared_stream(kw):
+    """`logpdf(sample_missing=True)` (reference gpar/model.py:229-237) with holes that are NOT closed downwards, n = 300, p = 4:
+    the device draws its imputations from Philox stream (seed, call index), which the oracle restates bit for bit - same seed,
+    same imputations, so the VALUES agree to rounding: against the product's host algebra on the numpy engine and against the
+    independent restatement `oracle.gpar_ref.gpar_logpdf(sample_missing=True)`.  A different seed gives a different value."""
+    from gpar_amd.regression import GPARRegressor
+    from oracle import gpar_ref
+
+    x, y = _problem(300, 2, 4, seed=31, missing=0.2)
+    y[0] = 0.25  # one complete row
+    assert np.isnan(y[:, 0]).any() and (np.isnan(y[:, 0]) & ~np.isnan(y[:, 2])).any()  # not closed downwards
+
+    def run():
+        reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False, **kw)
+        return float(reg.logpdf(x, y, sample_missing=True)), reg.get_variables(), reg.model_config
+
+    got, hypers, config = _on("hip", run, seed=41)
+    ref, _, _ = _on("oracle", run, seed=41)
+    other, _, _ = _on("hip", run, seed=42)
+    independent = gpar_ref.gpar_logpdf(x, y, None, hypers, config, impute=kw.get("impute", True), replace=kw.get("replace", False),
+                                       x_ind=kw.get("x_ind"), sample_missing=True, seed=41)
+    tol = 1e-8 if kw.get("x_ind") is None else 1e-7
+    assert abs(got - ref) <= tol * abs(ref), (got, ref)
+    assert abs(got - independent) <= tol * abs(independent), (got, independent)
+    if kw.get("replace"):
+        # impute AND replace: `_update_inputs` overwrites the whole column by posterior means (gpar/model.py:305-306), the draws included
+        assert other == got
+    else:
+        assert abs(other - got) > 1e-6 * abs(got)
+
+
 def test_layer_pipeline_is_bit_identical_to_serial_evaluation(monkeypatch):
     """Independent layers run on alternating streams (HipEngine.pipeline); values and their summation order are
     those of the serial loop, so the result must not change by a single bit - at a size where the look-ahead path
@@ -356,6 +412,37 @@ def test_gradient_matches_oracle(hip):
 
     ref, got = _on("oracle", grads), _on("hip", grads)
     np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(impute=True, replace=True, x_ind=np.linspace(0, 1, 24)),
+    dict(impute=True, replace=True),
+    dict(impute=True, replace=True, x_ind=np.linspace(0, 1, 24), sparse_method="fitc"),
+], ids=["impute+replace+inducing", "impute+replace", "impute+replace+fitc"])
+def test_joint_gradient_matches_oracle(hip, kw):
+    """The JOINT objective of fit(fix=False) (reference gpar/regression.py:447-456) in regimes where posterior means are fed
+    forward - imputed AND replaced columns, inducing inputs extended layer by layer: d / d(every hyper-parameter) through
+    `_PosteriorMean` and the input gradients of `_LogMarginal`, HIP kernels against the numpy engine."""
+    from gpar_amd.regression import GPARRegressor
+
+    rng = np.random.default_rng(19)
+    n, p = 180, 3
+    x = np.sort(rng.uniform(0, 1, n))
+    y = np.stack([np.sin(5 * x), np.cos(4 * x) + 0.4 * np.sin(5 * x) ** 2, x * np.sin(5 * x)], axis=1) + 0.05 * rng.standard_normal((n, p))
+    y[rng.random((n, p)) < 0.2] = np.nan
+    y[0] = [0.1, 0.9, 0.0]
+
+    def grads():
+        reg = GPARRegressor(scale=0.3, linear=True, linear_scale=3.0, nonlinear=True, rq=True, noise=0.05, normalise_y=False, **kw)
+        with torch.no_grad():
+            reg.logpdf(x, y)
+        reg.vs.requires_grad(True)
+        reg.logpdf(torch.tensor(x), torch.tensor(y)).backward()
+        return np.concatenate([(v.grad if v.grad is not None else torch.zeros_like(v)).numpy().reshape(-1) for v in reg.vs.get_vars()])
+
+    ref, got = _on("oracle", grads), _on("hip", grads)
+    assert np.max(np.abs(ref)) > 1e-2
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7 * np.max(np.abs(ref)))
 
 
 def test_gradient_matches_oracle_at_a_size_that_takes_the_recursive_inverse(hip):

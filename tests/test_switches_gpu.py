@@ -1,0 +1,125 @@
+"""Every environment switch DESIGN.md section 3.9 documents is part of the behaviour surface: each one, set to a non-default
+value, must leave a log marginal likelihood unchanged to 1e-11 (they select launch shapes, fusion and concurrency, never
+arithmetic that matters).  One n = 1300 problem (ragged: not a multiple of any tile size) plus one n = 5200 factorisation for
+the switches that only act on large matrices.  Switches read at call time are flipped in-process; the two that the library
+caches on first use are exercised in a fresh process."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from .conftest import make_engine
+from .test_parity_gpu import _problem
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CALL_TIME = [
+    ("GPAR_POTRF_NBO", "256"),
+    ("GPAR_PANEL_V", "1"),
+    ("GPAR_POTRF_FUSED", "0"),
+    ("GPAR_POTRF_LOOKAHEAD", "0"),
+    ("GPAR_POTRF_LOOKAHEAD", "1"),
+    ("GPAR_POTRF_GROUP", "2"),
+    ("GPAR_POTRF_GROUP", "1"),
+    ("GPAR_POTRF_PAIR_ROWS", "1024"),
+    ("GPAR_POTRF_PAIR_FIRST", "1"),
+    ("GPAR_INVERSE_RECURSIVE", "0"),
+    ("GPAR_TRSM_FUSED", "0"),
+    ("GPAR_TRSV", "0"),
+    ("GPAR_TRSM_GROUP", "2"),
+    ("GPAR_TRSM_PAIR_COLS", "1024"),
+    ("GPAR_LAYER_PIPELINE", "0"),
+    ("GPAR_LAYER_PIPELINE", "3"),
+    ("GPAR_LAYER_BATCH_ROWS", "0"),
+    ("GPAR_LAYER_BATCH_BYTES", str(8 * 1301 * 1317 * 2)),
+    ("GPAR_POTRF_BATCH_LOOKAHEAD", "0"),
+    ("GPAR_POTRF_PREZERO", "0"),
+    ("GPAR_FIT_THREADS", "1"),
+]
+CACHED = [("GPAR_GEMM_HALF_TILES", "0"), ("GPAR_GEMM_HALF_TILES", "100000")]
+
+
+def _evaluate():
+    """(logpdf of a 4-layer model at n = 1300, posterior mean checksum, gradient checksum, logdet at n = 5200)."""
+    import torch
+
+    from gpar_amd import hip as H
+    from gpar_amd.engine import get_engine
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(1300, 2, 4, seed=77)
+    reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False)
+    value = float(reg.logpdf(x, y))
+    reg.condition(x, y)
+    xs = np.random.default_rng(3).uniform(0, 1, (700, 2))
+    get_engine().seed(9)
+    mean = float(np.sum(reg.predict(xs, num_samples=3, latent=True)))
+    reg.vs.requires_grad(True)
+    reg.logpdf(torch.tensor(x), torch.tensor(y)).backward()
+    grad = float(sum(v.grad.abs().sum() for v in reg.vs.get_vars()))
+    reg.vs.requires_grad(False)
+    dev = get_engine().device
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand(5200, 3, generator=g, dtype=torch.float64).to(dev)
+    A = H.alloc_matrix(5200, 5200, dev)
+    A.copy_(torch.exp(-0.5 * torch.cdist(pts, pts) ** 2 / 0.25))
+    A.diagonal().add_(0.1)
+    logdet, info = H.potrf_(A)
+    assert int(info.item()) == 0
+    return value, mean, grad, float(logdet)
+
+
+def _close(a, b):
+    for u, v, tol in zip(a, b, (1e-11, 1e-9, 1e-8, 1e-11)):
+        assert abs(u - v) <= tol * abs(v), (a, b)
+
+
+@pytest.fixture(scope="module")
+def baseline():
+    from gpar_amd.engine import set_engine
+
+    eng = make_engine("hip")
+    previous = set_engine(eng)
+    try:
+        yield _evaluate()
+    finally:
+        set_engine(previous)
+
+
+@pytest.mark.parametrize("name,value", CALL_TIME, ids=[f"{k}={v}" for k, v in CALL_TIME])
+def test_call_time_switch_leaves_the_results_alone(baseline, monkeypatch, name, value):
+    from gpar_amd.engine import set_engine
+
+    monkeypatch.setenv(name, value)
+    eng = make_engine("hip")
+    previous = set_engine(eng)
+    try:
+        _close(_evaluate(), baseline)
+    finally:
+        set_engine(previous)
+
+
+@pytest.mark.parametrize("name,value", CACHED, ids=[f"{k}={v}" for k, v in CACHED])
+def test_cached_switch_leaves_the_results_alone(baseline, name, value):
+    code = ("import json, sys; sys.path.insert(0, %r); from tests.test_switches_gpu import _evaluate; from tests.conftest import make_engine; "
+            "from gpar_amd.engine import set_engine; set_engine(make_engine('hip')); print(json.dumps(_evaluate()))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{name: value}), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    _close(json.loads(out.stdout.strip().splitlines()[-1]), baseline)
+
+
+def test_every_documented_switch_is_exercised():
+    """The switch table of DESIGN.md and this file list the same variables (experiment knobs of section 7 excepted)."""
+    import re
+
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    table = text[text.index("### 3.9 Switches"):text.index("## 4. Oracle and parity")]
+    rows = [line for line in table.splitlines() if line.startswith("| `") and "experiment knobs" not in line]
+    documented = set(re.findall(r"`(GPAR_[A-Z_]+)`", "\n".join(row.split("|")[1] for row in rows)))
+    exercised = {k for k, _ in CALL_TIME + CACHED}
+    assert documented <= exercised, documented - exercised
