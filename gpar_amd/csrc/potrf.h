@@ -375,7 +375,17 @@ static int trsm_block_back_fused2(const double* L, int n, int ldl, double* B, in
 
 static inline int potrf_panel_any(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed,
                                   int batch = 1, long long batch_a = 0) {
-    if (env_int("GPAR_PANEL_V", 2) >= 2) return potrf_panel_fused2(A, N, lda, k0, W, logdet, info, stream, prezeroed, batch, batch_a);
+    if (env_int("GPAR_PANEL_V", 2) >= 2) {
+        // Experiment knob (default off): with at least this many rows left the panel is split into a chain-only launch (the W / 64
+        // team workgroups factor the diagonal block) and the fused triangular-solve block kernel for the rows below.
+        const int split_rows = batch == 1 ? env_int("GPAR_POTRF_PANEL_SPLIT_ROWS", 1 << 30) : (1 << 30);
+        if (N - k0 >= split_rows && N - k0 > W) {
+            int rc = potrf_panel_fused2(A, k0 + W, lda, k0, W, logdet, info, stream, prezeroed, 1, 0);
+            if (rc) return rc;
+            return trsm_block_fused2(A + (size_t)k0 * lda + k0, W, lda, A + (size_t)(k0 + W) * lda + k0, N - k0 - W, lda, 0, W / 64, 0, stream);
+        }
+        return potrf_panel_fused2(A, N, lda, k0, W, logdet, info, stream, prezeroed, batch, batch_a);
+    }
     for (int b = 0; b < batch; ++b) {   // (the first-generation kernel takes one matrix per launch)
         const int rc = potrf_panel_fused(A + (size_t)b * batch_a, N, lda, k0, W, logdet ? logdet + b : nullptr, info ? info + b : nullptr, stream, prezeroed);
         if (rc) return rc;
@@ -497,6 +507,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     hipStream_t side = (pol.lookahead && nf > nbo && la_init()) ? la_side(stream) : nullptr;
     const bool la = side != nullptr;
     hipEvent_t trail_done = nullptr;   // completion of the side-stream update issued in the previous step
+    hipEvent_t mid_done = nullptr;     // completion of the side-stream update of the current group's 2nd .. last panels' columns
     // Early in the factorisation two panels are factored back to back (the second after a narrow update of its own
     // columns by the first) and the rest of the matrix then receives ONE rank-2*nbo update: the trailing update reads and
     // writes every remaining element once per 1024 columns instead of once per 512, and a K = 1024 SYRK runs ~8 % faster
@@ -527,6 +538,8 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             for (int i = 0; i < G && !rc; ++i) {
                 const int ks = k0 + i * nbo;
                 if (i > 0) {   // this panel's columns: one update by the i panels of the group factored so far
+                    // (they must have received the previous step's update first: it runs at the head of the side stream)
+                    if (mid_done) { GPAR_HIP_TRY(hipStreamWaitEvent(stream, mid_done, 0)); mid_done = nullptr; }
                     bool pb;
                     prof_begin(stream, pb);
                     rc = potrf_gemm_update(c, k0, ks, ks + nbo, stream, 1);
@@ -561,16 +574,41 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             if (rc) return rc;
             continue;
         }
-        // (1) next panel's columns, on the caller's stream; they were last written by the previous side update
+        // (1) next panel's columns, on the caller's stream; they were last written by the previous side update.
+        // Two round-3 experiment knobs, both OFF by default because neither paid (profiles/r03_exp_potrf_lookahead.txt; same bits):
+        //   GPAR_POTRF_LA_SPLIT=1        when the next step is a GROUP of panels, only its first panel's columns are updated ahead of
+        //                                that panel; the other panels' columns go to the head of the side stream and the in-group
+        //                                update waits for them there (n = 16384: 25.94 -> 26.12 ms, 12288: 12.74 -> 12.67, 8192: 5.29 -> 5.21)
+        //   GPAR_POTRF_REST_AFTER_LA=r   with fewer than r rows left the big update is released only after the look-ahead update
+        //                                has finished, so that the next panel kernel is dispatched together with the big update's
+        //                                first round instead of queueing behind it (r = 8192 / 10240 / all: 26.36 / 26.85 / 27.52 ms):
+        //                                the chip is work-conserving as it is - what the panel kernel gains the big update loses.
         if (trail_done) GPAR_HIP_TRY(hipStreamWaitEvent(stream, trail_done, 0));
+        const bool next_grouped = next_end - kend > nbo && groupable(kend);
+        const int la_end = (next_grouped && env_int("GPAR_POTRF_LA_SPLIT", 0)) ? kend + nbo : next_end;
+        const bool rest_after_la = batch == 1 && (N - kend) < env_int("GPAR_POTRF_REST_AFTER_LA", 0);
         hipEvent_t panel_done = la_event();
-        GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
+        if (!rest_after_la) GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
         prof_begin(stream, pa);
-        rc = potrf_gemm_update(c, k0, kend, next_end, stream, 1);   // same kernel symbol: it is part of the trailing update
-        prof_end(stream, pa, N - kend, next_end - kend, (kend - k0) * batch);
+        rc = potrf_gemm_update(c, k0, kend, la_end, stream, 1);   // same kernel symbol: it is part of the trailing update
+        prof_end(stream, pa, N - kend, la_end - kend, (kend - k0) * batch);
         if (rc) return rc;
-        // (2) everything to the right of the next panel, on the side stream
+        if (rest_after_la) GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
+        // (2) everything to the right of the next panel, on the side stream: first the rest of the next group's columns ...
         GPAR_HIP_TRY(hipStreamWaitEvent(side, panel_done, 0));
+        mid_done = nullptr;
+        if (la_end < next_end) {
+            const int rows = N - la_end, cols = next_end - la_end;
+            const double* P = A + (size_t)la_end * lda + k0;
+            prof_begin(side, pa);
+            rc = gemm_launch(0, 1, rows, cols, kend - k0, -1.0, P, lda, P, lda, 1.0, A + (size_t)la_end * lda + la_end, lda,
+                             GPAR_GEMM_C_LOWER, side, 1, batch, batch_a, batch_a, batch_a);
+            prof_end(side, pa, rows, cols, (kend - k0) * batch);
+            if (rc) return rc;
+            mid_done = la_event();
+            GPAR_HIP_TRY(hipEventRecord(mid_done, side));
+        }
+        // ... then everything beyond the next step's columns
         {
             const int rows = N - next_end, cols = N - next_end;
             if (rows > 0) {
