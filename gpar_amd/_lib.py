@@ -24,7 +24,7 @@ POTRF_UNFUSED = 2
 WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE, WS_INPUT_GRAD = 1, 2, 3, 4, 5
 GRAD_NACC = GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 LIB_NAME = "libgpar_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -70,6 +70,8 @@ SIGNATURES = {
     "gpar_abi_version": (_c_int, []),
     "gpar_sizeof_fspec": (ctypes.c_size_t, []),
     "gpar_sizeof_kspec": (ctypes.c_size_t, []),
+    "gpar_jit_compile_check": (_c_int, [_c_int, ctypes.POINTER(KSpec), _c_int, ctypes.c_char_p, ctypes.c_char_p, _c_int]),
+    "gpar_jit_stats": (_c_int, [ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "gpar_featurize": (_c_int, [ctypes.POINTER(FSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "gpar_gram": (
         _c_int,

@@ -62,6 +62,7 @@ struct GemmArgs {
     int ksplit;          // > 0: blockIdx.y selects the K range [y * ksplit, (y + 1) * ksplit) and the output slab y
     long long part_stride;   // elements between consecutive partial slabs of C (split-K)
     long long batch_a, batch_b, batch_c;   // blockIdx.z selects problem z of a batch: operands advance by these many elements
+    int nfull, ntail;    // MIXED launches (see gemm_f64_kernel): blocks [0, nfull) take whole tiles, the 2 * ntail blocks behind them half tiles
     long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memrealtime stamps + hardware ids, normally null
     long long* stage_stamps;   // dev aid (tools/time_gemm_stages.hip, compiled with GPAR_GEMM_STAGE_STAMPS): 3 stamps per K stage
 };
@@ -347,16 +348,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, double* sme
     }
 }
 
-// TA: A stored k x m (op(A) = A^T);  TB: B stored n x k (op(B) = B^T).
-// ROLE only gives the trailing SYRK of gpar_potrf (ROLE = 1) its own kernel symbol, so that profilers report the
-// dominant kernel separately from the small panel-internal updates that share the code.
-// BM = 64: the workgroup computes one 64-row half of a 128 x 128 tile (blockIdx.x = 2 * tile + half; wave tile 32 x 64).
-// For launches with fewer tiles than compute units: a lone workgroup on a CU has one wave per SIMD and nothing to cover
-// its barrier / LDS latencies with (58 % MFMA issue); two half-tile workgroups per CU cover each other's.
-template <bool TA, bool TB, int ROLE, int BM = 128>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
+// `blk` of `nblk`: this workgroup's position among the launch's blocks OF ITS TILE SHAPE (whole tiles, or half tiles: two
+// consecutive positions per tile); `tile0`: index of the first tile those blocks cover.
+template <bool TA, bool TB, int BM>
+__device__ __forceinline__ void gemm_tile_body(GemmArgs& p, double* smem, const int blk, const int nblk, const int tile0) {
     constexpr int MI = BM / 32;   // 16-row blocks per wave
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr bool A_KC = !TA;
     constexpr bool B_KC = TB;
 
@@ -372,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         // K grows with the tile COLUMN (upper-triangular op(B)): the tiles of one column share their B panel and their K
         // length.  XCD x (the dispatcher puts block b on XCD b % 8) works through whole columns x, x + 8, ... of the
         // longest-first order: equal work per XCD, the shared panel stays in that XCD's L2, short tiles end the launch.
-        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+        const int b = blk, xcd = b & 7, j = b >> 3;
         tn = p.tiles_n - 1 - ((j / p.tiles_m) * 8 + xcd);
         tm = j % p.tiles_m;
     } else if (p.flags & (GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_A_LOWER | GPAR_GEMM_K_TO_COL)) {
@@ -380,11 +376,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         // hand one XCD all the long tiles (the triangular-aware inverse ran at 28 TF that way); deal them round-robin.  (K_FROM_ROW
         // without C_LOWER, grouped by rows like the columns above: 8.6 -> 9.2 ms at 8192^3 / 2 - the row-major enumeration
         // already starts with the longest tiles.)
-        idx = blockIdx.x / (GEMM_BM / BM);
+        idx = tile0 + blk / (GEMM_BM / BM);
     } else {
-        const int nb = gridDim.x / (GEMM_BM / BM), b = blockIdx.x / (GEMM_BM / BM);
+        const int nb = nblk / (GEMM_BM / BM), b = blk / (GEMM_BM / BM);
         const int xcd = b & 7, q = nb >> 3, r = nb & 7;
-        idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        idx = tile0 + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     if (tm >= 0) {
         // (mapped above)
@@ -405,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
         tm = idx / p.tiles_n;
         tn = idx % p.tiles_n;
     }
-    const int m0 = tm * GEMM_BM + (BM == GEMM_BM ? 0 : (int)(blockIdx.x & 1) * BM), n0 = tn * GEMM_BN;
+    const int m0 = tm * GEMM_BM + (BM == GEMM_BM ? 0 : (int)(blk & 1) * BM), n0 = tn * GEMM_BN;
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w >> 1, wn = w & 1;
@@ -517,6 +513,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     }
 }
 
+
+// TA: A stored k x m (op(A) = A^T);  TB: B stored n x k (op(B) = B^T).
+// ROLE only gives the trailing SYRK of gpar_potrf (ROLE = 1) its own kernel symbol, so that profilers report the
+// dominant kernel separately from the small panel-internal updates that share the code.
+// BM = 64: the workgroup computes one 64-row half of a 128 x 128 tile (blockIdx.x = 2 * tile + half; wave tile 32 x 64).
+// For launches with fewer tiles than compute units: a lone workgroup on a CU has one wave per SIMD and nothing to cover
+// its barrier / LDS latencies with (58 % MFMA issue); two half-tile workgroups per CU cover each other's.
+// MIXED (whole-tile instantiations of ROLE 1): the chip holds 512 workgroups of this kernel; a launch of T tiles runs T / 512
+// rounds of them, and a last round that is less than half full leaves most compute units idle for a whole tile time (n = 16384:
+// 2145 tiles, 4.19 rounds, 60.8 TFLOP/s against 65-66 for launches that end on a full round).  With p.ntail > 0 the tiles of that
+// last round are computed as half tiles by twice as many workgroups: blocks [0, nfull) take whole tiles, blocks nfull + 2 j,
+// nfull + 2 j + 1 the halves of tile nfull + j.  Same arithmetic per element: a tile's rows do not interact.
+template <bool TA, bool TB, int ROLE, int BM = 128>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (ROLE == 1 && BM == GEMM_BM && p.ntail > 0 && (int)blockIdx.x >= p.nfull)
+        gemm_tile_body<TA, TB, 64>(p, smem, (int)blockIdx.x - p.nfull, 2 * p.ntail, p.nfull);
+    else
+        gemm_tile_body<TA, TB, BM>(p, smem, (int)blockIdx.x, ROLE == 1 && BM == GEMM_BM && p.ntail > 0 ? p.nfull : (int)gridDim.x, 0);
+}
+
 inline int gemm_num_tiles(int tiles_m, int tiles_n, int flags) {
     if (flags & GPAR_GEMM_C_LOWER) {
         const int tn = tiles_n < tiles_m ? tiles_n : tiles_m;
@@ -562,7 +579,16 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     static int lds_extra = -1;
     if (lds_extra < 0) { const char* e = getenv("GPAR_GEMM_LDS_EXTRA"); lds_extra = e ? atoi(e) : 0; }
     const int GEMM_LDS_REQ = GEMM_LDS_BYTES + lds_extra;   // experiment knob: > 6.2 KB extra forces one workgroup per CU
-    dim3 grid(half ? 2 * ntiles : ntiles, 1, batch), block(256);
+    // whole tiles, except for a last round that would be at most half full (MIXED, see the kernel): the trailing update alone
+    p.nfull = ntiles; p.ntail = 0;
+    static int mixed_tail = -1;
+    if (mixed_tail < 0) { const char* e = getenv("GPAR_GEMM_MIXED_TAIL"); mixed_tail = e ? atoi(e) : 1; }
+    if (mixed_tail && !half && role == 1 && !ta && tb && batch == 1 && k >= 64 && ntiles > 512 && ntiles % 512 != 0 && ntiles % 512 <= 256 &&
+        !(flags & (GPAR_GEMM_A_LOWER | GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_K_TO_COL))) {
+        p.ntail = ntiles % 512;
+        p.nfull = ntiles - p.ntail;
+    }
+    dim3 grid(half ? 2 * ntiles : p.nfull + 2 * p.ntail, 1, batch), block(256);
     if (half && role == 1) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1, 64>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (half) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0, 64>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (role == 1 && !ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, GEMM_LDS_REQ, stream, p);
@@ -610,6 +636,7 @@ static int gemm_splitk_launch(int ta, int tb, int m, int n, int k, double alpha,
     p.stamps = nullptr; p.stage_stamps = nullptr;
     const int len = gpar_ceil_div(gpar_ceil_div(k, splits), GEMM_BK) * GEMM_BK;
     p.ksplit = len;
+    p.nfull = 0; p.ntail = 0;
     p.part_stride = (long long)m * n;
     const int nsl = gpar_ceil_div(k, len);
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);

@@ -1,12 +1,14 @@
 // libgpar_hip.so — C ABI (include/gpar_hip.h) over the gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC gpar_hip.hip -o ../libgpar_hip.so
 #include <mutex>
+#include <string.h>
 #include "common.h"
 #include "gemm_f64.h"
 #include "potrf.h"
 #include "panel.h"
 #include "panel2.h"
 #include "gram.h"
+#include "gram_jit.h"
 #include "blas1.h"
 
 namespace gpar {
@@ -194,10 +196,13 @@ static int gram_launch(const gpar_kspec_t* ks, const double* z1, int n1, int ldz
     if (n1 <= 0 || n2 <= 0) return 0;
     const int sym = (z1 == z2 && n1 == n2) ? 1 : 0;
     if ((flags & GPAR_GRAM_LOWER) && !sym) return GPAR_ARG_ERROR(5);
-    const size_t lds = (size_t)2 * (dz > 0 ? dz : 1) * GRAM_LD * sizeof(double);
+    const size_t lds = ((size_t)2 * (dz > 0 ? dz : 1) * GRAM_LD + GRAM_TAB_DOUBLES) * sizeof(double);
     const int nt1 = gpar_ceil_div(n1, GRAM_T), nt2 = gpar_ceil_div(n2, GRAM_T);
     dim3 grid(nt2, nt1, batch);
     if (flags & GPAR_GRAM_LOWER) grid = dim3((unsigned)((long long)nt1 * (nt1 + 1) / 2), 1, batch);
+    // per-specification kernel (gram_jit.h) for problems large enough to repay its compilation; the interpreter otherwise
+    if (gram_jit_launch(ks, z1, n1, ldz1, z2, n2, ldz2, dz, K, ldk, flags, diag_add, diag_const, row_scale, sym, grid, stream, batch_z, batch_k))
+        return 0;
     hipLaunchKernelGGL(gram_kernel, grid, dim3(256), lds, stream, *ks, z1, n1, ldz1, z2, n2, ldz2, dz, K, ldk, flags, diag_add,
                        diag_const, row_scale, sym, batch_z, batch_k);
     GPAR_LAUNCH_CHECK();
@@ -232,6 +237,36 @@ extern "C" {
 int gpar_abi_version(void) { return GPAR_ABI_VERSION; }
 size_t gpar_sizeof_fspec(void) { return sizeof(gpar_fspec_t); }
 size_t gpar_sizeof_kspec(void) { return sizeof(gpar_kspec_t); }
+
+// ---- run-time specialisation (jit.h) ----------------------------------------------------------------------------------
+int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char* arch, char* log, int log_len) {
+    GPAR_API_GUARD_NOSTREAM;
+    if (!ks || !arch || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS || dz < 0 ||
+        dz > GPAR_MAX_DIMS)
+        return GPAR_ARG_ERROR(1);
+    std::string source, entry;
+    if (kind == JIT_GRAM) {
+        source = gram_jit_source(*ks, dz, gram_jit_strip(1 << 20, dz));   // the shape a large problem gets
+        entry = "gram_jit";
+    }
+    else return GPAR_ARG_ERROR(2);
+    std::string code, text;
+    const bool ok = jit_compile(source, entry.c_str(), arch, code, text);
+    if (log && log_len > 0) {
+        const size_t n = text.size() < (size_t)(log_len - 1) ? text.size() : (size_t)(log_len - 1);
+        memcpy(log, text.data(), n);
+        log[n] = '\0';
+    }
+    return ok ? (int)code.size() : -1;
+}
+
+int gpar_jit_stats(int* compiled, int* failures, int* cached) {
+    GPAR_API_GUARD_NOSTREAM;
+    if (compiled) *compiled = g_jit.compiled;
+    if (failures) *failures = g_jit.failures;
+    if (cached) *cached = (int)g_jit.cache.size();
+    return 0;
+}
 
 int gpar_featurize(const gpar_fspec_t* fs, const double* x, int n, int ldx, double* z, int ldz, void* stream) {
     GPAR_API_GUARD;

@@ -13,8 +13,10 @@
 
 namespace gpar {
 
-constexpr int GRAM_T = 64;
-constexpr int GRAM_LD = 68;
+// shared with the generated kernels (gram_jit.h), one text for both: typedefs, GRAM_T / GRAM_LD, gram_accum*, gram_exp8, gram_rq8
+#define GPAR_DEVICE_CODE(...) __VA_ARGS__
+#include "gram_math.inc"
+#undef GPAR_DEVICE_CODE
 
 __global__ __launch_bounds__(256) void featurize_kernel(gpar_fspec_t fs, const double* __restrict__ x, int n, int ldx,
                                                         double* __restrict__ z, int ldz) {
@@ -34,78 +36,6 @@ __device__ __forceinline__ double gram_nonlin(int type, double s, double alpha) 
     if (type == GPAR_K_EQ) return exp(-0.5 * s);
     if (type == GPAR_K_RQ) return exp(-alpha * log1p(s / (2.0 * alpha)));
     return s;
-}
-
-// Squared distances / inner products of a 4 x 2 micro-tile over ND feature dims starting at d0, fully unrolled: all 3 ND
-// LDS reads are issued before the first fused multiply-add (a rolled loop over a run-time dim count waits out the LDS
-// latency and pays the loop overhead once per dim: the kernel ran at 46 % of the vector-ALU issue rate).
-template <int ND, bool LINEAR>
-__device__ __forceinline__ void gram_accum(const double* __restrict__ Za, const double* __restrict__ Zb, int d0, int ty, int cb,
-                                           double (&s)[8]) {
-    typedef double g_d2 __attribute__((ext_vector_type(2)));
-    typedef double g_d4 __attribute__((ext_vector_type(4)));
-    g_d4 za[ND];
-    g_d2 zb[ND];
-#pragma unroll
-    for (int q = 0; q < ND; ++q) {
-        za[q] = *reinterpret_cast<const g_d4*>(&Za[(d0 + q) * GRAM_LD + 4 * ty]);
-        zb[q] = *reinterpret_cast<const g_d2*>(&Zb[(d0 + q) * GRAM_LD + cb]);
-    }
-#pragma unroll
-    for (int q = 0; q < ND; ++q) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (LINEAR) {
-                s[2 * i] = fma(za[q][i], zb[q][0], s[2 * i]);
-                s[2 * i + 1] = fma(za[q][i], zb[q][1], s[2 * i + 1]);
-            } else {
-                const double d0_ = za[q][i] - zb[q][0], d1_ = za[q][i] - zb[q][1];
-                s[2 * i] = fma(d0_, d0_, s[2 * i]);
-                s[2 * i + 1] = fma(d1_, d1_, s[2 * i + 1]);
-            }
-        }
-    }
-}
-
-template <bool LINEAR>
-__device__ __forceinline__ void gram_accum_dims(const double* __restrict__ Za, const double* __restrict__ Zb, int off, int nd, int ty,
-                                                int cb, double (&s)[8]) {
-    int d = off;
-    // four dims at a time: 12 doubles of operands per dim - eight at a time needed 220 registers (two waves per SIMD)
-    for (; d + 4 <= off + nd; d += 4) gram_accum<4, LINEAR>(Za, Zb, d, ty, cb, s);
-    switch (off + nd - d) {   // wave-uniform
-        case 3: gram_accum<3, LINEAR>(Za, Zb, d, ty, cb, s); break;
-        case 2: gram_accum<2, LINEAR>(Za, Zb, d, ty, cb, s); break;
-        case 1: gram_accum<1, LINEAR>(Za, Zb, d, ty, cb, s); break;
-        default: break;
-    }
-}
-
-// exp(x) for eight independent arguments x <= 0 (exponents of EQ / RQ factors), written so that the eight polynomial
-// chains interleave (the library call compiles to one serial 11-deep Horner chain per call, and with the type dispatch around
-// it the compiler emitted the eight calls of a micro-tile one after the other: latency-bound instead of issue-bound).
-// x = k ln2 + r, |r| <= ln2 / 2; exp(r) by its Taylor polynomial of degree 13 (remainder 4e-18 relative); 2^k by v_ldexp_f64,
-// which also flushes to zero / denormals below -708.  Agrees with the correctly rounded value to 1 ulp.
-__device__ __forceinline__ void gram_exp8(double (&x)[8]) {
-    constexpr double L2E = 1.4426950408889634074, LN2H = 6.93147180369123816490e-01, LN2L = 1.90821492927058770002e-10;
-    double k[8], r[8], p[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) k[i] = __builtin_rint(x[i] * L2E);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = fma(k[i], -LN2L, fma(k[i], -LN2H, x[i]));
-    constexpr double c[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
-                              1.0 / 5040.0,       1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0,      0.5};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) p[i] = c[0];
-#pragma unroll
-    for (int j = 1; j < 12; ++j) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) p[i] = fma(p[i], r[i], c[j]);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) p[i] = fma(fma(p[i], r[i], 1.0), r[i], 1.0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_ldexp(p[i], (int)k[i]);
 }
 
 // Two passes of a 4 x 2 micro-tile per thread.  Per product term the exponents of its EQ / RQ factors are SUMMED and
@@ -131,10 +61,12 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
         while (bm * (bm + 1) / 2 > tile) --bm;
         bn = tile - bm * (bm + 1) / 2;
     }
-    double* Za = gsm;
-    double* Zb = gsm + (size_t)dz * GRAM_LD;
+    const double* tab = gsm;                         // exponential / logarithm tables (gram_math.inc), then the two feature panels
+    double* Za = gsm + GRAM_TAB_DOUBLES;
+    double* Zb = Za + (size_t)dz * GRAM_LD;
     const int t = threadIdx.x;
     const int row0 = bm * GRAM_T, col0 = bn * GRAM_T;
+    gram_load_tables(gsm, t);
     for (int idx = t; idx < GRAM_T * dz; idx += 256) {
         const int r = idx / dz, d = idx - r * dz;
         Za[d * GRAM_LD + r] = (row0 + r < n1) ? z1[(size_t)(row0 + r) * ldz1 + d] : 0.0;
@@ -143,8 +75,6 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
     __syncthreads();
     const int tx = t & 15, ty = t >> 4;
     const bool vec = ((ldk & 1) == 0) && ((((uintptr_t)K) & 15u) == 0);
-    typedef double g_d2 __attribute__((ext_vector_type(2)));
-    typedef double g_d4 __attribute__((ext_vector_type(4)));
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         const int cb = 32 * h + 2 * tx;   // first of this thread's two columns within the tile
@@ -173,15 +103,13 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
 #pragma unroll
                         for (int e = 0; e < 8; ++e) expo[e] = fma(-0.5, s[e], expo[e]);
                     } else {   // RQ: (1 + s / 2 alpha)^-alpha = exp(-alpha log1p(s / 2 alpha))
-                        const double alpha = ks.factor[f].alpha, h2a = 0.5 / alpha;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) expo[e] = fma(-alpha, log1p(s[e] * h2a), expo[e]);
+                        gram_rq8(s, ks.factor[f].alpha, expo, tab);
                     }
                 }
                 ++f;
             }
             if (any_exp) {
-                gram_exp8(expo);
+                gram_exp8(expo, tab);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) total[e] = fma(lin[e], expo[e], total[e]);
             } else {

@@ -1,0 +1,328 @@
+// Source generator of the per-specification Gram kernel (see jit.h).  Same tiling, arguments and arithmetic as gram_kernel
+// (gram.h) - 64 x 64 outputs per 256-thread workgroup, two passes of a 4 x 2 micro-tile per thread, feature panels staged
+// transposed in LDS - with the term list unrolled into straight-line code: no loops over terms / factors, no type dispatch,
+// dim counts as template arguments of the shared accumulation helpers.
+#pragma once
+#include <string>
+
+#include "common.h"
+#include "jit.h"
+
+namespace gpar {
+
+#define GPAR_DEVICE_CODE(...) #__VA_ARGS__
+static const char* const GRAM_MATH_SRC =
+#include "gram_math.inc"
+    ;
+#undef GPAR_DEVICE_CODE
+
+// Mirror of the two ABI structs for the generated translation unit (hiprtc sees no project headers); the static_asserts tie
+// it to include/gpar_hip.h.
+static const char* const GRAM_JIT_PRELUDE = R"GJ(
+struct gj_factor { int type; int term; int off; int nd; double alpha; };
+struct gj_kspec { int nterms; int nfactors; double coef[8]; gj_factor factor[12]; };
+#define GPAR_GRAM_LOWER 1
+)GJ";
+static_assert(GPAR_MAX_TERMS == 8 && GPAR_MAX_FACTORS == 12, "gram_jit.h mirrors gpar_kspec_t");
+static_assert(sizeof(gpar_factor_t) == 24 && sizeof(gpar_kspec_t) == 8 + 8 * 8 + 12 * 24, "gram_jit.h mirrors gpar_kspec_t");
+
+// Straight-line evaluation of all terms into total[8] for the micro-tile (ty, cb).  Mirrors the interpreter's order of
+// operations exactly: per term expo = sum of factor exponents (EQ: fma(-0.5, s, expo); RQ: gram_rq8), lin = coef * product of
+// linear factors, one gram_exp8 per term that has a nonlinear factor, total = fma(lin, expo, total) or total += lin.
+static std::string gram_jit_terms(const gpar_kspec_t& ks) {
+    std::string o;
+    int f = 0;
+    for (int t = 0; t < ks.nterms; ++t) {
+        const std::string ts = std::to_string(t);
+        o += "        {   // term " + ts + "\n";
+        o += "            double expo[8], lin[8];\n";
+        o += "            _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) { expo[e] = 0.0; lin[e] = ks.coef[" + ts + "]; }\n";
+        bool any_exp = false;
+        while (f < ks.nfactors && ks.factor[f].term == t) {
+            const gpar_factor_t& fa = ks.factor[f];
+            const std::string off = std::to_string(fa.off), nd = std::to_string(fa.nd), fs = std::to_string(f);
+            o += "            {\n                double s[8];\n                _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) s[e] = 0.0;\n";
+            if (fa.type == GPAR_K_LINEAR) {
+                o += "                gram_accum_static<" + off + ", " + nd + ", true>(Za, Zb, ty, cb, s);\n";
+                o += "                _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) lin[e] *= s[e];\n";
+            } else {
+                any_exp = true;
+                o += "                gram_accum_static<" + off + ", " + nd + ", false>(Za, Zb, ty, cb, s);\n";
+                if (fa.type == GPAR_K_EQ) o += "                _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) expo[e] = fma(-0.5, s[e], expo[e]);\n";
+                else o += "                gram_rq8(s, ks.factor[" + fs + "].alpha, expo, tab);\n";
+            }
+            o += "            }\n";
+            ++f;
+        }
+        if (any_exp) {
+            o += "            gram_exp8(expo, tab);\n";
+            o += "            _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) total[e] = fma(lin[e], expo[e], total[e]);\n";
+        } else {
+            o += "            _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) total[e] += lin[e];\n";
+        }
+        o += "        }\n";
+    }
+    return o;
+}
+
+// Wide kernels (more than 16 feature dims): one 64 x 64 tile per workgroup, exactly the interpreter's shape.  Their arithmetic per
+// tile is several times a narrow kernel's, so the panel staging is a small share, and they have no registers to spare for a strip
+// loop (42 dims: 256 registers as it is).
+static std::string gram_jit_source_tile(const gpar_kspec_t& ks, int dz) {
+    std::string o = GRAM_JIT_PRELUDE;
+    o += GRAM_MATH_SRC;
+    o += "\nconstexpr int DZ = " + std::to_string(dz > 0 ? dz : 1) + ";\nconstexpr int DZ_LOAD = " + std::to_string(dz) + ";\n";
+    o += R"GJ(
+extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const double* __restrict__ z1, int n1, int ldz1,
+                                                              const double* __restrict__ z2, int n2, int ldz2,
+                                                              double* __restrict__ K, int ldk, int flags,
+                                                              const double* __restrict__ diag_add, double diag_const,
+                                                              const double* __restrict__ row_scale, int sym, long long batch_z,
+                                                              long long batch_k) {
+    __shared__ __attribute__((aligned(32))) double gsm[2 * DZ * GRAM_LD];
+    __shared__ __attribute__((aligned(32))) double tab[GRAM_TAB_DOUBLES];
+    z1 += (size_t)blockIdx.z * batch_z;
+    z2 += (size_t)blockIdx.z * batch_z;
+    K += (size_t)blockIdx.z * batch_k;
+    int bm = blockIdx.y, bn = blockIdx.x;
+    if (flags & GPAR_GRAM_LOWER) {
+        const int tile = blockIdx.x;
+        bm = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+        while ((bm + 1) * (bm + 2) / 2 <= tile) ++bm;
+        while (bm * (bm + 1) / 2 > tile) --bm;
+        bn = tile - bm * (bm + 1) / 2;
+    }
+    double* Za = gsm;
+    double* Zb = gsm + DZ * GRAM_LD;
+    const int t = threadIdx.x;
+    const int row0 = bm * GRAM_T, col0 = bn * GRAM_T;
+    gram_load_tables(tab, t);
+    for (int idx = t; idx < GRAM_T * DZ_LOAD; idx += 256) {
+        const int r = idx / DZ_LOAD, d = idx - r * DZ_LOAD;
+        Za[d * GRAM_LD + r] = (row0 + r < n1) ? z1[(size_t)(row0 + r) * ldz1 + d] : 0.0;
+        Zb[d * GRAM_LD + r] = (col0 + r < n2) ? z2[(size_t)(col0 + r) * ldz2 + d] : 0.0;
+    }
+    __syncthreads();
+    const int tx = t & 15, ty = t >> 4;
+    const bool vec = ((ldk & 1) == 0) && ((((size_t)K) & 15u) == 0);
+    _Pragma("unroll 1")
+    for (int h = 0; h < 2; ++h) {
+        const int cb = 32 * h + 2 * tx;
+        double total[8];
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) total[e] = 0.0;
+        // (the row features do not depend on the pass h; kept in registers across both passes they would be 8 registers per dim:
+        // the row index is made opaque inside the loop, so that each pass reads its features again)
+        int ty_h = ty;
+        asm volatile("" : "+v"(ty_h));
+#define ty ty_h
+)GJ";
+    o += gram_jit_terms(ks);
+    o += R"GJ(
+#undef ty
+        _Pragma("unroll")
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * ty + i;
+            if (row >= n1) continue;
+            const int col = col0 + cb;
+            double v0 = total[2 * i], v1 = total[2 * i + 1];
+            if (row_scale) { const double rs = row_scale[row]; v0 *= rs; v1 *= rs; }
+            if (sym) {
+                const double dadd = (diag_add ? diag_add[row] : 0.0) + diag_const;
+                if (col == row) v0 += dadd;
+                if (col + 1 == row) v1 += dadd;
+            }
+            double* out = K + (size_t)row * ldk + col;
+            if (vec && col + 1 < n2) {
+                *reinterpret_cast<g_d2*>(out) = g_d2{v0, v1};
+            } else {
+                if (col < n2) out[0] = v0;
+                if (col + 1 < n2) out[1] = v1;
+            }
+        }
+    }
+}
+)GJ";
+    return o;
+}
+
+// Column tiles per workgroup: a workgroup walks a strip of up to `strip` consecutive 64 x 64 tiles of one tile row (1, 2, 4 or 8:
+// part of the generated source and of the cache key).
+static int gram_jit_strip(long long tiles, int dz) {
+    if (dz > 16) return 0;   // wide kernels: one tile per workgroup (gram_jit_source_tile)
+    if (const char* e = getenv("GPAR_GRAM_JIT_STRIP")) { const int v = atoi(e); if (v >= 0 && v <= 64) return v; }
+    // as long as ~2000 workgroups remain (three rounds of the chip's 768 slots).  Measured (ms; strip 1 / 2 / 4 / 8): C3 lower
+    // triangle n = 16384, 8 dims 0.449 / 0.415 / 0.398 / 0.394; C4 cross 65536 x 1024, 14 dims 0.283 / 0.245 / 0.227 / 0.228;
+    // C2 n = 4096, 5 dims 0.031 / 0.033 / 0.035 / 0.042.
+    int strip = 8;
+    while (strip > 1 && tiles / strip < 2000) strip /= 2;
+    return strip;
+}
+
+static std::string gram_jit_source(const gpar_kspec_t& ks, int dz, int strip) {
+    if (strip <= 0) return gram_jit_source_tile(ks, dz);
+    std::string o = GRAM_JIT_PRELUDE;
+    o += GRAM_MATH_SRC;
+    o += "\nconstexpr int DZ = " + std::to_string(dz > 0 ? dz : 1) + ";\nconstexpr int DZ_LOAD = " + std::to_string(dz) + ";\n";
+    o += "constexpr int STRIP = " + std::to_string(strip) + ";\n";
+    o += "constexpr bool PREFETCH = true;\n";
+    o += R"GJ(
+// One workgroup = one strip of up to STRIP consecutive 64 x 64 tiles of a tile row (blockIdx.y = tile row, blockIdx.x = strip;
+// strips wholly above the diagonal of a lower-triangular build leave at once).  The row panel Za and the tables are staged
+// once per strip; the column panel of tile c + 1 is requested from global memory before tile c is computed and stored to the
+// other LDS buffer after it: a single-tile workgroup spends as long waiting for its panels (global -> LDS -> barrier, ~2 us)
+// as computing (57 vector instructions per entry: 1.6 us), and three of them per compute unit cover only half of that.
+constexpr int PANEL = GRAM_T * DZ_LOAD;             // doubles per feature panel
+constexpr int PER_THREAD = (PANEL + 255) / 256;
+
+__device__ __forceinline__ void gj_panel_load(const double* __restrict__ z, int n, int ldz, int r0, int t, double (&reg)[PER_THREAD > 0 ? PER_THREAD : 1]) {
+    _Pragma("unroll")
+    for (int q = 0; q < PER_THREAD; ++q) {
+        const int idx = t + 256 * q;
+        const int r = idx / DZ, d = idx - r * DZ;
+        const bool ok = idx < PANEL && r0 + r < n;
+        reg[q] = ok ? z[(size_t)(ok ? r0 + r : 0) * ldz + (ok ? d : 0)] : 0.0;
+    }
+}
+__device__ __forceinline__ void gj_panel_store(double* __restrict__ Z, int t, const double (&reg)[PER_THREAD > 0 ? PER_THREAD : 1]) {
+    _Pragma("unroll")
+    for (int q = 0; q < PER_THREAD; ++q) {
+        const int idx = t + 256 * q;
+        const int r = idx / DZ, d = idx - r * DZ;
+        if (idx < PANEL) Z[d * GRAM_LD + r] = reg[q];
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const double* __restrict__ z1, int n1, int ldz1,
+                                                              const double* __restrict__ z2, int n2, int ldz2,
+                                                              double* __restrict__ K, int ldk, int flags,
+                                                              const double* __restrict__ diag_add, double diag_const,
+                                                              const double* __restrict__ row_scale, int sym, long long batch_z,
+                                                              long long batch_k) {
+    __shared__ __attribute__((aligned(32))) double gsm[3 * DZ * GRAM_LD];
+    __shared__ __attribute__((aligned(32))) double tab[GRAM_TAB_DOUBLES];
+    const int nt2 = (n2 + GRAM_T - 1) / GRAM_T;
+    int bm = blockIdx.y, bn0 = blockIdx.x * STRIP;
+    if (flags & GPAR_GRAM_LOWER) {
+        // 1-D grid over the strips of the lower triangle (empty workgroups above the diagonal are not free: ~25 ns of dispatch
+        // each, as many again as useful ones).  Tile rows come in groups of STRIP rows with g + 1 strips each, g = 0, 1, ...:
+        // STRIP g (g + 1) / 2 strips precede group g.
+        const int L = blockIdx.x;
+        int g = (int)((sqrt(8.0 * (double)L / (double)STRIP + 1.0) - 1.0) * 0.5);
+        while (STRIP * (g + 1) * (g + 2) / 2 <= L) ++g;
+        while (STRIP * g * (g + 1) / 2 > L) --g;
+        const int rem = L - STRIP * g * (g + 1) / 2;
+        bm = g * STRIP + rem / (g + 1);
+        bn0 = (rem % (g + 1)) * STRIP;
+    }
+    int bn1 = bn0 + STRIP < nt2 ? bn0 + STRIP : nt2;                 // tiles [bn0, bn1)
+    if ((flags & GPAR_GRAM_LOWER) && bn1 > bm + 1) bn1 = bm + 1;     // lower triangle: nothing right of the diagonal tile
+    if (bn0 >= bn1 || bm * GRAM_T >= n1) return;
+    z1 += (size_t)blockIdx.z * batch_z;
+    z2 += (size_t)blockIdx.z * batch_z;
+    K += (size_t)blockIdx.z * batch_k;
+    double* Za = gsm;
+    const int t = threadIdx.x;
+    const int row0 = bm * GRAM_T;
+    double preg[PER_THREAD > 0 ? PER_THREAD : 1];
+    gram_load_tables(tab, t);
+    gj_panel_load(z1, n1, ldz1, row0, t, preg);
+    gj_panel_store(Za, t, preg);
+    gj_panel_load(z2, n2, ldz2, bn0 * GRAM_T, t, preg);
+    gj_panel_store(gsm + DZ * GRAM_LD, t, preg);
+    __syncthreads();
+    const int tx = t & 15, ty = t >> 4;
+    const bool vec = ((ldk & 1) == 0) && ((((size_t)K) & 15u) == 0);
+    _Pragma("unroll 1")
+    for (int bn = bn0; bn < bn1; ++bn) {
+        const double* Zb = gsm + (1 + ((bn - bn0) & 1)) * DZ * GRAM_LD;
+        const int col0 = bn * GRAM_T;
+        const bool more = bn + 1 < bn1;
+        if (PREFETCH && more) gj_panel_load(z2, n2, ldz2, col0 + GRAM_T, t, preg);   // in flight under this tile's arithmetic
+    _Pragma("unroll 1")
+    for (int h = 0; h < 2; ++h) {
+        const int cb = 32 * h + 2 * tx;
+        double total[8];
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) total[e] = 0.0;
+)GJ";
+    // (the row features - Za at 4 ty - do not depend on the pass h or on the tile: up to 16 dims stay in registers across the strip)
+    o += gram_jit_terms(ks);
+    o += R"GJ(
+        _Pragma("unroll")
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * ty + i;
+            if (row >= n1) continue;
+            const int col = col0 + cb;
+            double v0 = total[2 * i], v1 = total[2 * i + 1];
+            if (row_scale) { const double rs = row_scale[row]; v0 *= rs; v1 *= rs; }
+            if (sym) {
+                const double dadd = (diag_add ? diag_add[row] : 0.0) + diag_const;
+                if (col == row) v0 += dadd;
+                if (col + 1 == row) v1 += dadd;
+            }
+            double* out = K + (size_t)row * ldk + col;
+            if (vec && col + 1 < n2) {
+                *reinterpret_cast<g_d2*>(out) = g_d2{v0, v1};
+            } else {
+                if (col < n2) out[0] = v0;
+                if (col + 1 < n2) out[1] = v1;
+            }
+        }
+    }
+        if (more) {
+            if (!PREFETCH) gj_panel_load(z2, n2, ldz2, col0 + GRAM_T, t, preg);
+            gj_panel_store(gsm + (1 + ((bn + 1 - bn0) & 1)) * DZ * GRAM_LD, t, preg);
+            __syncthreads();   // the next panel is complete, and every wave is done reading this one before it is overwritten again
+        }
+    }
+}
+)GJ";
+    return o;
+}
+
+// Arguments of gram_jit in declaration order (hipModuleLaunchKernel takes an array of pointers to them).
+struct GramJitArgs {
+    gpar_kspec_t ks;
+    const double* z1; int n1, ldz1;
+    const double* z2; int n2, ldz2;
+    double* K; int ldk, flags;
+    const double* diag_add; double diag_const;
+    const double* row_scale; int sym;
+    long long batch_z, batch_k;
+};
+
+// Problems with at least this many entries take the generated kernel (GPAR_GRAM_JIT_MIN_ENTRIES; 0: always, negative: never).
+// Below it a launch is over in microseconds either way, and a model with many distinct small layers (the test-suite's) would
+// pay ~0.3-1 s of compilation per structure for nothing.
+static long long gram_jit_min_entries() {
+    const char* e = getenv("GPAR_GRAM_JIT_MIN_ENTRIES");
+    return e ? atoll(e) : (1LL << 22);
+}
+
+// Launch the generated kernel if there is (or can be) one for this structure; false: the caller falls back to the interpreter.
+static bool gram_jit_launch(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz,
+                            double* K, int ldk, int flags, const double* diag_add, double diag_const, const double* row_scale, int sym,
+                            dim3 grid, hipStream_t stream, long long batch_z, long long batch_k) {
+    const long long min_entries = gram_jit_min_entries();
+    if (min_entries < 0 || (long long)n1 * n2 * grid.z < min_entries) return false;
+    // (the interpreter's grid enumerates tiles; this kernel takes tile rows x strips of column tiles)
+    const int nt1 = gpar_ceil_div(n1, GRAM_T), nt2 = gpar_ceil_div(n2, GRAM_T);
+    const long long tiles = ((flags & GPAR_GRAM_LOWER) ? (long long)nt1 * (nt1 + 1) / 2 : (long long)nt1 * nt2) * grid.z;
+    const int strip = gram_jit_strip(tiles, dz);
+    hipFunction_t fn = jit_get(JIT_GRAM, *ks, dz, strip, "gram_jit", [&]() { return gram_jit_source(*ks, dz, strip); });
+    if (!fn) return false;
+    if (strip <= 0) {
+        // (the interpreter's own grid, as passed in)
+    } else if (flags & GPAR_GRAM_LOWER) {
+        // strips of the lower triangle: full groups of `strip` rows with g + 1 strips per row, then the rows of a last, partial group
+        const int full = nt1 / strip, rest = nt1 - full * strip;
+        grid = dim3((unsigned)((long long)strip * full * (full + 1) / 2 + (long long)rest * (full + 1)), 1, grid.z);
+    } else {
+        grid = dim3(gpar_ceil_div(nt2, strip), nt1, grid.z);
+    }
+    GramJitArgs a{*ks, z1, n1, ldz1, z2, n2, ldz2, K, ldk, flags, diag_add, diag_const, row_scale, sym, batch_z, batch_k};
+    void* params[] = {&a.ks, &a.z1, &a.n1, &a.ldz1, &a.z2, &a.n2, &a.ldz2, &a.K, &a.ldk, &a.flags, &a.diag_add, &a.diag_const,
+                      &a.row_scale, &a.sym, &a.batch_z, &a.batch_k};
+    return hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, 256, 1, 1, 0, stream, params, nullptr) == hipSuccess;
+}
+
+}  // namespace gpar

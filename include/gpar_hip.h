@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPAR_ABI_VERSION 3
+#define GPAR_ABI_VERSION 4
 
 /* ---- kernel specification -------------------------------------------------------------------
  * A GPAR layer kernel (gpar/regression.py:92-180) is a sum of products of elementary kernels applied
@@ -102,6 +102,18 @@ typedef struct {
 #define GPAR_GEMM_A_LOWER 2 /* treat op(A) as lower triangular (entries with k > m are zero) */
 #define GPAR_GEMM_K_FROM_ROW 4 /* op(A)[m][k] is stored as zero for k < m (with C_LOWER also op(B)^T[n][k] for k < row): k starts at the tile's first row */
 #define GPAR_GEMM_K_TO_COL 8 /* op(B)[k][n] is stored as zero for k > n (upper-triangular op(B)): k ends with the tile's last column */
+
+/* ---- run-time specialisation (ABI v4) -----------------------------------------------------------
+ * A layer's kernel STRUCTURE is fixed when the model is built (gpar/regression.py:92-180 decides the term list once per layer);
+ * for large problems gpar_gram compiles a kernel for that structure with hiprtc on first use (values - coefficients, RQ shapes -
+ * stay arguments: training never recompiles) and caches it per device; small problems and any compilation failure use the
+ * ahead-of-time interpreter, which computes the same bits.  Environment: GPAR_GRAM_JIT_MIN_ENTRIES (default 2^22 entries per
+ * launch; 0 = always, negative = never).
+ *   gpar_jit_compile_check  compiles (does not load) the kernel of `kind` (0: Gram) for `ks` / `dz` and architecture `arch`
+ *                           (e.g. "gfx950"): returns the code-object size, or -1 with the compiler's log in `log`; needs no GPU.
+ *   gpar_jit_stats          kernels compiled / compilations failed / structures cached so far in this process. */
+int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char* arch, char* log, int log_len);
+int gpar_jit_stats(int* compiled, int* failures, int* cached);
 
 int gpar_abi_version(void);
 size_t gpar_sizeof_fspec(void);

@@ -665,3 +665,80 @@ def test_kernel_input_gradients_match_oracle(env, m, p_cols, n1, n2):
         got = eng.kernel_input_grads(ck, to_dev(x1), None, lower, sym=True).cpu().numpy()
         ref = 2.0 * ok.kernel_input_grads(spec, x1, x1, Ws)
         assert np.max(np.abs(got - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref))), name
+
+
+# ---- per-specification (run-time compiled) Gram kernels --------------------------------------------------------------------
+
+def _jit_cases():
+    """(name, kernel, width): the kernel families GPARRegressor builds (gpar/regression.py:92-180) at several widths."""
+    from gpar_amd.regression import GPARRegressor, _construct_gpar
+    from gpar_amd.engine import set_engine
+    from oracle.engine import OracleEngine
+
+    previous = set_engine(OracleEngine())   # (only to instantiate the hyper-parameters of the host-side model objects)
+    try:
+        out = []
+        for name, kw, m, layer in [
+            ("eq-lin-eq", dict(scale=0.5, linear=True, nonlinear=True, markov=2), 4, 7),
+            ("eq-only", dict(scale=0.5, linear=False), 2, 0),
+            ("per-rq-wide", dict(scale=0.5, per=True, rq=True, linear=True, nonlinear=True), 3, 15),
+            ("rq-inputlinear-const", dict(scale=0.7, rq=True, input_linear=True, linear=True, nonlinear=True), 2, 3),
+            ("markov0-constant-term", dict(linear=True, nonlinear=True, markov=0), 1, 2),
+        ]:
+            reg = GPARRegressor(**kw)
+            f, _ = _construct_gpar(reg, reg.vs, m, layer + 1).layers[layer]()
+            out.append((name, f.kernel, m + layer))
+        return out
+    finally:
+        set_engine(previous)
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_generated_gram_kernel_is_bit_identical_to_the_interpreter(case, monkeypatch):
+    """The kernel compiled at run time for a layer's STRUCTURE (csrc/gram_jit.h, hiprtc) and the ahead-of-time interpreter
+    (csrc/gram.h) share their arithmetic verbatim (csrc/gram_math.inc): every entry must agree to the last bit - symmetric
+    lower-triangular builds with noise diagonal and jitter, ragged sizes, cross-Gram with row scaling, a batch."""
+    import ctypes
+
+    import torch
+
+    from gpar_amd import _lib
+    from gpar_amd import hip as H
+    from gpar_amd.kernels import compile_kernel
+
+    name, kernel, width = _jit_cases()[case]
+    dev = torch.device("cuda:0")
+    ck = compile_kernel(kernel, width)
+    g = torch.Generator().manual_seed(case)
+    x = torch.randn(333, width, generator=g, dtype=torch.float64).to(dev)
+    x2 = torch.randn(130, width, generator=g, dtype=torch.float64).to(dev)
+    z, z2 = H.featurize(ck, x), H.featurize(ck, x2)
+    noise = torch.rand(333, generator=g, dtype=torch.float64).to(dev)
+    rs = torch.rand(333, generator=g, dtype=torch.float64).to(dev) + 0.5
+    zb = H.featurize(ck, torch.randn(3 * 70, width, generator=g, dtype=torch.float64).to(dev))
+
+    def build():
+        sym = H.gram(ck, z, None, lower=True, diag_add=noise, diag_const=1e-12, out=torch.zeros(333, 336, dtype=torch.float64, device=dev)[:, :333])
+        cross = H.gram(ck, z, z2, row_scale=rs)
+        batch = H.gram_batch_(ck, zb, 3, H.alloc_matrix(210, 70, dev, zero=True), lower=True, diag_const=0.1)
+        torch.cuda.synchronize()
+        return torch.tril(sym).clone(), cross.clone(), batch.clone()
+
+    lib = _lib.load()
+    counts = lambda: tuple(c.value for c in cs) if not lib.gpar_jit_stats(*[ctypes.byref(c) for c in cs]) else None
+    cs = [ctypes.c_int(), ctypes.c_int(), ctypes.c_int()]
+    monkeypatch.setenv("GPAR_GRAM_JIT_MIN_ENTRIES", "-1")   # never: the interpreter
+    ref = build()
+    before = counts()
+    monkeypatch.setenv("GPAR_GRAM_JIT_MIN_ENTRIES", "0")    # always: the generated kernel
+    got = build()
+    after = counts()
+    assert after[1] == before[1], "a generated kernel failed to compile"
+    assert after[2] >= 1   # at least this structure is cached now
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b), name
+    # and both agree with the numpy oracle's kernel evaluation
+    from oracle import kernels as ok
+
+    want = ok.gram(ok.spec_to_dict(kernel.resolve(width)), x.cpu().numpy(), x2.cpu().numpy()) * rs.cpu().numpy()[:, None]
+    np.testing.assert_allclose(got[1].cpu().numpy(), want, rtol=1e-13, atol=1e-15)

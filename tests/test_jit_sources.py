@@ -1,0 +1,56 @@
+"""The run-time specialised kernels are generated source (csrc/gram_jit.h): `gpar_jit_compile_check` compiles - without loading,
+so without a GPU - the kernel of a given layer structure for gfx950.  Every kernel family GPARRegressor can build must compile."""
+import ctypes
+
+import numpy as np
+import pytest
+
+
+def _specs():
+    from gpar_amd.engine import set_engine
+    from gpar_amd.kernels import compile_kernel
+    from gpar_amd.regression import GPARRegressor, _construct_gpar
+    from oracle.engine import OracleEngine
+
+    previous = set_engine(OracleEngine())
+    try:
+        out = []
+        for kw, m, p in [
+            (dict(scale=0.5, linear=True, nonlinear=True, markov=2), 4, 8),                       # BASELINE C3
+            (dict(scale=0.5, linear=True), 2, 4),                                                 # C2
+            (dict(scale=0.5, per=True, rq=True, linear=True, nonlinear=True), 3, 16),             # C5 (42 feature dims in the last layer)
+            (dict(rq=True, input_linear=True, linear=True, nonlinear=True, scale_tie=True), 2, 3),
+            (dict(linear=True, nonlinear=True, markov=0), 1, 3),                                  # constant output term
+        ]:
+            reg = GPARRegressor(**kw)
+            gpar = _construct_gpar(reg, reg.vs, m, p)
+            for layer in sorted({0, 1, p - 1}):
+                f, _ = gpar.layers[layer]()
+                out.append(compile_kernel(f.kernel, m + layer))
+        return out
+    finally:
+        set_engine(previous)
+
+
+def test_every_layer_structure_compiles_for_gfx950():
+    from gpar_amd import _lib
+
+    lib = _lib.load()
+    log = ctypes.create_string_buffer(1 << 16)
+    sizes = []
+    for ck in _specs():
+        size = lib.gpar_jit_compile_check(0, ctypes.byref(ck.kspec), ck.dz, b"gfx950", log, len(log))
+        assert size > 0, log.value.decode()[:4000]
+        sizes.append(size)
+    assert len(sizes) >= 12 and len(set(sizes)) > 3   # different structures, different code
+
+
+def test_bad_arguments_are_refused():
+    from gpar_amd import _lib
+
+    lib = _lib.load()
+    ck = _specs()[0]
+    log = ctypes.create_string_buffer(4096)
+    assert lib.gpar_jit_compile_check(99, ctypes.byref(ck.kspec), ck.dz, b"gfx950", log, len(log)) < -1000   # unknown kind
+    assert lib.gpar_jit_compile_check(0, ctypes.byref(ck.kspec), 1000, b"gfx950", log, len(log)) < -1000     # more dims than the spec holds
+    assert lib.gpar_jit_compile_check(0, None, ck.dz, b"gfx950", log, len(log)) < -1000
