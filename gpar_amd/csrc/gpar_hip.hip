@@ -9,6 +9,7 @@
 #include "panel2.h"
 #include "gram.h"
 #include "gram_jit.h"
+#include "grad_jit.h"
 #include "blas1.h"
 
 namespace gpar {
@@ -248,6 +249,13 @@ int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char*
     if (kind == JIT_GRAM) {
         source = gram_jit_source(*ks, dz, gram_jit_strip(1 << 20, dz));   // the shape a large problem gets
         entry = "gram_jit";
+    } else if (kind == JIT_GRAD || kind == JIT_GRAD + 10 || kind == JIT_GRAD + 20 || kind == JIT_GRAD + 30) {
+        // 1: symmetric weights; 11: rectangular; 21 / 31: the same with frequency derivatives (periodic features)
+        source = grad_jit_source(*ks, dz, (kind / 10) & 1, kind >= 20);
+        entry = "gram_grad_jit";
+    } else if (kind == JIT_INPUT_GRAD || kind == JIT_INPUT_GRAD + 10) {
+        source = input_grad_jit_source(*ks, dz, kind / 10);
+        entry = "gram_input_grad_jit";
     }
     else return GPAR_ARG_ERROR(2);
     std::string code, text;
@@ -384,10 +392,11 @@ static int gram_grad_launch(const gpar_kspec_t* ks, const double* z1, const doub
     const size_t lds = ((size_t)4 * (dz > 0 ? dz : 1) * GRAM_LD + 4 * GRAD_NACC) * sizeof(double);
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&gram_grad_kernel), 160 * 1024));
     if (lds > 160 * 1024) return GPAR_ARG_ERROR(7);
-    hipLaunchKernelGGL(gram_grad_kernel, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, *ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2,
-                       dz, W, ldw, mode, workspace);
-    hipLaunchKernelGGL(gram_grad_reduce_kernel, dim3(gpar_ceil_div(GRAD_NACC, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const double*)workspace, nblocks, out);
+    // per-specification kernel (grad_jit.h) for problems large enough to repay its compilation; the interpreter otherwise
+    if (!grad_jit_launch(ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2, dz, W, ldw, mode, workspace, nblocks, (hipStream_t)stream))
+        hipLaunchKernelGGL(gram_grad_kernel, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, *ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2,
+                           dz, W, ldw, mode, workspace);
+    hipLaunchKernelGGL(gram_grad_reduce_kernel, dim3(GRAD_NACC), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, nblocks, out);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
@@ -428,8 +437,9 @@ int gpar_gram_input_grad(const gpar_kspec_t* ks, const double* z1, int n1, int l
     const size_t lds = ((size_t)2 * dz * GRAM_LD + (size_t)GRAM_T * dz) * sizeof(double);
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&gram_input_grad_kernel), 160 * 1024));
     if (lds > 160 * 1024) return GPAR_ARG_ERROR(7);
-    hipLaunchKernelGGL(gram_input_grad_kernel, dim3(gpar_ceil_div(n1, GRAM_T), nsplit), dim3(256), lds, (hipStream_t)stream, *ks, z1, n1,
-                       ldz1, z2, n2, ldz2, dz, W, ldw, mode, nsplit, workspace);
+    if (!input_grad_jit_launch(ks, z1, n1, ldz1, z2, n2, ldz2, dz, W, ldw, mode, nsplit, workspace, (hipStream_t)stream))
+        hipLaunchKernelGGL(gram_input_grad_kernel, dim3(gpar_ceil_div(n1, GRAM_T), nsplit), dim3(256), lds, (hipStream_t)stream, *ks, z1, n1,
+                           ldz1, z2, n2, ldz2, dz, W, ldw, mode, nsplit, workspace);
     const long long total = (long long)n1 * dz;
     hipLaunchKernelGGL(gram_input_grad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const double*)workspace, nsplit, n1, dz, out, ldo);

@@ -538,13 +538,17 @@ __global__ __launch_bounds__(256) void gram_input_grad_reduce_kernel(const doubl
     out[(size_t)r * ldo + d] = s;
 }
 
-__global__ __launch_bounds__(256) void gram_grad_reduce_kernel(const double* __restrict__ partial, int nblocks,
-                                                               double* __restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// Sum of the per-workgroup partial sums, one wave per moment: lane l adds blocks l, l + 64, ... in order, the 64 lane sums are
+// combined by a fixed butterfly (deterministic).  (One thread per moment walking all blocks took 155 us for 1024 blocks - a chain
+// of dependent loads - which was more than the generated gradient kernel itself.)
+__global__ __launch_bounds__(64) void gram_grad_reduce_kernel(const double* __restrict__ partial, int nblocks,
+                                                              double* __restrict__ out) {
+    const int k = blockIdx.x, lane = threadIdx.x;
     if (k >= GRAD_NACC) return;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * GRAD_NACC + k];
-    out[k] = s;
+    for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * GRAD_NACC + k];
+    s = wave_sum(s);
+    if (lane == 0) out[k] = s;
 }
 
 }  // namespace gpar

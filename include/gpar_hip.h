@@ -109,8 +109,12 @@ typedef struct {
  * stay arguments: training never recompiles) and caches it per device; small problems and any compilation failure use the
  * ahead-of-time interpreter, which computes the same bits.  Environment: GPAR_GRAM_JIT_MIN_ENTRIES (default 2^22 entries per
  * launch; 0 = always, negative = never).
- *   gpar_jit_compile_check  compiles (does not load) the kernel of `kind` (0: Gram) for `ks` / `dz` and architecture `arch`
- *                           (e.g. "gfx950"): returns the code-object size, or -1 with the compiler's log in `log`; needs no GPU.
+ *   gpar_jit_compile_check  compiles (does not load) the kernel of `kind` for `ks` / `dz` and architecture `arch` (e.g. "gfx950"):
+ *                           returns the code-object size, or -1 with the compiler's log in `log`; needs no GPU.  kind 0: Gram;
+ *                           1 / 11: parameter-gradient pass with symmetric / rectangular weights (21 / 31: with frequency
+ *                           derivatives of periodic features); 2 / 12: input-gradient pass, symmetric / rectangular weights.
+ *                           (gpar_gram_grad* / gpar_gram_input_grad use generated kernels from GPAR_GRAD_JIT_MIN_ENTRIES weight
+ *                           entries on, default 2^20; summation order differs from the interpreter's: agreement to rounding.)
  *   gpar_jit_stats          kernels compiled / compilations failed / structures cached so far in this process. */
 int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char* arch, char* log, int log_len);
 int gpar_jit_stats(int* compiled, int* failures, int* cached);

@@ -742,3 +742,53 @@ def test_generated_gram_kernel_is_bit_identical_to_the_interpreter(case, monkeyp
 
     want = ok.gram(ok.spec_to_dict(kernel.resolve(width)), x.cpu().numpy(), x2.cpu().numpy()) * rs.cpu().numpy()[:, None]
     np.testing.assert_allclose(got[1].cpu().numpy(), want, rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_generated_gradient_kernels_match_the_interpreter(case, monkeypatch):
+    """The run-time compiled gradient passes (csrc/grad_jit.h) against the ahead-of-time interpreter (csrc/gram.h): the moment sums
+    of the parameter-gradient pass with symmetric and rectangular weights (ragged sizes; with frequency derivatives where the
+    kernel has periodic features) and the input-gradient pass in both modes.  Same sums in a different order: agreement to
+    rounding (1e-11 of the largest sum), not to the bit."""
+    import ctypes
+
+    import torch
+
+    from gpar_amd import _lib
+    from gpar_amd import hip as H
+    from gpar_amd.kernels import compile_kernel
+
+    name, kernel, width = _jit_cases()[case]
+    dev = torch.device("cuda:0")
+    ck = compile_kernel(kernel, width)
+    g = torch.Generator().manual_seed(100 + case)
+    x = torch.randn(333, width, generator=g, dtype=torch.float64).to(dev)
+    x2 = torch.randn(130, width, generator=g, dtype=torch.float64).to(dev)
+    z, z2 = H.featurize(ck, x), H.featurize(ck, x2)
+    periodic = any(f.periods is not None for t in ck.kernel.terms for f in t.factors)
+    zd = H.featurize_dfreq(ck, x) if periodic else None
+    zd2 = H.featurize_dfreq(ck, x2) if periodic else None
+    Wsym = torch.randn(333, 336, generator=g, dtype=torch.float64).to(dev)[:, :333]
+    Wrect = torch.randn(333, 130, generator=g, dtype=torch.float64).to(dev)
+
+    def run():
+        out = [H.gram_grad(ck, z, zd, Wsym, nblocks=7), H.gram_grad_cross(ck, z, zd, z2, zd2, Wrect.contiguous(), H.GRAD_RECT, nblocks=5),
+               H.gram_grad_cross(ck, z, zd, z, zd, Wsym, H.GRAD_SYM)]
+        if ck.dz:
+            out += [H.gram_input_grad(ck, z, z2, Wrect.contiguous(), H.GRAD_RECT), H.gram_input_grad(ck, z, z, Wsym, H.GRAD_SYM)]
+        torch.cuda.synchronize()
+        return [o.clone() for o in out]
+
+    lib = _lib.load()
+    cs = [ctypes.c_int(), ctypes.c_int(), ctypes.c_int()]
+    monkeypatch.setenv("GPAR_GRAD_JIT_MIN_ENTRIES", "-1")
+    ref = run()
+    lib.gpar_jit_stats(*[ctypes.byref(c) for c in cs])
+    failures = cs[1].value
+    monkeypatch.setenv("GPAR_GRAD_JIT_MIN_ENTRIES", "0")
+    got = run()
+    lib.gpar_jit_stats(*[ctypes.byref(c) for c in cs])
+    assert cs[1].value == failures, "a generated gradient kernel failed to compile"
+    for a, b in zip(got, ref):
+        scale = float(b.abs().max()) + 1e-300
+        assert float((a - b).abs().max()) <= 1e-11 * scale, (name, float((a - b).abs().max()), scale)
