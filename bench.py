@@ -12,7 +12,8 @@ prints ONE JSON line.  Besides the contract fields it carries
                 (rem * (rem + 1) * kb per launch) / hipEvent-measured time, against the fp64 matrix peak;
   cpu_baseline  the reference's CPU path restated on torch-CPU fp64 operators (oracle/torch_cpu.py, kind "port"), timed
                 on this box's host cores on a bounded sample of the same workload;
-  fit_predict   wall-clock of `fit(iters=20)` + `predict(num_samples=100)` at the same size (the other half of BASELINE's metric).
+  fit_predict   wall-clock of `fit(iters=20)` + `predict(num_samples=100)` at the same size (the other half of BASELINE's metric);
+  config_grid   log marginal likelihood wall-clock of BASELINE.json's other configurations (C2, C4, C5; C5 with its predict leg).
 """
 import argparse
 import json
@@ -301,6 +302,13 @@ def main():
             leg = {"error": f"{type(exc).__name__}: {exc}", "n_gpus": world}
         if rank == 0:
             out["fit_predict"] = leg
+    if rank == 0 and world == 1 and not args.no_extras and (n, m, p) == (16384, 4, 8):
+        # the other BASELINE.json configurations on the same GPU, in the same run (parity-test cases, not the headline)
+        del x, y, w
+        try:
+            out["config_grid"] = config_grid_leg(eng)
+        except Exception as exc:
+            out["config_grid"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_leg(x_np, y_np, m, p, budget_s=args.cpu_budget)
     emit()
@@ -395,6 +403,60 @@ def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=20, num_samples=1
         sync()
         leg["predict_replace_ms"] = 1e3 * (time.perf_counter() - t4)
     return leg
+
+
+GRID = {
+    "C2": dict(n=4096, m=2, p=4, kw=dict(scale=0.5, linear=True, nonlinear=False, noise=0.1)),
+    "C4": dict(n=65536, m=8, p=4, M=1024, kw=dict(scale=0.5, linear=True, nonlinear=True, noise=0.1)),
+    "C5": dict(n=8192, m=3, p=16, kw=dict(scale=0.5, per=True, rq=True, linear=True, nonlinear=True, noise=0.1)),
+}
+
+
+def config_grid_leg(eng, evals=5, warmup=2):
+    """Log marginal likelihood of BASELINE.json's other configurations (C2 dense n = 4096, C4 inducing points n = 65536 / M = 1024,
+    C5 periodic + RQ n = 8192 p = 16) on one GPU: best and median wall-clock of `evals` evaluations each, with the algorithmic
+    flop count against the fp64 matrix peak; C5 also times its second leg, predict(num_samples=200)."""
+    import torch
+
+    from gpar_amd.regression import GPARRegressor
+
+    grid = {}
+    for name, cfg in GRID.items():
+        n, m, p = cfg["n"], cfg["m"], cfg["p"]
+        x_np, y_np = synthetic(n, m, p)
+        kw = dict(cfg["kw"], normalise_y=False)
+        if "M" in cfg:
+            kw["x_ind"] = np.random.default_rng(3).uniform(0, 1, (cfg["M"], m))
+        reg = GPARRegressor(**kw)
+        x, y = eng.tensor(x_np), eng.tensor(y_np)
+        value = None
+        for _ in range(warmup):
+            value = float(reg.logpdf(x, y))
+        times = []
+        for _ in range(evals):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            value = float(reg.logpdf(x, y))
+            torch.cuda.synchronize()
+            times.append(1e3 * (time.perf_counter() - t0))
+        flops = p * (2.0 * cfg["M"] ** 2 * n + 2.0 * cfg["M"] ** 3 / 3.0) if "M" in cfg else p * (n**3 / 3.0 + n * n)
+        rec = {"n": n, "m": m, "p": p, "M": cfg.get("M"), "logpdf_ms_best": min(times), "logpdf_ms_median": float(np.median(times)),
+               "logpdf": value, "algorithmic_flops": flops,
+               "frac_of_fp64_matrix_peak": flops / (min(times) * 1e-3) * 1e-12 / FP64_MATRIX_PEAK_TFLOPS}
+        if name == "C5":
+            reg.condition(x_np, y_np)
+            xs = np.random.default_rng(2).uniform(0, 1, (2048, m))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mean, lo, hi = reg.predict(xs, num_samples=200, credible_bounds=True)
+            torch.cuda.synchronize()
+            rec["predict_200_samples_ms"] = 1e3 * (time.perf_counter() - t0)
+            rec["predict_n_star"] = 2048
+            rec["predict_finite"] = bool(np.isfinite(mean).all() and np.isfinite(lo).all() and np.isfinite(hi).all())
+        grid[name] = rec
+        del x, y, reg
+        torch.cuda.empty_cache()
+    return grid
 
 
 def _leaf_spec(spec):

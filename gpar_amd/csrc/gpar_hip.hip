@@ -239,6 +239,28 @@ int gpar_abi_version(void) { return GPAR_ABI_VERSION; }
 size_t gpar_sizeof_fspec(void) { return sizeof(gpar_fspec_t); }
 size_t gpar_sizeof_kspec(void) { return sizeof(gpar_kspec_t); }
 
+// Everything the library creates lazily, created now: the look-ahead side stream paired with `stream`, the event ring and
+// every kernel's dynamic-LDS attribute on the device that owns `stream`.  After it, entry points called
+// on `stream` make no HIP object-creation call - the precondition of capturing them into a hipGraph (the run-time compiled
+// kernels excepted: a structure is compiled at its first large launch, which must therefore happen once outside the capture).
+int gpar_init(void* stream) {
+    GPAR_API_GUARD;
+    if (!la_init()) return -(int)hipErrorOutOfMemory;
+    if (!la_side((hipStream_t)stream)) return -(int)hipErrorOutOfMemory;
+    const void* big[] = {reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>),
+                         reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>),
+                         reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0, 64>),
+                         reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1, 64>), reinterpret_cast<const void*>(&gram_grad_kernel),
+                         reinterpret_cast<const void*>(&gram_input_grad_kernel)};
+    for (const void* fn : big) GPAR_HIP_TRY(gpar_set_max_lds(fn, 160 * 1024));
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_panel_kernel), PNL_LDS_BYTES));
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&trsm_block_kernel), PNL_LDS_BYTES));
+    const void* p2[] = {reinterpret_cast<const void*>(&potrf_panel2_kernel), reinterpret_cast<const void*>(&trsm_block2_kernel),
+                        reinterpret_cast<const void*>(&trsm_block2_back_kernel), reinterpret_cast<const void*>(&trinv_blocks2_kernel)};
+    for (const void* fn : p2) GPAR_HIP_TRY(gpar_set_max_lds(fn, P2_LDS_BYTES));
+    return 0;
+}
+
 // ---- run-time specialisation (jit.h) ----------------------------------------------------------------------------------
 int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char* arch, char* log, int log_len) {
     GPAR_API_GUARD_NOSTREAM;

@@ -385,6 +385,14 @@ class HipEngine:
             return None
         return _LayerPipeline(self, _device_streams(self.device, depth))
 
+    def side_stream(self):
+        """One extra stream for a short piece of work that is independent of what the caller enqueues next (the factorisation of
+        K_zz beside the cross-Gram build of the inducing-point path); None while the engine is in safe mode, inside a layer
+        pipeline stage, or when disabled (GPAR_SIDE_STREAM=0)."""
+        if getattr(self._tls, "safe", False) or getattr(self._tls, "pipe_depth", 0) or os.environ.get("GPAR_SIDE_STREAM", "1") == "0":
+            return None
+        return _device_streams(self.device, 1)[0]
+
     def worker_streams(self, depth=None):
         """The same streams, for callers that drive them from separate host threads (GPARRegressor.fit trains
         independent layers concurrently).  Empty when disabled (GPAR_FIT_THREADS=0/1)."""

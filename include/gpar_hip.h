@@ -117,6 +117,11 @@ typedef struct {
  *                           entries on, default 2^20; summation order differs from the interpreter's: agreement to rounding.)
  *   gpar_jit_stats          kernels compiled / compilations failed / structures cached so far in this process. */
 int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char* arch, char* log, int log_len);
+/* Creates NOW what the library otherwise creates at first use on the device that owns `stream`: the look-ahead side stream paired
+ * with `stream`, the event ring, the kernels' dynamic-LDS attributes (not the profile hook's events: profiling is not capturable).  After it no entry point called
+ * on `stream` creates a HIP object, so a sequence of calls can be captured into a hipGraph (a run-time compiled
+ * kernel structure must have been launched once before the capture).  Optional: everything still initialises lazily without it. */
+int gpar_init(void* stream);
 int gpar_jit_stats(int* compiled, int* failures, int* cached);
 
 int gpar_abi_version(void);

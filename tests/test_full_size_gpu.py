@@ -331,3 +331,46 @@ def test_two_processes_on_one_gpu_complete_their_handoffs(hip, tmp_path):
         assert all(c in (0, -77) for c in r["codes"]), r
         assert r["same"], r
     assert results[0]["checksum"] == pytest.approx(results[1]["checksum"], rel=1e-12)
+
+
+def test_factorisation_can_be_captured_into_a_graph_after_gpar_init(hip):
+    """the boundary must be usable under hipGraph capture.  `gpar_init(stream)` creates the library's lazily
+    created state (look-ahead side stream, events, kernel attributes) up front; a factorisation with look-ahead - two streams, event
+    fork / join - is then captured on torch's capture stream and replayed: same bits as the eager call, every replay."""
+    import ctypes
+
+    from gpar_amd import _lib
+    from gpar_amd import hip as H
+
+    dev = hip.device
+    n = 5200   # look-ahead active (n >= 4608), a ragged last panel
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(n, 3, generator=g, dtype=torch.float64).to(dev)
+    K = torch.exp(-0.5 * torch.cdist(x, x) ** 2 / 0.25)
+    K.diagonal().add_(0.1)
+    eager = H.alloc_matrix(n, n, dev)
+    eager.copy_(K)
+    logdet_e, info = H.potrf_(eager)
+    assert int(info.item()) == 0
+    A = H.alloc_matrix(n, n, dev)
+    logdet = torch.zeros(1, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        assert lib.gpar_init(ctypes.c_void_p(side.cuda_stream)) == 0
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            A.copy_(K)
+            logdet.zero_()
+            info.zero_()
+            H.potrf_(A, logdet=logdet, info=info)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for _ in range(3):
+        A.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        assert float(logdet) == float(logdet_e)
+        assert torch.equal(torch.tril(A), torch.tril(eager))
