@@ -78,7 +78,7 @@ extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const
                                                               double* __restrict__ K, int ldk, int flags,
                                                               const double* __restrict__ diag_add, double diag_const,
                                                               const double* __restrict__ row_scale, int sym, long long batch_z,
-                                                              long long batch_k) {
+                                                              long long batch_k, int strip) {
     __shared__ __attribute__((aligned(32))) double gsm[2 * DZ * GRAM_LD];
     __shared__ __attribute__((aligned(32))) double tab[GRAM_TAB_DOUBLES];
     z1 += (size_t)blockIdx.z * batch_z;
@@ -163,7 +163,10 @@ static std::string gram_jit_source(const gpar_kspec_t& ks, int dz, int strip) {
     std::string o = GRAM_JIT_PRELUDE;
     o += GRAM_MATH_SRC;
     o += "\nconstexpr int DZ = " + std::to_string(dz > 0 ? dz : 1) + ";\nconstexpr int DZ_LOAD = " + std::to_string(dz) + ";\n";
-    o += "constexpr int STRIP = " + std::to_string(strip) + ";\n";
+    // (the strip length is a kernel argument: it only bounds a loop, and as a constant every problem size that picks another
+    // length would compile the structure again - 0.4 s each, which showed in the first predict / fit of a run)
+    (void)strip;
+    o += "#define STRIP strip\n";
     o += "constexpr bool PREFETCH = true;\n";
     o += R"GJ(
 // One workgroup = one strip of up to STRIP consecutive 64 x 64 tiles of a tile row (blockIdx.y = tile row, blockIdx.x = strip;
@@ -197,7 +200,7 @@ extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const
                                                               double* __restrict__ K, int ldk, int flags,
                                                               const double* __restrict__ diag_add, double diag_const,
                                                               const double* __restrict__ row_scale, int sym, long long batch_z,
-                                                              long long batch_k) {
+                                                              long long batch_k, int strip) {
     __shared__ __attribute__((aligned(32))) double gsm[3 * DZ * GRAM_LD];
     __shared__ __attribute__((aligned(32))) double tab[GRAM_TAB_DOUBLES];
     const int nt2 = (n2 + GRAM_T - 1) / GRAM_T;
@@ -288,6 +291,7 @@ struct GramJitArgs {
     const double* diag_add; double diag_const;
     const double* row_scale; int sym;
     long long batch_z, batch_k;
+    int strip;
 };
 
 // Problems with at least this many entries take the generated kernel (GPAR_GRAM_JIT_MIN_ENTRIES; 0: always, negative: never).
@@ -308,7 +312,7 @@ static bool gram_jit_launch(const gpar_kspec_t* ks, const double* z1, int n1, in
     const int nt1 = gpar_ceil_div(n1, GRAM_T), nt2 = gpar_ceil_div(n2, GRAM_T);
     const long long tiles = ((flags & GPAR_GRAM_LOWER) ? (long long)nt1 * (nt1 + 1) / 2 : (long long)nt1 * nt2) * grid.z;
     const int strip = gram_jit_strip(tiles, dz);
-    hipFunction_t fn = jit_get(JIT_GRAM, *ks, dz, strip, "gram_jit", [&]() { return gram_jit_source(*ks, dz, strip); });
+    hipFunction_t fn = jit_get(JIT_GRAM, *ks, dz, strip > 0 ? 1 : 0, "gram_jit", [&]() { return gram_jit_source(*ks, dz, strip); });
     if (!fn) return false;
     if (strip <= 0) {
         // (the interpreter's own grid, as passed in)
@@ -319,9 +323,9 @@ static bool gram_jit_launch(const gpar_kspec_t* ks, const double* z1, int n1, in
     } else {
         grid = dim3(gpar_ceil_div(nt2, strip), nt1, grid.z);
     }
-    GramJitArgs a{*ks, z1, n1, ldz1, z2, n2, ldz2, K, ldk, flags, diag_add, diag_const, row_scale, sym, batch_z, batch_k};
+    GramJitArgs a{*ks, z1, n1, ldz1, z2, n2, ldz2, K, ldk, flags, diag_add, diag_const, row_scale, sym, batch_z, batch_k, strip};
     void* params[] = {&a.ks, &a.z1, &a.n1, &a.ldz1, &a.z2, &a.n2, &a.ldz2, &a.K, &a.ldk, &a.flags, &a.diag_add, &a.diag_const,
-                      &a.row_scale, &a.sym, &a.batch_z, &a.batch_k};
+                      &a.row_scale, &a.sym, &a.batch_z, &a.batch_k, &a.strip};
     return hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, 256, 1, 1, 0, stream, params, nullptr) == hipSuccess;
 }
 
