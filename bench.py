@@ -236,7 +236,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
             "traffic": pmc_traffic(n, m, p),
-            "traffic_source": "profiles/r02_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)",
+            "traffic_source": "profiles/r03_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)",
             "launches": launches.value,
             "flop_per_launch": flops.value / launches.value,
             "avg_launch_ms": ms.value / launches.value,
@@ -335,14 +335,26 @@ def relaunch(gpus):
     os.execve(sys.executable, cmd, env)
 
 
+def _gemm_source_sha():
+    import hashlib
+
+    with open(os.path.join(ROOT, "gpar_amd", "csrc", "gemm_f64.h"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def pmc_traffic(n, m, p):
     """HBM bytes per trailing-SYRK launch from the committed PMC passes of this very workload (null for any other
-    workload: counters cannot be collected from inside the timed process)."""
-    path = os.path.join(ROOT, "profiles", "r02_bench_pmc_traffic.json")
+    workload: counters cannot be collected from inside the timed process) - and null if the kernel's source has changed
+    since those passes were taken (tools/refresh_profiles.sh stamps them with a hash of csrc/gemm_f64.h), so that a stale
+    figure is never reported beside a new kernel."""
+    path = os.path.join(ROOT, "profiles", "r03_bench_pmc_traffic.json")
     if (n, m, p) != (16384, 4, 8) or not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f).get("traffic_bytes_per_launch")
+        rec = json.load(f)
+    if rec.get("gemm_source_sha16") != _gemm_source_sha():
+        return None
+    return rec.get("traffic_bytes_per_launch")
 
 
 def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=20, num_samples=100, n_star=2048):

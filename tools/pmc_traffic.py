@@ -37,6 +37,7 @@ def main():
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 0 --no-extras --no-cpu`",
         "kernel": "gpar::gemm_f64_kernel<false, true, 1, 128> + <false, true, 1, 64> (all trailing-update launches of the timed, lock-step evaluation: gpar_potrf_batch)",
         "launches": n,
+        "gemm_source_sha16": __import__("hashlib").sha256(open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "gpar_amd", "csrc", "gemm_f64.h"), "rb").read()).hexdigest()[:16],
         "fetch_bytes_per_launch_x2_corrected": fetch_b, "fetch_bytes_per_launch_raw": fetch_b / 2,
         "write_bytes_per_launch": write_b,
         "traffic_bytes_per_launch": fetch_b + write_b,

@@ -1,7 +1,7 @@
-# rocprofv3 kernel statistics of the BASELINE configs (run through gpurun):  bash tools/profile_configs.sh r02 C2 C4 C5
+# rocprofv3 kernel statistics of the BASELINE configs (run through gpurun):  bash tools/profile_configs.sh r03 C2 C4 C5
 # Summaries land in gpurun_out/<tag>_<config>_kernel_stats.txt; copy them to profiles/.
 set -u
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 CONFIGS=${@:-C2 C4 C5}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
