@@ -42,6 +42,8 @@ CALL_TIME = [
     ("GPAR_FIT_THREADS", "1"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "0"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "-1"),
+    ("GPAR_GRAD_JIT_MIN_ENTRIES", "0"),
+    ("GPAR_GRAD_JIT_MIN_ENTRIES", "-1"),
 ]
 CACHED = [("GPAR_GEMM_HALF_TILES", "0"), ("GPAR_GEMM_HALF_TILES", "100000"), ("GPAR_GEMM_MIXED_TAIL", "0")]
 
