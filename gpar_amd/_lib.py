@@ -72,6 +72,7 @@ SIGNATURES = {
     "gpar_sizeof_kspec": (ctypes.c_size_t, []),
     "gpar_jit_compile_check": (_c_int, [_c_int, ctypes.POINTER(KSpec), _c_int, ctypes.c_char_p, ctypes.c_char_p, _c_int]),
     "gpar_init": (_c_int, [_ptr]),
+    "gpar_jit_prepare": (_c_int, [_c_int, ctypes.POINTER(KSpec), _c_int, _ptr]),
     "gpar_jit_stats": (_c_int, [ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "gpar_featurize": (_c_int, [ctypes.POINTER(FSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "gpar_gram": (

@@ -262,24 +262,16 @@ int gpar_init(void* stream) {
 }
 
 // ---- run-time specialisation (jit.h) ----------------------------------------------------------------------------------
+static bool jit_request(int kind, const gpar_kspec_t& ks, int dz, int& jkind, int& extra, std::string& entry, std::string& source, bool want_source);
+
 int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char* arch, char* log, int log_len) {
     GPAR_API_GUARD_NOSTREAM;
     if (!ks || !arch || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS || dz < 0 ||
         dz > GPAR_MAX_DIMS)
         return GPAR_ARG_ERROR(1);
     std::string source, entry;
-    if (kind == JIT_GRAM) {
-        source = gram_jit_source(*ks, dz, gram_jit_strip(1 << 20, dz));   // the shape a large problem gets
-        entry = "gram_jit";
-    } else if (kind == JIT_GRAD || kind == JIT_GRAD + 10 || kind == JIT_GRAD + 20 || kind == JIT_GRAD + 30) {
-        // 1: symmetric weights; 11: rectangular; 21 / 31: the same with frequency derivatives (periodic features)
-        source = grad_jit_source(*ks, dz, (kind / 10) & 1, kind >= 20);
-        entry = "gram_grad_jit";
-    } else if (kind == JIT_INPUT_GRAD || kind == JIT_INPUT_GRAD + 10) {
-        source = input_grad_jit_source(*ks, dz, kind / 10);
-        entry = "gram_input_grad_jit";
-    }
-    else return GPAR_ARG_ERROR(2);
+    int jkind = 0, extra = 0;
+    if (!jit_request(kind, *ks, dz, jkind, extra, entry, source, true)) return GPAR_ARG_ERROR(2);
     std::string code, text;
     const bool ok = jit_compile(source, entry.c_str(), arch, code, text);
     if (log && log_len > 0) {
@@ -288,6 +280,55 @@ int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char*
         log[n] = '\0';
     }
     return ok ? (int)code.size() : -1;
+}
+
+// (kind, structure) -> what the launch paths would ask jit_get for: cache key ingredients, entry point, source
+static bool jit_request(int kind, const gpar_kspec_t& ks, int dz, int& jkind, int& extra, std::string& entry, std::string& source, bool want_source) {
+    if (kind == JIT_GRAM) {
+        const int strip = gram_jit_strip(1 << 20, dz);
+        jkind = JIT_GRAM; extra = strip > 0 ? 1 : 0; entry = "gram_jit";
+        if (want_source) source = gram_jit_source(ks, dz, strip);
+    } else if (kind == JIT_GRAD || kind == JIT_GRAD + 10 || kind == JIT_GRAD + 20 || kind == JIT_GRAD + 30) {
+        const int mode = (kind / 10) & 1, has_zd = kind >= 20;
+        jkind = JIT_GRAD; extra = 100 + mode * 2 + has_zd; entry = "gram_grad_jit";
+        if (want_source) source = grad_jit_source(ks, dz, mode, has_zd);
+    } else if (kind == JIT_INPUT_GRAD || kind == JIT_INPUT_GRAD + 10) {
+        jkind = JIT_INPUT_GRAD; extra = 200 + kind / 10; entry = "gram_input_grad_jit";
+        if (want_source) source = input_grad_jit_source(ks, dz, kind / 10);
+    } else {
+        return false;
+    }
+    return true;
+}
+
+// Compile the kernel of `kind` for this structure NOW if it is not cached yet, on the calling thread and OUTSIDE the library's
+// mutex: a host that knows which structures a model will need (all layers of a GPARRegressor) calls this from several threads at
+// once, so that p structures cost one compilation time instead of p, and no compilation happens inside a timed or pipelined
+// evaluation (where it would also hold the mutex every other thread's launches need).  Returns 0 (ready), 1 (compilation failed:
+// the interpreter will be used) or an argument error.
+int gpar_jit_prepare(int kind, const gpar_kspec_t* ks, int dz, void* stream) {
+    if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS || dz < 0 || dz > GPAR_MAX_DIMS)
+        return GPAR_ARG_ERROR(1);
+    int jkind = 0, extra = 0;
+    std::string entry, source, key, arch;
+    {
+        GPAR_API_GUARD;
+        if (!jit_request(kind, *ks, dz, jkind, extra, entry, source, false)) return GPAR_ARG_ERROR(2);
+        key = jit_key(jkind, *ks, dz, extra);
+        if (key.empty()) return -(int)hipErrorInvalidDevice;
+        auto it = g_jit.cache.find(key);
+        if (it != g_jit.cache.end()) return it->second.failed ? 1 : 0;
+        arch = jit_device_arch();
+    }
+    jit_request(kind, *ks, dz, jkind, extra, entry, source, true);
+    std::string code, log;
+    const bool ok = !arch.empty() && jit_compile(source, entry.c_str(), arch, code, log);
+    {
+        GPAR_API_GUARD;
+        auto it = g_jit.cache.find(key);   // (another thread may have been faster)
+        if (it != g_jit.cache.end()) return it->second.failed ? 1 : 0;
+        return jit_install(key, code, entry.c_str(), ok, log) ? 0 : 1;
+    }
 }
 
 int gpar_jit_stats(int* compiled, int* failures, int* cached) {

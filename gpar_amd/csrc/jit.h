@@ -86,20 +86,16 @@ static std::string jit_device_arch() {
     return std::string(prop.gcnArchName);
 }
 
-// The compiled function for (kind, structure) on the current device, or nullptr (never compiled twice: a failure is cached too).
-// `make_source` is only called on a cache miss.  Callers hold the library mutex.
-template <typename MakeSource>
-static hipFunction_t jit_get(int kind, const gpar_kspec_t& ks, int dz, int extra, const char* entry, MakeSource make_source) {
+static std::string jit_key(int kind, const gpar_kspec_t& ks, int dz, int extra) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    const std::string key = std::to_string(dev) + "#" + std::to_string(kind) + "#" + jit_signature(ks, dz, extra);
-    auto it = g_jit.cache.find(key);
-    if (it != g_jit.cache.end()) return it->second.failed ? nullptr : it->second.fn;
+    if (hipGetDevice(&dev) != hipSuccess) return "";
+    return std::to_string(dev) + "#" + std::to_string(kind) + "#" + jit_signature(ks, dz, extra);
+}
+
+// Load a compiled code object on the current device and enter it into the cache (callers hold the library mutex).
+static hipFunction_t jit_install(const std::string& key, const std::string& code, const char* entry, bool compiled_ok, const std::string& log) {
     JitEntry e;
-    std::string code, log;
-    const std::string arch = jit_device_arch();
-    if (arch.empty() || !jit_compile(make_source(), entry, arch, code, log) ||
-        hipModuleLoadData(&e.module, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.module, entry) != hipSuccess) {
+    if (!compiled_ok || hipModuleLoadData(&e.module, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.module, entry) != hipSuccess) {
         e.failed = true;
         e.fn = nullptr;
         g_jit.failures++;
@@ -109,6 +105,20 @@ static hipFunction_t jit_get(int kind, const gpar_kspec_t& ks, int dz, int extra
     }
     g_jit.cache[key] = e;
     return e.failed ? nullptr : e.fn;
+}
+
+// The compiled function for (kind, structure) on the current device, or nullptr (never compiled twice: a failure is cached too).
+// `make_source` is only called on a cache miss.  Callers hold the library mutex.
+template <typename MakeSource>
+static hipFunction_t jit_get(int kind, const gpar_kspec_t& ks, int dz, int extra, const char* entry, MakeSource make_source) {
+    const std::string key = jit_key(kind, ks, dz, extra);
+    if (key.empty()) return nullptr;
+    auto it = g_jit.cache.find(key);
+    if (it != g_jit.cache.end()) return it->second.failed ? nullptr : it->second.fn;
+    std::string code, log;
+    const std::string arch = jit_device_arch();
+    const bool ok = !arch.empty() && jit_compile(make_source(), entry, arch, code, log);
+    return jit_install(key, code, entry, ok, log);
 }
 
 }  // namespace gpar

@@ -95,6 +95,7 @@ class HipEngine:
         self._seed = int(seed)
         self._calls = 0
         self._tls = threading.local()  # per host thread: pending device-side info words of an open defer_checks() block
+        self._prepared = set()         # (kernel structure, kind) whose run-time compiled device kernel has been requested
 
     # ---- memory ----------------------------------------------------------------------------------
     def tensor(self, x):
@@ -129,6 +130,51 @@ class HipEngine:
         ck = compile_kernel(kernel, width)
         cache[width] = (stamp, ck)
         return ck
+
+    def prepare(self, kernels, rows, training=False, sparse=False, inputs=False):
+        """Compile, NOW and concurrently, the run-time specialised device kernels that evaluating (and, with `training`,
+        differentiating) layers with these `(kernel, width)` pairs on `rows` data points will ask for (csrc/jit.h): each structure
+        costs 0.3-0.6 s of hiprtc time at first use, and left to the first evaluation the p layers' structures compile one after
+        the other inside it, under the library's lock.  `gpar_jit_prepare` compiles outside the lock, one host thread per
+        structure.  `sparse`: rectangular weight passes as well; `inputs`: the input-gradient passes (joint objective, trainable
+        inducing inputs).  Does nothing for problems below the thresholds from which the generated kernels are used."""
+        import ctypes
+        from concurrent.futures import ThreadPoolExecutor
+
+        lib = _lib.load()
+        gram_min = int(os.environ.get("GPAR_GRAM_JIT_MIN_ENTRIES", str(1 << 22)))
+        grad_min = int(os.environ.get("GPAR_GRAD_JIT_MIN_ENTRIES", str(1 << 20)))
+        entries = int(rows) * int(rows)
+        todo = {}
+        for kernel, width in kernels:
+            ck = self.compile(kernel, width)
+            structure = (ck.dz, int(ck.kspec.nterms)) + tuple(
+                (int(f.type), int(f.term), int(f.off), int(f.nd)) for f in ck.kspec.factor[: int(ck.kspec.nfactors)])
+            zd = 20 if self._periodic(ck) else 0
+            kinds = []
+            if 0 <= gram_min <= entries:
+                kinds.append(0)
+            if training and 0 <= grad_min <= entries:
+                kinds.append(1 + zd)
+                if sparse:
+                    kinds.append(11 + zd)
+                if inputs and 1 <= ck.dz <= 20:
+                    kinds += [2, 12]
+            for kind in kinds:
+                if (structure, kind) not in self._prepared:
+                    todo[(structure, kind)] = (kind, ck)
+        if not todo:
+            return 0
+        stream = hip.stream_ptr(self.device)
+
+        def compile_one(item):
+            kind, ck = item
+            return lib.gpar_jit_prepare(kind, ctypes.byref(ck.kspec), ck.dz, stream)
+
+        with ThreadPoolExecutor(max_workers=min(8, len(todo))) as pool:
+            list(pool.map(compile_one, todo.values()))
+        self._prepared.update(todo)
+        return len(todo)
 
     def features(self, ck, x):
         return hip.featurize(ck, self._mat(x))

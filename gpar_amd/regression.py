@@ -8,6 +8,8 @@ to one fused device kernel, and every Gram / Cholesky / solve runs in libgpar_hi
 Hyper-parameter names, initialisations and bounds follow reference regression.py:92-180 exactly (table in
 SURVEY.md Appendix C), so `get_variables()` dictionaries are interchangeable.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -272,6 +274,7 @@ class GPARRegressor:
         eng = get_engine()
         x_dev, y_dev, w_dev = eng.tensor(self.x), eng.tensor(self.y), eng.tensor(self.w)
         y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
+        self._prepare_kernels(self.m, self.p, self.n, training=True, inputs=not fix or bool(optimise_x_ind))
 
         def train_layer(pi):
             if fix:
@@ -311,6 +314,17 @@ class GPARRegressor:
             for pi in range(self.p):
                 train_layer(pi)
 
+    def _prepare_kernels(self, m, p, rows, training=False, inputs=False):
+        """Have the engine compile the layers' run-time specialised device kernels up front and concurrently (HipEngine.prepare);
+        the layer constructors instantiate their hyper-parameters on the way, as the first evaluation would."""
+        eng = get_engine()
+        if not hasattr(eng, "prepare") or rows * rows < (1 << 20) or os.environ.get("GPAR_JIT_PREPARE", "1") == "0":
+            return
+        with torch.no_grad():
+            layers = _construct_gpar(self, self.vs, m, p).layers
+            eng.prepare([(model()[0].kernel, m + pi) for pi, model in enumerate(layers)], rows, training=training, sparse=self.sparse,
+                        inputs=inputs)
+
     def logpdf(self, x, y, w=None, sample_missing=False, posterior=False):
         """Log-density of observations under the prior (or, with `posterior`, the conditioned model).  Returns a
         numpy scalar unless x or y was a torch tensor (reference regression.py:461-506)."""
@@ -321,6 +335,7 @@ class GPARRegressor:
         m, p = x.shape[1], y.shape[1]
         if posterior and not self.is_conditioned:
             raise RuntimeError("Must condition or fit model before computing the logpdf under the posterior.")
+        self._prepare_kernels(m, p, int(x.shape[0]))
         gpar = _construct_gpar(self, self.vs, m, p)
         if posterior:
             gpar = gpar | (self.x, self.y, self.w)

@@ -117,6 +117,11 @@ typedef struct {
  *                           entries on, default 2^20; summation order differs from the interpreter's: agreement to rounding.)
  *   gpar_jit_stats          kernels compiled / compilations failed / structures cached so far in this process. */
 int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char* arch, char* log, int log_len);
+/* Compile (if not cached yet) and load the kernel of `kind` (codes as above) for this structure on the device that owns `stream`,
+ * on the calling thread and outside the library's lock: call it for all layers of a model from several host threads at once and
+ * no compilation happens inside an evaluation.  0: ready; 1: compilation failed (the interpreter will serve); < 0: argument error.
+ * [a GPARRegressor's layer structures are known when the model is built: gpar/regression.py:92-180] */
+int gpar_jit_prepare(int kind, const gpar_kspec_t* ks, int dz, void* stream);
 /* Creates NOW what the library otherwise creates at first use on the device that owns `stream`: the look-ahead side stream paired
  * with `stream`, the event ring, the kernels' dynamic-LDS attributes (not the profile hook's events: profiling is not capturable).  After it no entry point called
  * on `stream` creates a HIP object, so a sequence of calls can be captured into a hipGraph (a run-time compiled
