@@ -8,6 +8,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -62,3 +63,24 @@ def test_start_up_watchdog_ends_a_rank_whose_peers_never_arrive():
                          text=True, timeout=120)
     assert out.returncode == 3, (out.returncode, out.stderr[-1000:])
     assert "did not form" in _last_json(out.stdout)["error"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_hip_engine_agree_with_one():
+    """The multi-rank control flow on the REAL engine: `python bench.py --gpus 2` starts two ranks itself; with GPAR_BENCH_ONE_GPU=1
+    (a development mode: both ranks use GPU 0 and talk over gloo - timings mean nothing) they shard the layers of a small model,
+    all-reduce the layer log-likelihoods and run the sharded fit + predict leg; the log marginal likelihood must equal the
+    single-process value to rounding."""
+    def run(gpus, extra_env):
+        cmd = [sys.executable, BENCH, "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--rows", "1536", "--p", "4", "--no-cpu"]
+        out = subprocess.run(cmd, env=dict(_env(), **extra_env), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return _last_json(out.stdout)
+
+    one = run(1, {})
+    two = run(2, {"GPAR_BENCH_ONE_GPU": "1"})
+    assert two["n_gpus"] == 2 and two["config"]["layers_per_rank"] == [2, 2] and len(two["per_rank_busy_ms"]) == 2
+    assert abs(two["config"]["logpdf"] - one["config"]["logpdf"]) <= 1e-10 * abs(one["config"]["logpdf"])
+    for line in (one, two):   # the sharded fit (layer pi trained on rank pi mod 2, latents broadcast) and sample-parallel predict ran
+        assert "error" not in line["fit_predict"], line["fit_predict"]
+        assert line["fit_predict"]["fit_evaluations"] > 20 and np.isfinite(line["fit_predict"]["predict_mean_abs"])

@@ -12,7 +12,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_gram/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gram_kernel" in r["Kernel_Name"]:
+        if "gram_kernel" in r["Kernel_Name"] or "gram_jit" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:28s} launches {len(v):3d}  mean {sum(v)/len(v):.4g}")
