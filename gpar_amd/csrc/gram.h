@@ -13,7 +13,7 @@
 
 namespace gpar {
 
-// shared with the generated kernels (gram_jit.h), one text for both: typedefs, GRAM_T / GRAM_LD, gram_accum*, gram_exp8, gram_rq8
+// shared with the generated kernels (gram_jit.h), one text for both: typedefs, GRAM_T / GRAM_LD, gram_accum*, gram_exph8, gram_rqh8
 #define GPAR_DEVICE_CODE(...) __VA_ARGS__
 #include "gram_math.inc"
 #undef GPAR_DEVICE_CODE
@@ -101,15 +101,15 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
                     any_exp = true;
                     if (type == GPAR_K_EQ) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) expo[e] = fma(-0.5, s[e], expo[e]);
+                        for (int e = 0; e < 8; ++e) expo[e] += s[e];   // doubled exponent: gram_exph8 takes exp(-E / 2)
                     } else {   // RQ: (1 + s / 2 alpha)^-alpha = exp(-alpha log1p(s / 2 alpha))
-                        gram_rq8(s, ks.factor[f].alpha, expo, tab);
+                        gram_rqh8(s, ks.factor[f].alpha, expo, tab);
                     }
                 }
                 ++f;
             }
             if (any_exp) {
-                gram_exp8(expo, tab);
+                gram_exph8(expo, tab);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) total[e] = fma(lin[e], expo[e], total[e]);
             } else {

@@ -27,8 +27,8 @@ static_assert(GPAR_MAX_TERMS == 8 && GPAR_MAX_FACTORS == 12, "gram_jit.h mirrors
 static_assert(sizeof(gpar_factor_t) == 24 && sizeof(gpar_kspec_t) == 8 + 8 * 8 + 12 * 24, "gram_jit.h mirrors gpar_kspec_t");
 
 // Straight-line evaluation of all terms into total[8] for the micro-tile (ty, cb).  Mirrors the interpreter's order of
-// operations exactly: per term expo = sum of factor exponents (EQ: fma(-0.5, s, expo); RQ: gram_rq8), lin = coef * product of
-// linear factors, one gram_exp8 per term that has a nonlinear factor, total = fma(lin, expo, total) or total += lin.
+// operations exactly: per term expo = DOUBLED sum of factor exponents (EQ: expo += s - the first one a plain copy, 0 + s being s -; RQ: gram_rqh8), lin = coef * product of
+// linear factors, one gram_exph8 per term that has a nonlinear factor, total = fma(lin, expo, total) or total += lin.
 static std::string gram_jit_terms(const gpar_kspec_t& ks) {
     std::string o;
     int f = 0;
@@ -37,7 +37,7 @@ static std::string gram_jit_terms(const gpar_kspec_t& ks) {
         o += "        {   // term " + ts + "\n";
         o += "            double expo[8], lin[8];\n";
         o += "            _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) { expo[e] = 0.0; lin[e] = ks.coef[" + ts + "]; }\n";
-        bool any_exp = false;
+        bool any_exp = false, first_exp = true;
         while (f < ks.nfactors && ks.factor[f].term == t) {
             const gpar_factor_t& fa = ks.factor[f];
             const std::string off = std::to_string(fa.off), nd = std::to_string(fa.nd), fs = std::to_string(f);
@@ -48,14 +48,15 @@ static std::string gram_jit_terms(const gpar_kspec_t& ks) {
             } else {
                 any_exp = true;
                 o += "                gram_accum_static<" + off + ", " + nd + ", false>(Za, Zb, ty, cb, s);\n";
-                if (fa.type == GPAR_K_EQ) o += "                _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) expo[e] = fma(-0.5, s[e], expo[e]);\n";
-                else o += "                gram_rq8(s, ks.factor[" + fs + "].alpha, expo, tab);\n";
+                if (fa.type == GPAR_K_EQ) o += std::string("                _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) expo[e] ") + (first_exp ? "= s[e];\n" : "+= s[e];\n");
+                else o += "                gram_rqh8(s, ks.factor[" + fs + "].alpha, expo, tab);\n";
+                first_exp = false;
             }
             o += "            }\n";
             ++f;
         }
         if (any_exp) {
-            o += "            gram_exp8(expo, tab);\n";
+            o += "            gram_exph8(expo, tab);\n";
             o += "            _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) total[e] = fma(lin[e], expo[e], total[e]);\n";
         } else {
             o += "            _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) total[e] += lin[e];\n";
@@ -147,13 +148,15 @@ extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const
 
 // Column tiles per workgroup: a workgroup walks a strip of up to `strip` consecutive 64 x 64 tiles of one tile row (1, 2, 4 or 8:
 // part of the generated source and of the cache key).
+static int gram_jit_smax(int dz) { return dz <= 9 ? 8 : 4; }   // (1 + SMAX) panels of dz x 68 doubles: <= 44 KB
+
 static int gram_jit_strip(long long tiles, int dz) {
     if (dz > 16) return 0;   // wide kernels: one tile per workgroup (gram_jit_source_tile)
-    if (const char* e = getenv("GPAR_GRAM_JIT_STRIP")) { const int v = atoi(e); if (v >= 0 && v <= 64) return v; }
+    if (const char* e = getenv("GPAR_GRAM_JIT_STRIP")) { const int v = atoi(e); if (v >= 0 && v <= 64) return v < gram_jit_smax(dz) ? v : gram_jit_smax(dz); }
     // as long as ~2000 workgroups remain (three rounds of the chip's 768 slots).  Measured (ms; strip 1 / 2 / 4 / 8): C3 lower
     // triangle n = 16384, 8 dims 0.449 / 0.415 / 0.398 / 0.394; C4 cross 65536 x 1024, 14 dims 0.283 / 0.245 / 0.227 / 0.228;
     // C2 n = 4096, 5 dims 0.031 / 0.033 / 0.035 / 0.042.
-    int strip = 8;
+    int strip = gram_jit_smax(dz);
     while (strip > 1 && tiles / strip < 2000) strip /= 2;
     return strip;
 }
@@ -167,13 +170,14 @@ static std::string gram_jit_source(const gpar_kspec_t& ks, int dz, int strip) {
     // length would compile the structure again - 0.4 s each, which showed in the first predict / fit of a run)
     (void)strip;
     o += "#define STRIP strip\n";
-    o += "constexpr bool PREFETCH = true;\n";
+    o += "constexpr int SMAX = " + std::to_string(gram_jit_smax(dz)) + ";\n";
     o += R"GJ(
-// One workgroup = one strip of up to STRIP consecutive 64 x 64 tiles of a tile row (blockIdx.y = tile row, blockIdx.x = strip;
-// strips wholly above the diagonal of a lower-triangular build leave at once).  The row panel Za and the tables are staged
-// once per strip; the column panel of tile c + 1 is requested from global memory before tile c is computed and stored to the
-// other LDS buffer after it: a single-tile workgroup spends as long waiting for its panels (global -> LDS -> barrier, ~2 us)
-// as computing (57 vector instructions per entry: 1.6 us), and three of them per compute unit cover only half of that.
+// One workgroup = one strip of up to STRIP <= SMAX consecutive 64 x 64 tiles of a tile row (blockIdx.y = tile row, blockIdx.x = strip;
+// lower-triangular builds enumerate their strips in one dimension).  The tables, the row panel Za and ALL column panels of the
+// strip are staged up front with every load in flight at once (<= 44 KB of LDS: three workgroups per compute unit, which the
+// registers allow anyway); the tile loop then holds no load, no barrier and no wait - waves drift apart, so one wave's stores
+// drain under another's arithmetic.  (The first version double-buffered one column panel per tile: a barrier per tile and a
+// full vmcnt(0) drain of the tile's stores at each loop head; tools/exp_gram: 0.312 -> 0.301 ms at C3.)
 constexpr int PANEL = GRAM_T * DZ_LOAD;             // doubles per feature panel
 constexpr int PER_THREAD = (PANEL + 255) / 256;
 
@@ -201,7 +205,7 @@ extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const
                                                               const double* __restrict__ diag_add, double diag_const,
                                                               const double* __restrict__ row_scale, int sym, long long batch_z,
                                                               long long batch_k, int strip) {
-    __shared__ __attribute__((aligned(32))) double gsm[3 * DZ * GRAM_LD];
+    __shared__ __attribute__((aligned(32))) double gsm[(1 + SMAX) * DZ * GRAM_LD];
     __shared__ __attribute__((aligned(32))) double tab[GRAM_TAB_DOUBLES];
     const int nt2 = (n2 + GRAM_T - 1) / GRAM_T;
     int bm = blockIdx.y, bn0 = blockIdx.x * STRIP;
@@ -226,21 +230,21 @@ extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const
     double* Za = gsm;
     const int t = threadIdx.x;
     const int row0 = bm * GRAM_T;
-    double preg[PER_THREAD > 0 ? PER_THREAD : 1];
     gram_load_tables(tab, t);
-    gj_panel_load(z1, n1, ldz1, row0, t, preg);
-    gj_panel_store(Za, t, preg);
-    gj_panel_load(z2, n2, ldz2, bn0 * GRAM_T, t, preg);
-    gj_panel_store(gsm + DZ * GRAM_LD, t, preg);
+    {
+        double preg[1 + SMAX][PER_THREAD > 0 ? PER_THREAD : 1];
+        gj_panel_load(z1, n1, ldz1, row0, t, preg[0]);
+        _Pragma("unroll") for (int q = 0; q < SMAX; ++q) if (q < bn1 - bn0) gj_panel_load(z2, n2, ldz2, (bn0 + q) * GRAM_T, t, preg[1 + q]);
+        gj_panel_store(Za, t, preg[0]);
+        _Pragma("unroll") for (int q = 0; q < SMAX; ++q) if (q < bn1 - bn0) gj_panel_store(gsm + (1 + q) * DZ * GRAM_LD, t, preg[1 + q]);
+    }
     __syncthreads();
     const int tx = t & 15, ty = t >> 4;
     const bool vec = ((ldk & 1) == 0) && ((((size_t)K) & 15u) == 0);
     _Pragma("unroll 1")
     for (int bn = bn0; bn < bn1; ++bn) {
-        const double* Zb = gsm + (1 + ((bn - bn0) & 1)) * DZ * GRAM_LD;
+        const double* Zb = gsm + (1 + (bn - bn0)) * DZ * GRAM_LD;
         const int col0 = bn * GRAM_T;
-        const bool more = bn + 1 < bn1;
-        if (PREFETCH && more) gj_panel_load(z2, n2, ldz2, col0 + GRAM_T, t, preg);   // in flight under this tile's arithmetic
     _Pragma("unroll 1")
     for (int h = 0; h < 2; ++h) {
         const int cb = 32 * h + 2 * tx;
@@ -271,11 +275,6 @@ extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const
             }
         }
     }
-        if (more) {
-            if (!PREFETCH) gj_panel_load(z2, n2, ldz2, col0 + GRAM_T, t, preg);
-            gj_panel_store(gsm + (1 + ((bn + 1 - bn0) & 1)) * DZ * GRAM_LD, t, preg);
-            __syncthreads();   // the next panel is complete, and every wave is done reading this one before it is overwritten again
-        }
     }
 }
 )GJ";

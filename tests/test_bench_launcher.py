@@ -84,3 +84,44 @@ def test_two_ranks_on_the_hip_engine_agree_with_one():
     for line in (one, two):   # the sharded fit (layer pi trained on rank pi mod 2, latents broadcast) and sample-parallel predict ran
         assert "error" not in line["fit_predict"], line["fit_predict"]
         assert line["fit_predict"]["fit_evaluations"] > 20 and np.isfinite(line["fit_predict"]["predict_mean_abs"])
+
+
+_RCCL_PROBE = r"""
+import datetime, os, sys
+import torch
+import torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", sys.argv[1])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, timeout=datetime.timedelta(seconds=60), device_id=torch.device("cuda:0"))
+dev = torch.device("cuda:0")
+word = torch.full((1,), 3.25, dtype=torch.float64, device=dev)
+dist.all_reduce(word, op=dist.ReduceOp.SUM)                      # sharded_logpdf: sum of the layer log-likelihoods
+peak = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(peak, op=dist.ReduceOp.MAX)                      # bench.py: max over ranks of the elapsed time
+col = torch.arange(5.0, dtype=torch.float64, device=dev).reshape(5, 1)
+dist.broadcast(col, src=0)                                       # dependent regimes: the forwarded column
+send = torch.arange(6.0, dtype=torch.float64, device=dev)
+recv = [torch.empty_like(send)]
+dist.all_gather(recv, send)                                      # packed factors / samples
+dist.barrier()
+torch.cuda.synchronize()
+assert float(word) == 3.25 and float(peak) == 1.5 and torch.equal(recv[0], send) and float(col.sum()) == 10.0
+dist.destroy_process_group()
+print("rccl ok")
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_forms_a_communicator_and_carries_fp64_on_this_box(tmp_path):
+    """What `bench.py --gpus N` and gpar_amd/parallel.py ask of RCCL, on the one GPU of the test box: a communicator bound to the
+    device at init (`device_id=`), and the collectives they issue on fp64 device tensors.  A world of one rank moves no data
+    between GPUs - it shows that the backend loads and accepts these calls (the N > 1 control flow runs over gloo above and in
+    tests/test_distributed.py); the 8-GPU run itself is the driver's."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    script = tmp_path / "rccl_probe.py"
+    script.write_text(_RCCL_PROBE)
+    out = subprocess.run([sys.executable, str(script), str(port)], env=_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-3000:]
