@@ -286,7 +286,8 @@ int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char*
 static bool jit_request(int kind, const gpar_kspec_t& ks, int dz, int& jkind, int& extra, std::string& entry, std::string& source, bool want_source) {
     if (kind == JIT_GRAM) {
         const int strip = gram_jit_strip(1 << 20, dz);
-        jkind = JIT_GRAM; extra = strip > 0 ? 1 : 0; entry = "gram_jit";
+        if (strip <= 0) return false;   // wide structure: there is no generated Gram kernel (gram_jit.h)
+        jkind = JIT_GRAM; extra = 1; entry = "gram_jit";
         if (want_source) source = gram_jit_source(ks, dz, strip);
     } else if (kind == JIT_GRAD || kind == JIT_GRAD + 10 || kind == JIT_GRAD + 20 || kind == JIT_GRAD + 30) {
         const int mode = (kind / 10) & 1, has_zd = kind >= 20;

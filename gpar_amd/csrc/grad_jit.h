@@ -217,10 +217,13 @@ struct GradJitArgs {
     double* partial;
 };
 
-// Problems with at least this many weight entries take the generated kernel (GPAR_GRAD_JIT_MIN_ENTRIES; 0: always, negative: never).
+// Launches of at least this many weight entries take the generated kernel (GPAR_GRAD_JIT_MIN_ENTRIES; 0: always, negative: never).
+// The generated passes are 4-5x faster than the interpreter (no accumulator spills), ~1.1 ms per evaluation and layer at 2^24
+// entries (n = 4096): the reference's default training run (1000 iterations) repays 0.5 s of compilation several times over from
+// there on; at n = 1024 it would cost a 0.06 s fit 0.5 s.
 static long long grad_jit_min_entries() {
     const char* e = getenv("GPAR_GRAD_JIT_MIN_ENTRIES");
-    return e ? atoll(e) : (1LL << 20);
+    return e ? atoll(e) : (1LL << 24);
 }
 
 static bool grad_jit_launch(const gpar_kspec_t* ks, const double* z1, const double* zd1, int n1, int ldz1, const double* z2, const double* zd2,

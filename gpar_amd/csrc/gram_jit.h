@@ -66,103 +66,27 @@ static std::string gram_jit_terms(const gpar_kspec_t& ks) {
     return o;
 }
 
-// Wide kernels (more than 16 feature dims): one 64 x 64 tile per workgroup, exactly the interpreter's shape.  Their arithmetic per
-// tile is several times a narrow kernel's, so the panel staging is a small share, and they have no registers to spare for a strip
-// loop (42 dims: 256 registers as it is).
-static std::string gram_jit_source_tile(const gpar_kspec_t& ks, int dz) {
-    std::string o = GRAM_JIT_PRELUDE;
-    o += GRAM_MATH_SRC;
-    o += "\nconstexpr int DZ = " + std::to_string(dz > 0 ? dz : 1) + ";\nconstexpr int DZ_LOAD = " + std::to_string(dz) + ";\n";
-    o += R"GJ(
-extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const double* __restrict__ z1, int n1, int ldz1,
-                                                              const double* __restrict__ z2, int n2, int ldz2,
-                                                              double* __restrict__ K, int ldk, int flags,
-                                                              const double* __restrict__ diag_add, double diag_const,
-                                                              const double* __restrict__ row_scale, int sym, long long batch_z,
-                                                              long long batch_k, int strip) {
-    __shared__ __attribute__((aligned(32))) double gsm[2 * DZ * GRAM_LD];
-    __shared__ __attribute__((aligned(32))) double tab[GRAM_TAB_DOUBLES];
-    z1 += (size_t)blockIdx.z * batch_z;
-    z2 += (size_t)blockIdx.z * batch_z;
-    K += (size_t)blockIdx.z * batch_k;
-    int bm = blockIdx.y, bn = blockIdx.x;
-    if (flags & GPAR_GRAM_LOWER) {
-        const int tile = blockIdx.x;
-        bm = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
-        while ((bm + 1) * (bm + 2) / 2 <= tile) ++bm;
-        while (bm * (bm + 1) / 2 > tile) --bm;
-        bn = tile - bm * (bm + 1) / 2;
-    }
-    double* Za = gsm;
-    double* Zb = gsm + DZ * GRAM_LD;
-    const int t = threadIdx.x;
-    const int row0 = bm * GRAM_T, col0 = bn * GRAM_T;
-    gram_load_tables(tab, t);
-    for (int idx = t; idx < GRAM_T * DZ_LOAD; idx += 256) {
-        const int r = idx / DZ_LOAD, d = idx - r * DZ_LOAD;
-        Za[d * GRAM_LD + r] = (row0 + r < n1) ? z1[(size_t)(row0 + r) * ldz1 + d] : 0.0;
-        Zb[d * GRAM_LD + r] = (col0 + r < n2) ? z2[(size_t)(col0 + r) * ldz2 + d] : 0.0;
-    }
-    __syncthreads();
-    const int tx = t & 15, ty = t >> 4;
-    const bool vec = ((ldk & 1) == 0) && ((((size_t)K) & 15u) == 0);
-    _Pragma("unroll 1")
-    for (int h = 0; h < 2; ++h) {
-        const int cb = 32 * h + 2 * tx;
-        double total[8];
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) total[e] = 0.0;
-        // (the row features do not depend on the pass h; kept in registers across both passes they would be 8 registers per dim:
-        // the row index is made opaque inside the loop, so that each pass reads its features again)
-        int ty_h = ty;
-        asm volatile("" : "+v"(ty_h));
-#define ty ty_h
-)GJ";
-    o += gram_jit_terms(ks);
-    o += R"GJ(
-#undef ty
-        _Pragma("unroll")
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + 4 * ty + i;
-            if (row >= n1) continue;
-            const int col = col0 + cb;
-            double v0 = total[2 * i], v1 = total[2 * i + 1];
-            if (row_scale) { const double rs = row_scale[row]; v0 *= rs; v1 *= rs; }
-            if (sym) {
-                const double dadd = (diag_add ? diag_add[row] : 0.0) + diag_const;
-                if (col == row) v0 += dadd;
-                if (col + 1 == row) v1 += dadd;
-            }
-            double* out = K + (size_t)row * ldk + col;
-            if (vec && col + 1 < n2) {
-                *reinterpret_cast<g_d2*>(out) = g_d2{v0, v1};
-            } else {
-                if (col < n2) out[0] = v0;
-                if (col + 1 < n2) out[1] = v1;
-            }
-        }
-    }
-}
-)GJ";
-    return o;
-}
-
-// Column tiles per workgroup: a workgroup walks a strip of up to `strip` consecutive 64 x 64 tiles of one tile row (1, 2, 4 or 8:
-// part of the generated source and of the cache key).
+// Generated Gram kernels exist for NARROW structures only (at most GRAM_JIT_MAX_DZ feature dims).  A wide one (C5's last layer: 42
+// dims, rq + eq.eq + linear + rq) is bound by its ~190 arithmetic instructions per entry either way - generated 0.303 ms,
+// interpreter 0.295 ms at n = 8192 (profiles/r03_gram_configs*.jsonl) - so its 0.5 s of compilation would buy nothing.
+constexpr int GRAM_JIT_MAX_DZ = 16;
 static int gram_jit_smax(int dz) { return dz <= 9 ? 8 : 4; }   // (1 + SMAX) panels of dz x 68 doubles: <= 44 KB
 
+// Column tiles per workgroup: a workgroup walks a strip of up to `strip` consecutive 64 x 64 tiles of one tile row (a kernel
+// argument; at most SMAX, which is part of the generated source and a function of dz).
 static int gram_jit_strip(long long tiles, int dz) {
-    if (dz > 16) return 0;   // wide kernels: one tile per workgroup (gram_jit_source_tile)
-    if (const char* e = getenv("GPAR_GRAM_JIT_STRIP")) { const int v = atoi(e); if (v >= 0 && v <= 64) return v < gram_jit_smax(dz) ? v : gram_jit_smax(dz); }
-    // as long as ~2000 workgroups remain (three rounds of the chip's 768 slots).  Measured (ms; strip 1 / 2 / 4 / 8): C3 lower
-    // triangle n = 16384, 8 dims 0.449 / 0.415 / 0.398 / 0.394; C4 cross 65536 x 1024, 14 dims 0.283 / 0.245 / 0.227 / 0.228;
-    // C2 n = 4096, 5 dims 0.031 / 0.033 / 0.035 / 0.042.
+    if (dz > GRAM_JIT_MAX_DZ) return 0;
+    if (const char* e = getenv("GPAR_GRAM_JIT_STRIP")) { const int v = atoi(e); if (v >= 1 && v <= 64) return v < gram_jit_smax(dz) ? v : gram_jit_smax(dz); }
+    // as long as ~2000 workgroups remain (three rounds of the chip's 768 slots).  Measured with the first version of the strip
+    // kernel (ms; strip 1 / 2 / 4 / 8): C3 lower triangle n = 16384, 8 dims 0.449 / 0.415 / 0.398 / 0.394; C4 cross 65536 x 1024,
+    // 14 dims 0.283 / 0.245 / 0.227 / 0.228; C2 n = 4096, 5 dims 0.031 / 0.033 / 0.035 / 0.042.
     int strip = gram_jit_smax(dz);
     while (strip > 1 && tiles / strip < 2000) strip /= 2;
     return strip;
 }
 
 static std::string gram_jit_source(const gpar_kspec_t& ks, int dz, int strip) {
-    if (strip <= 0) return gram_jit_source_tile(ks, dz);
+    if (strip <= 0) return std::string();   // (wide structure: no generated kernel)
     std::string o = GRAM_JIT_PRELUDE;
     o += GRAM_MATH_SRC;
     o += "\nconstexpr int DZ = " + std::to_string(dz > 0 ? dz : 1) + ";\nconstexpr int DZ_LOAD = " + std::to_string(dz) + ";\n";
@@ -293,12 +217,13 @@ struct GramJitArgs {
     int strip;
 };
 
-// Problems with at least this many entries take the generated kernel (GPAR_GRAM_JIT_MIN_ENTRIES; 0: always, negative: never).
-// Below it a launch is over in microseconds either way, and a model with many distinct small layers (the test-suite's) would
-// pay ~0.3-1 s of compilation per structure for nothing.
+// Launches of at least this many entries take the generated kernel (GPAR_GRAM_JIT_MIN_ENTRIES; 0: always, negative: never).
+// A structure costs 0.3-0.6 s of hiprtc time once per process; per launch the generated kernel saves ~30 % of a Gram build that
+// is 0.03 ms at n = 4096 and 0.46 ms at n = 16384.  From 2^26 entries (n = 8192 symmetric, C4's 65536 x 1024 cross-Gram) a few
+// hundred evaluations - one training run - repay it; below, the interpreter's microseconds are not worth half a second.
 static long long gram_jit_min_entries() {
     const char* e = getenv("GPAR_GRAM_JIT_MIN_ENTRIES");
-    return e ? atoll(e) : (1LL << 22);
+    return e ? atoll(e) : (1LL << 26);
 }
 
 // Launch the generated kernel if there is (or can be) one for this structure; false: the caller falls back to the interpreter.
@@ -311,11 +236,10 @@ static bool gram_jit_launch(const gpar_kspec_t* ks, const double* z1, int n1, in
     const int nt1 = gpar_ceil_div(n1, GRAM_T), nt2 = gpar_ceil_div(n2, GRAM_T);
     const long long tiles = ((flags & GPAR_GRAM_LOWER) ? (long long)nt1 * (nt1 + 1) / 2 : (long long)nt1 * nt2) * grid.z;
     const int strip = gram_jit_strip(tiles, dz);
-    hipFunction_t fn = jit_get(JIT_GRAM, *ks, dz, strip > 0 ? 1 : 0, "gram_jit", [&]() { return gram_jit_source(*ks, dz, strip); });
+    if (strip <= 0) return false;   // wide structure: the interpreter
+    hipFunction_t fn = jit_get(JIT_GRAM, *ks, dz, 1, "gram_jit", [&]() { return gram_jit_source(*ks, dz, strip); });
     if (!fn) return false;
-    if (strip <= 0) {
-        // (the interpreter's own grid, as passed in)
-    } else if (flags & GPAR_GRAM_LOWER) {
+    if (flags & GPAR_GRAM_LOWER) {
         // strips of the lower triangle: full groups of `strip` rows with g + 1 strips per row, then the rows of a last, partial group
         const int full = nt1 / strip, rest = nt1 - full * strip;
         grid = dim3((unsigned)((long long)strip * full * (full + 1) / 2 + (long long)rest * (full + 1)), 1, grid.z);

@@ -54,6 +54,11 @@ class HandOffTimeoutError(ArithmeticError):
 
 
 _HW_QUEUES = None
+# defaults of the library's thresholds (csrc/gram_jit.h, csrc/grad_jit.h): entries per launch from which kernels compiled at run time
+# for the layer's structure are used, and the widest structure that has a generated Gram kernel
+GRAM_JIT_MIN_ENTRIES = 1 << 26
+GRAD_JIT_MIN_ENTRIES = 1 << 24
+GRAM_JIT_MAX_DZ = 16
 
 
 def _hardware_queues():
@@ -142,8 +147,8 @@ class HipEngine:
         from concurrent.futures import ThreadPoolExecutor
 
         lib = _lib.load()
-        gram_min = int(os.environ.get("GPAR_GRAM_JIT_MIN_ENTRIES", str(1 << 22)))
-        grad_min = int(os.environ.get("GPAR_GRAD_JIT_MIN_ENTRIES", str(1 << 20)))
+        gram_min = int(os.environ.get("GPAR_GRAM_JIT_MIN_ENTRIES", str(GRAM_JIT_MIN_ENTRIES)))
+        grad_min = int(os.environ.get("GPAR_GRAD_JIT_MIN_ENTRIES", str(GRAD_JIT_MIN_ENTRIES)))
         entries = int(rows) * int(rows)
         todo = {}
         for kernel, width in kernels:
@@ -152,7 +157,7 @@ class HipEngine:
                 (int(f.type), int(f.term), int(f.off), int(f.nd)) for f in ck.kspec.factor[: int(ck.kspec.nfactors)])
             zd = 20 if self._periodic(ck) else 0
             kinds = []
-            if 0 <= gram_min <= entries:
+            if 0 <= gram_min <= entries and ck.dz <= GRAM_JIT_MAX_DZ:
                 kinds.append(0)
             if training and 0 <= grad_min <= entries:
                 kinds.append(1 + zd)

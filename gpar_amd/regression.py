@@ -318,7 +318,7 @@ class GPARRegressor:
         """Have the engine compile the layers' run-time specialised device kernels up front and concurrently (HipEngine.prepare);
         the layer constructors instantiate their hyper-parameters on the way, as the first evaluation would."""
         eng = get_engine()
-        if not hasattr(eng, "prepare") or rows * rows < (1 << 20) or os.environ.get("GPAR_JIT_PREPARE", "1") == "0":
+        if not hasattr(eng, "prepare") or rows * rows < (1 << 22) or os.environ.get("GPAR_JIT_PREPARE", "1") == "0":   # (prepare applies the thresholds)
             return
         with torch.no_grad():
             layers = _construct_gpar(self, self.vs, m, p).layers

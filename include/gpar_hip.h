@@ -107,14 +107,16 @@ typedef struct {
  * A layer's kernel STRUCTURE is fixed when the model is built (gpar/regression.py:92-180 decides the term list once per layer);
  * for large problems gpar_gram compiles a kernel for that structure with hiprtc on first use (values - coefficients, RQ shapes -
  * stay arguments: training never recompiles) and caches it per device; small problems and any compilation failure use the
- * ahead-of-time interpreter, which computes the same bits.  Environment: GPAR_GRAM_JIT_MIN_ENTRIES (default 2^22 entries per
- * launch; 0 = always, negative = never).
+ * ahead-of-time interpreter, which computes the same bits.  Environment: GPAR_GRAM_JIT_MIN_ENTRIES (default 2^26 entries per
+ * launch - where a training run repays the 0.3-0.6 s a structure costs; 0 = always, negative = never).  Structures with more
+ * than 16 feature dims have no generated Gram kernel (they are bound by their arithmetic either way).
  *   gpar_jit_compile_check  compiles (does not load) the kernel of `kind` for `ks` / `dz` and architecture `arch` (e.g. "gfx950"):
- *                           returns the code-object size, or -1 with the compiler's log in `log`; needs no GPU.  kind 0: Gram;
+ *                           returns the code-object size, or -1 with the compiler's log in `log`; needs no GPU.  kind 0: Gram
+ *                           (an argument error for a structure with more than 16 feature dims);
  *                           1 / 11: parameter-gradient pass with symmetric / rectangular weights (21 / 31: with frequency
  *                           derivatives of periodic features); 2 / 12: input-gradient pass, symmetric / rectangular weights.
  *                           (gpar_gram_grad* / gpar_gram_input_grad use generated kernels from GPAR_GRAD_JIT_MIN_ENTRIES weight
- *                           entries on, default 2^20; summation order differs from the interpreter's: agreement to rounding.)
+ *                           entries on, default 2^24; summation order differs from the interpreter's: agreement to rounding.)
  *   gpar_jit_stats          kernels compiled / compilations failed / structures cached so far in this process. */
 int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char* arch, char* log, int log_len);
 /* Compile (if not cached yet) and load the kernel of `kind` (codes as above) for this structure on the device that owns `stream`,
