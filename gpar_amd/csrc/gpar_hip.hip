@@ -265,7 +265,7 @@ int gpar_init(void* stream) {
 static bool jit_request(int kind, const gpar_kspec_t& ks, int dz, int& jkind, int& extra, std::string& entry, std::string& source, bool want_source);
 
 int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char* arch, char* log, int log_len) {
-    GPAR_API_GUARD_NOSTREAM;
+    // (no library lock: nothing shared is touched - source generation and hiprtc only -, and several threads may check at once)
     if (!ks || !arch || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS || dz < 0 ||
         dz > GPAR_MAX_DIMS)
         return GPAR_ARG_ERROR(1);
