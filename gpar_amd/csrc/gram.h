@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
             const int col = col0 + cb;
             double v0 = total[2 * i], v1 = total[2 * i + 1];
             if (row_scale) { const double rs = row_scale[row]; v0 *= rs; v1 *= rs; }
-            if (sym) {
+            if (sym && col0 == row0) {   // (the noise diagonal only exists in diagonal tiles: a workgroup-uniform branch)
                 const double dadd = (diag_add ? diag_add[row] : 0.0) + diag_const;
                 if (col == row) v0 += dadd;
                 if (col + 1 == row) v1 += dadd;

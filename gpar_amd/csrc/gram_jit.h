@@ -178,6 +178,9 @@ extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const
     // (the row features - Za at 4 ty - do not depend on the pass h or on the tile: up to 16 dims stay in registers across the strip)
     o += gram_jit_terms(ks);
     o += R"GJ(
+        // (the noise diagonal only exists in the diagonal tiles of a symmetric build: everywhere else its row load, two compares
+        // and two selects per pair of entries are skipped by a workgroup-uniform branch)
+        const bool diag_tile = sym && col0 == row0;
         _Pragma("unroll")
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + 4 * ty + i;
@@ -185,7 +188,7 @@ extern "C" __global__ __launch_bounds__(256, 2) void gram_jit(gj_kspec ks, const
             const int col = col0 + cb;
             double v0 = total[2 * i], v1 = total[2 * i + 1];
             if (row_scale) { const double rs = row_scale[row]; v0 *= rs; v1 *= rs; }
-            if (sym) {
+            if (diag_tile) {
                 const double dadd = (diag_add ? diag_add[row] : 0.0) + diag_const;
                 if (col == row) v0 += dadd;
                 if (col + 1 == row) v1 += dadd;
