@@ -1,0 +1,127 @@
+"""Seeded random differential test of the public API: HIP path (through the C ABI) against
+
+  (1) `oracle.gpar_ref.gpar_logpdf` - the restatement that shares nothing with the product - for the prior log-density, and
+  (2) the product's host algebra on the CPU oracle engine for posterior log-density and replace-mode predictions,
+
+over randomly drawn model options (every kernel switch of gpar/regression.py:264-286, markov orders, tied scales, inducing
+points with each approximation), ragged sizes (n = 2 .. 160, m = 1 .. 3, p = 1 .. 4), random missing patterns (including a
+fully observed and a nearly empty output) and random weights.  The cases are fixed by their seeds; what the parametrised parity
+tests cover by design, this covers by accident."""
+import numpy as np
+import pytest
+
+from .conftest import make_engine, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n, m, p = int(rng.integers(2, 161)), int(rng.integers(1, 4)), int(rng.integers(1, 5))
+    kw = dict(
+        scale=float(rng.uniform(0.2, 1.5)), noise=float(rng.uniform(0.02, 0.5)), normalise_y=False,
+        linear=bool(rng.integers(2)), nonlinear=bool(rng.integers(2)), input_linear=bool(rng.integers(2)), rq=bool(rng.integers(2)),
+        per=bool(rng.integers(3) == 0), scale_tie=bool(rng.integers(4) == 0),
+        markov=[None, None, 0, 1, 2][int(rng.integers(5))],
+        impute=bool(rng.integers(2)), replace=bool(rng.integers(3) == 0),
+    )
+    if kw["per"]:
+        kw["per_period"] = float(rng.uniform(0.3, 1.2))
+    if rng.integers(3) == 0 and n >= 6:
+        kw["x_ind"] = rng.uniform(0, 1, (int(rng.integers(2, min(n, 14))), m))
+        kw["sparse_method"] = ["vfe", "vfe", "fitc", "dtc"][int(rng.integers(4))]
+    x = rng.uniform(0, 1, (n, m))
+    cols = []
+    for i in range(p):
+        base = np.sin(2 * np.pi * (x @ rng.uniform(0.5, 1.5, m)) + i)
+        if cols:
+            base = base + 0.4 * cols[-1]
+        cols.append(base + 0.1 * rng.standard_normal(n))
+    y = np.stack(cols, axis=1)
+    mode = int(rng.integers(4))
+    if mode == 1:
+        y[rng.random(y.shape) < 0.25] = np.nan
+    elif mode == 2 and p > 1:
+        j = int(rng.integers(p))
+        y[rng.random(n) < 0.9, j] = np.nan      # a nearly empty output
+        y[0, j] = 0.1
+    elif mode == 3:
+        y[rng.random(y.shape) < 0.1] = np.nan
+        y[int(rng.integers(n))] = np.nan          # a row with nothing observed
+    if np.isnan(y).all(axis=0).any():             # every output keeps at least one observation
+        y[0] = 0.3
+    w = None if rng.integers(2) else rng.uniform(0.5, 2.0, (n, p))
+    xs = rng.uniform(0, 1, (int(rng.integers(1, 30)), m))
+    return kw, x, y, w, xs
+
+
+def _run(kind, kw, x, y, w, xs):
+    from gpar_amd.engine import set_engine
+    from gpar_amd.regression import GPARRegressor
+
+    eng = make_engine(kind, seed=5)
+    previous = set_engine(eng)
+    try:
+        reg = GPARRegressor(**kw)
+        prior = float(reg.logpdf(x, y, w))
+        reg.condition(x, y, w)
+        post = float(reg.logpdf(x, y, w, posterior=True))
+        # one latent posterior sample on the engines' shared Philox stream (same seed, same draws)
+        sample = to_np(reg.sample(xs, num_samples=1, latent=True, posterior=True)[0])
+        return prior, post, sample, reg.get_variables(), reg.model_config
+    finally:
+        set_engine(previous)
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_configuration(seed):
+    from oracle import gpar_ref
+
+    kw, x, y, w, xs = _case(seed)
+    sparse = "x_ind" in kw
+    prior, post, sample, hypers, config = _run("hip", kw, x, y, w, xs)
+    o_prior, o_post, o_sample, _, _ = _run("oracle", kw, x, y, w, xs)
+    # inducing-point chains go through K_zz^-1 with a 1e-12 jitter: conditioning-limited, everything else to rounding
+    tol = 1e-6 if sparse else 1e-9
+    scale = max(abs(o_prior), 1.0)
+    assert abs(prior - o_prior) <= tol * scale, (kw, prior, o_prior)
+    assert abs(post - o_post) <= tol * max(abs(o_post), 1.0), (kw, post, o_post)
+    np.testing.assert_allclose(sample, o_sample, rtol=0, atol=(1e-4 if sparse else 1e-7) * max(1.0, np.abs(o_sample).max()))
+    if kw.get("sparse_method", "vfe") == "vfe":   # the independent restatement implements the reference's default approximation
+        want = gpar_ref.gpar_logpdf(x, y, w, hypers, config, impute=kw["impute"], replace=kw["replace"], x_ind=kw.get("x_ind"))
+        assert abs(prior - want) <= tol * max(abs(want), 1.0), (kw, prior, want)
+
+
+def _grads(kind, kw, x, y, w):
+    import torch
+
+    from gpar_amd.engine import set_engine
+    from gpar_amd.regression import GPARRegressor
+
+    eng = make_engine(kind, seed=5)
+    previous = set_engine(eng)
+    try:
+        reg = GPARRegressor(**kw)
+        with torch.no_grad():
+            reg.logpdf(x, y, w)
+        reg.vs.requires_grad(True)
+        args = [torch.tensor(x), torch.tensor(y)] + ([] if w is None else [torch.tensor(w)])
+        value = reg.logpdf(*args)
+        value.backward()
+        names = [v for v in reg.vs.get_vars()]
+        return float(value.detach()), np.concatenate([(v.grad if v.grad is not None else torch.zeros_like(v)).numpy().reshape(-1) for v in names])
+    finally:
+        set_engine(previous)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_configuration_gradient(seed):
+    """d logpdf / d(every hyper-parameter) - the joint objective of fit(fix=False), through imputed / replaced columns and
+    extended inducing inputs where the drawn configuration has them - HIP kernels against the numpy engine."""
+    kw, x, y, w, _ = _case(200 + seed)
+    sparse = "x_ind" in kw
+    value, got = _grads("hip", kw, x, y, w)
+    o_value, ref = _grads("oracle", kw, x, y, w)
+    assert abs(value - o_value) <= (1e-6 if sparse else 1e-9) * max(abs(o_value), 1.0)
+    big = max(np.max(np.abs(ref)), 1e-3)
+    np.testing.assert_allclose(got, ref, rtol=1e-4 if sparse else 1e-6, atol=(1e-5 if sparse else 1e-7) * big, err_msg=str(kw))
