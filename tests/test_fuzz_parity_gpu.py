@@ -125,3 +125,40 @@ def test_random_configuration_gradient(seed):
     assert abs(value - o_value) <= (1e-6 if sparse else 1e-9) * max(abs(o_value), 1.0)
     big = max(np.max(np.abs(ref)), 1e-3)
     np.testing.assert_allclose(got, ref, rtol=1e-4 if sparse else 1e-6, atol=(1e-5 if sparse else 1e-7) * big, err_msg=str(kw))
+
+
+def _mid_case(seed):
+    """Sizes at which the blocked device paths run: fused 512-column panels, look-ahead, the recursive inverse (n a multiple of
+    512) and its fallback (ragged n after missing rows are dropped), generated kernels (the session's thresholds), M up to 320."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([1024, 1536, 2048, int(rng.integers(600, 2600))]))
+    m, p = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    kw = dict(scale=float(rng.uniform(0.3, 1.0)), noise=float(rng.uniform(0.05, 0.3)), normalise_y=False, linear=True,
+              nonlinear=bool(rng.integers(2)), rq=bool(rng.integers(2)), per=bool(rng.integers(4) == 0),
+              markov=[None, 1, 2][int(rng.integers(3))], impute=bool(rng.integers(2)), replace=bool(rng.integers(4) == 0))
+    if rng.integers(3) == 0:
+        kw["x_ind"] = rng.uniform(0, 1, (int(rng.integers(40, 321)), m))
+    x = rng.uniform(0, 1, (n, m))
+    cols = []
+    for i in range(p):
+        base = np.sin(2 * np.pi * (x @ rng.uniform(0.5, 1.5, m)) + i)
+        if cols:
+            base = base + 0.4 * cols[-1]
+        cols.append(base + 0.1 * rng.standard_normal(n))
+    y = np.stack(cols, axis=1)
+    if rng.integers(2):
+        y[rng.random(y.shape) < 0.07] = np.nan
+        y[0] = 0.2
+    w = None if rng.integers(2) else rng.uniform(0.5, 2.0, (n, p))
+    return kw, x, y, w
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_configuration_at_blocked_sizes(seed):
+    kw, x, y, w = _mid_case(seed)
+    sparse = "x_ind" in kw
+    value, got = _grads("hip", kw, x, y, w)
+    o_value, ref = _grads("oracle", kw, x, y, w)
+    assert abs(value - o_value) <= (1e-6 if sparse else 1e-9) * max(abs(o_value), 1.0), (kw, value, o_value)
+    big = max(np.max(np.abs(ref)), 1e-3)
+    np.testing.assert_allclose(got, ref, rtol=1e-4 if sparse else 1e-6, atol=(1e-5 if sparse else 1e-7) * big, err_msg=str(kw))
