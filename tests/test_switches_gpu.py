@@ -1,7 +1,7 @@
 """Every environment switch DESIGN.md section 3.9 documents is part of the behaviour surface: each one, set to a non-default
 value, must leave a log marginal likelihood unchanged to 1e-11 (they select launch shapes, fusion and concurrency, never
 arithmetic that matters).  One n = 1300 problem (ragged: not a multiple of any tile size) plus one n = 5200 factorisation for
-the switches that only act on large matrices.  Switches read at call time are flipped in-process; the two that the library
+the switches that only act on large matrices.  Switches read at call time are flipped in-process; the three that the library
 caches on first use are exercised in a fresh process."""
 import json
 import os
@@ -45,7 +45,8 @@ CALL_TIME = [
     ("GPAR_GRAD_JIT_MIN_ENTRIES", "0"),
     ("GPAR_GRAD_JIT_MIN_ENTRIES", "-1"),
 ]
-CACHED = [("GPAR_GEMM_HALF_TILES", "0"), ("GPAR_GEMM_HALF_TILES", "100000"), ("GPAR_GEMM_MIXED_TAIL", "0")]
+CACHED = [("GPAR_GEMM_HALF_TILES", "0"), ("GPAR_GEMM_HALF_TILES", "100000"), ("GPAR_GEMM_MIXED_TAIL", "0"), ("GPAR_GEMM_TILE_BLOCK", "0"),
+          ("GPAR_GEMM_TILE_BLOCK", "16")]
 
 
 def _evaluate():
