@@ -127,6 +127,19 @@ __device__ __forceinline__ int p2_wblock(int jb) {
     return 16 * (jb >> 1) * PNL_LD + 16 * (2 + (jb & 1));
 }
 
+// Refinement flags.  A strip solves against the diagonal 16 x 16 blocks of the tile through their explicit inverses W:
+// x0 = W t is not backward stable - its residual t - L x0 is of order eps * cond(L_bb) |t| where substitution leaves eps |L| |x|.
+// For K + noise that is invisible (pivots of a block within a factor ~10 of each other); for K_zz + 1e-12 of many inducing inputs
+// on one axis - numerically rank-deficient by construction - the block in which the pivots fall from 1 to 1e-6 has cond ~ 1e6,
+// the factorisation's backward error grew from 2e-15 (LAPACK, and the unfused path here) to 1e-13, and one n = 2048 case failed
+// outright where LAPACK does not (tools/diag_illcond_potrf.py).  So whoever inverts a block also records whether its largest
+// pivot exceeds P2_REFINE_RATIO times its smallest, and the strips give such blocks one step of iterative refinement:
+// x1 = x0 + W (t - L_bb x0), eight more matrix-core products for that block - backward stable while eps * cond << 1, and paid
+// only where it is needed.  The four flags of a tile sit in row 1, columns 16 .. 19 of the tile (strictly upper: scratch by the
+// ABI's convention, clear of the progress words in row 0 and of the inverses from column 32 on).
+constexpr double P2_REFINE_RATIO = 32.0;
+__device__ __forceinline__ int p2_flag_slot(int jb) { return PNL_LD + 16 + jb; }
+
 // Wave w inverts the w-th diagonal 16 x 16 block  [La 0; Lba Lb]  of the lower-triangular tile Cs into the 16 x 16 block
 // W at p2_wblock(w):  W = [Wa 0; -Wb Lba Wa, Wb].
 //   (1) the two 8 x 8 inverses by substitution on 16 lanes (lane = 8 h + j solves L_h x = e_j; all 36 coefficients of its
@@ -146,6 +159,14 @@ __device__ __forceinline__ void p2_inverse_blocks(double* __restrict__ Cs, int w
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int k = 0; k <= i; ++k) c[i][k] = Cs[(b8 + i) * PNL_LD + b8 + k];
+        {   // refinement flag of this block: spread of its sixteen pivots (each lane holds the eight of its half)
+            double mn = c[0][0], mx = c[0][0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) { mn = fmin(mn, c[k][k]); mx = fmax(mx, c[k][k]); }
+            mn = fmin(mn, __shfl_xor(mn, 8, 64));
+            mx = fmax(mx, __shfl_xor(mx, 8, 64));
+            if (lane == 0) Cs[p2_flag_slot(w)] = (mx > P2_REFINE_RATIO * mn) ? 1.0 : 0.0;
+        }
         double x[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = (i == j) ? 1.0 : 0.0;
@@ -200,6 +221,18 @@ __device__ __forceinline__ void p2_strip(const double* __restrict__ Cs, pan_d4 (
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4)
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(W[l15 * PNL_LD + 4 * k4 + lk], T[jb][k4], x, 0, 0, 0);
+        if (Cs[p2_flag_slot(jb)] != 0.0) {   // (wave-uniform) an ill-conditioned block: x += W (t - L_bb x)
+            pan_d4 r = T[jb];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int k = 4 * k4 + lk;
+                const double l = Cs[(16 * jb + l15) * PNL_LD + 16 * jb + k];   // L_bb[m = l15][k]; above its diagonal the tile holds scratch
+                r = __builtin_amdgcn_mfma_f64_16x16x4f64(k <= l15 ? -l : 0.0, x[k4], r, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(W[l15 * PNL_LD + 4 * k4 + lk], r[k4], x, 0, 0, 0);
+        }
         T[jb] = x;
 #pragma unroll
         for (int j2 = jb + 1; j2 < 4; ++j2) {
@@ -826,6 +859,11 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
                 if (r0 + (off / PNL_LD) < brows) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
             }
         }
+        if (t < 2 && r0 + 1 < brows) {   // the four refinement flags: row 1, columns 16 .. 19
+            const pan_d2 v = *reinterpret_cast<const pan_d2*>(Cs + p2_flag_slot(2 * t));
+            double* dst = B + (size_t)(r0 + 1) * ldb + bc0 + 64 * trow + 16 + 2 * t;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+        }
         P2_STAMP(trow, 3);   // inverses + stores issued
         p2_publish(p, trow, (unsigned long long)trow + 1);
         P2_STAMP(trow, 4);   // published
@@ -945,6 +983,18 @@ __device__ __forceinline__ void p2_strip_back(const double* __restrict__ Cs, pan
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4)   // x^T = W^T t^T:  A[m][k] = W[k][m]
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(W[(4 * k4 + lk) * PNL_LD + l15], T[jb][k4], x, 0, 0, 0);
+        if (Cs[p2_flag_slot(jb)] != 0.0) {   // (wave-uniform) an ill-conditioned block: x += W^T (t - L_bb^T x)
+            pan_d4 r = T[jb];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int k = 4 * k4 + lk;
+                const double l = Cs[(16 * jb + k) * PNL_LD + 16 * jb + l15];   // L_bb^T[m = l15][k] = L_bb[k][m]: zero for m > k
+                r = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 <= k ? -l : 0.0, x[k4], r, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(W[(4 * k4 + lk) * PNL_LD + l15], r[k4], x, 0, 0, 0);
+        }
         T[jb] = x;
 #pragma unroll
         for (int j2 = jb - 1; j2 >= 0; --j2) {

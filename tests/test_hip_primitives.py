@@ -838,3 +838,62 @@ def test_generated_gradient_kernels_match_the_interpreter(case, monkeypatch):
     for a, b in zip(got, ref):
         scale = float(b.abs().max()) + 1e-300
         assert float((a - b).abs().max()) <= 1e-11 * scale, (name, float((a - b).abs().max()), scale)
+
+
+def _rank_deficient(n, ell, jitter, seed=0):
+    x = np.sort(np.random.default_rng(seed).uniform(0, 1, n))
+    return np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2 / ell ** 2) + jitter * np.eye(n)
+
+
+@pytest.mark.parametrize("n,ell,jitter", [(2048, 0.1, 1e-12), (1024, 0.5, 1e-12), (512, 0.1, 1e-10), (314, 0.5, 1e-12), (1300, 0.3, 1e-11)])
+def test_factorisation_of_a_numerically_rank_deficient_matrix_is_backward_stable(n, ell, jitter):
+    """K_zz of many inducing inputs on ONE axis plus lab's jitter - what `x_ind = np.linspace(...)` gives the reference
+    (gpar/model.py:286-287; examples/paper/air_temp.py) - is rank-deficient to working precision: after ~30 pivots the Schur
+    complement is the jitter.  LAPACK factors it with a backward error of 2e-15.  The fused panel kernel solves its strips
+    through explicit inverses of 16 x 16 diagonal blocks, which is not backward stable for the block in which the pivots fall by
+    six orders of magnitude: 1e-13, and one of these cases failed with "not positive definite" - until such blocks got a step of
+    iterative refinement (csrc/panel2.h: refinement flags).  Now: succeeds, and |L L^T - A| within 4x LAPACK's."""
+    import torch
+
+    from gpar_amd import hip as H
+
+    dev = torch.device("cuda:0")
+    A = _rank_deficient(n, ell, jitter)
+    ref = np.linalg.cholesky(A)
+    ref_err = np.abs(ref @ ref.T - A).max()
+    B = H.alloc_matrix(n, n, dev)
+    B.copy_(torch.tensor(A, device=dev))
+    logdet, info = H.potrf_(B)
+    assert int(info.item()) == 0
+    L = torch.tril(B).cpu().numpy()
+    err = np.abs(L @ L.T - A).max()
+    assert err <= 4 * ref_err + 1e-15, (err, ref_err)
+    # the log-determinant of such a matrix is a sum of ~n logs of pivots that are the jitter plus rounding noise (1e-16 n against
+    # 1e-12: each determined to 3-4 digits, by LAPACK as much as here): agreement to that
+    want = 2 * np.log(np.diag(ref)).sum()
+    assert abs(float(logdet) - want) <= 1e-3 * abs(want), (float(logdet), want)
+
+
+@pytest.mark.parametrize("n", [1024, 1300])
+def test_many_row_solves_against_an_ill_conditioned_factor_are_backward_stable(n):
+    """The same blocks in the fused triangular solves (`gpar_trsm_rlt`: K_xz L_z^-T of the inducing-point path, 4096 rows;
+    `gpar_trsm_rln`: the backward solve of its gradient): residuals |X L^T - B| and |X L - B| relative to |X| |L| at rounding
+    level, as substitution would leave them."""
+    import torch
+
+    from gpar_amd import hip as H
+
+    dev = torch.device("cuda:0")
+    L = np.linalg.cholesky(_rank_deficient(n, 0.2, 1e-12, seed=3))
+    Ld = H.alloc_matrix(n, n, dev)
+    Ld.copy_(torch.tensor(L, device=dev))
+    rhs = np.random.default_rng(4).standard_normal((4096, n))
+    for solve, apply in ((H.trsm_rlt_, lambda X: X @ L.T), (H.trsm_rln_, lambda X: X @ L)):
+        X = H.alloc_matrix(4096, n, dev)
+        X.copy_(torch.tensor(rhs, device=dev))
+        solve(Ld, X)
+        Xh = X.cpu().numpy()
+        resid = np.abs(apply(Xh) - rhs).max(axis=1)
+        scale = (np.abs(Xh) @ np.abs(L).sum(axis=0 if solve is H.trsm_rlt_ else 1)) + np.abs(rhs).max(axis=1)
+        assert np.isfinite(Xh).all()
+        assert (resid <= 1e-13 * scale).all(), float((resid / scale).max())
