@@ -476,9 +476,11 @@ class GPAR:
 
         if self.sparse:
             x_ind = torch.cat([x_ind, estimate(x_ind)], dim=1)
-        if self.impute and self.replace:
-            y = estimate(x)
-        else:
+        if (self.impute and self.replace) or (self.replace and complete):
+            y = estimate(x)   # (complete data: every row is observed, so "replace the observed ones" is all of them)
+        elif not complete:
+            # (`complete` is known from the masks: with it there is nothing to impute, and no `.any()` - a host sync per layer,
+            # after which the host cannot prepare layer i + 1 while the GPU works on layer i: 0.3-0.5 ms per layer at C4)
             if self.impute and bool((~available).any()):
                 y = merge(y, estimate(x[~available]), ~available)
             if self.replace and bool(available.any()):
