@@ -790,85 +790,161 @@ static int chol_inverse_run(const double* L, int n, int ldl, double* X, int ldx,
 constexpr int TRSV_NB = 512;
 constexpr int TRSV_LD = 65;
 
-// One 512-column block, eight 64-column sub-blocks from last to first.  Wave 0 solves a sub-block entirely in registers: lane =
-// column, the 64 rows of the triangle it needs (L[i][lane], zero above the diagonal) requested up front - during the
-// previous sub-block's update phase - and a 64-step chain of {multiply by the reciprocal pivot, v_readlane, multiply-add}.
-// Waves 1-3 apply the new x_s to the sub-blocks to its left: each has the 64 rows of its FIRST column block in registers
-// before x_s exists (requested while wave 0 solves; wave 1 takes the next sub-block to be solved), so the dependent part is
-// 64 multiply-adds against LDS broadcasts; further column blocks follow with their own loads.  (The first version staged
-// the triangle through LDS, read one row per step from it inside the chain and loaded the update rows only after the
-// solve: 13 us per sub-block, 106 us per block; this one ~2.)
+// One 512-column block, eight 64-column sub-blocks from last to first, one workgroup of four waves, each on its own SIMD.
+//   wave 0, the solver: sub-block s entirely in registers - lane = column, the 64 rows of the triangle it needs (L[i][lane], zero
+//     above the diagonal), scaled by the reciprocal pivot up front - and a 64-step chain of {v_readlane x 2, multiply-add}.
+//     Two register sets: the triangle of the next sub-block is in flight while one is in use (a third set would push the
+//     kernel past 512 registers - the updaters hold three - and into scratch: 34 -> 66 us).
+//   waves 1-3, the updaters: task (s, c), c < s, is  x_c -= x_s L[s][c]  (64 x 64 tile, lane = column; x_s read once per lane and
+//     broadcast through scalar registers).  Target sub-block c belongs to wave 1 + c % 3 - one writer per target, a fixed
+//     summation order - and a wave works TARGET-major: target c gets the sources s = 7 .. c + 1 in that order, the last of which
+//     is the only task on the critical path (x_{c+1} has just been solved, x_c is next); the first tasks of its NEXT target
+//     (sources solved long ago) are a backlog that runs under the other waves' critical steps.  Three register sets: the tiles
+//     of the next two tasks are in flight while one is used - tile addresses are static, nothing waits for memory that it
+//     could have asked for earlier.
+// Hand-offs are words in LDS, not barriers: ready[s] (x_s is in LDS) and done[c] (updates applied to target c so far); a wave
+// polls the one word it needs, so nobody waits for a wave that is busy with work off the critical path.
+// History: (1) triangle staged through LDS, a row read per step inside the chain: 106 us per block; (2) triangle in registers,
+// ALL updates of source s between the chains of s and s - 1, second and third tile of a wave requested only after the first:
+// 55 us; (3) this one.  What bounds it: the chain (64 dependent steps of ~30 ns per sub-block) and what one compute unit can
+// pull from L2 / HBM with nine tiles in flight (1.1 MB per block).
+#ifdef GPAR_TRSV_STAMPS
+__device__ long long g_trsv_stamps[4][64];
+#define TRSV_STAMP(k) do { if (lane == 0 && (k) < 64) g_trsv_stamps[w][(k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TRSV_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void trsv_block_kernel(const double* __restrict__ L, int ldl, double* __restrict__ b, int c0, int c1) {
     __shared__ double xb[TRSV_NB];
+    __shared__ int ready[TRSV_NB / 64], done[TRSV_NB / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    TRSV_STAMP(0);
     const int W = c1 - c0;
-    for (int i = t; i < W; i += 256) xb[i] = b[c0 + i];
+    for (int i = t; i < TRSV_NB; i += 256) xb[i] = i < W ? b[c0 + i] : 0.0;   // (zeros beyond a ragged edge: x there stays zero)
+    if (t < TRSV_NB / 64) { ready[t] = 0; done[t] = 0; }
     const int nsub = (W + 63) / 64;
-    double lv[64];   // wave 0: the triangle's column `lane`; waves 1-3: column `lane` of the update rows
-    double dg = 1.0;
-    auto load_triangle = [&](int s) {
-        const int cs = c0 + 64 * s;
-        const int cb = (c1 - cs < 64) ? c1 - cs : 64;
-        const int lc = lane < cb ? lane : cb - 1;
-#pragma unroll
-        for (int i = 0; i < 64; ++i) lv[i] = L[(size_t)(cs + (i < cb ? i : cb - 1)) * ldl + cs + lc];   // clamped, never behind a branch
-        dg = L[(size_t)(cs + lc) * ldl + cs + lc];
+    auto cols_of = [&](int s) { const int cs = c0 + 64 * s; return (c1 - cs < 64) ? c1 - cs : 64; };
+    auto wait_word = [&](int* word, int value) {   // (all lanes read the same word: a broadcast; the loop is wave-uniform)
+        while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < value) __builtin_amdgcn_s_sleep(1);
     };
-    if (w == 0) load_triangle(nsub - 1);
-    __syncthreads();
-    for (int s = nsub - 1; s >= 0; --s) {
-        const int cs = c0 + 64 * s;
-        const int cb = (c1 - cs < 64) ? c1 - cs : 64;
-        const int myc = s - w;   // waves 1-3: first column block to update
-        if (w > 0 && myc >= 0) {
-            const double* Lp = L + (size_t)cs * ldl + c0 + 64 * myc + lane;
+    auto post_word = [&](int* word, int value) {   // every lane's LDS writes of this wave are ordered before the word
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // (row pointers are wave-uniform - scalar arithmetic -, the lane only adds its column: one address instruction per load
+    // instead of a 64-bit multiply-add each, which made requesting a tile cost as much as using it)
+    auto load_rows = [&](const double* base, int cb, int col, double (&lv)[64]) {
+        if (cb == 64) {
 #pragma unroll
-            for (int i = 0; i < 64; ++i) lv[i] = Lp[(size_t)(i < cb ? i : cb - 1) * ldl];
+            for (int i = 0; i < 64; ++i) lv[i] = (base + (size_t)i * ldl)[col];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) lv[i] = (base + (size_t)(i < cb ? i : cb - 1) * ldl)[col];   // clamped, never behind a branch
         }
-        if (w == 0) {
-            // entries above the diagonal (row i < column) and beyond a ragged edge are zero: a lane's right-hand side then stops
-            // changing once its own step has passed, and its solution is read off after the loop
+    };
+    if (w == 0) {
+        double tri[2][64], dg[2];
+        auto load_triangle = [&](int s, double (&lv)[64], double& d) {
+            const int cs = c0 + 64 * s, cb = cols_of(s);
+            const int lc = lane < cb ? lane : cb - 1;
+            const double* base = L + (size_t)cs * ldl + cs;
+            load_rows(base, cb, lc, lv);
+            d = (base + (size_t)lc * ldl)[lc];
+        };
+        auto solve = [&](int s, double (&lv)[64], double d) {
+            const int cb = cols_of(s);
+            // The column is scaled by its reciprocal pivot up front (64 independent multiplies, off the chain): lane j then carries
+            // x_j-to-be, (b_j - sum_{i > j} x_i L[i][j]) / L[j][j], and a chain step is {v_readlane x 2, multiply-add}.  Entries above
+            // the diagonal (row i < column) and beyond a ragged edge are zero: a lane's value stops changing once its own step
+            // has passed, and is read off after the loop.
+            const double rinv = lane < cb ? 1.0 / d : 0.0;
 #pragma unroll
-            for (int i = 0; i < 64; ++i) lv[i] = (lane < i && i < cb) ? lv[i] : 0.0;
-            double bj = lane < cb ? xb[64 * s + lane] : 0.0;
-            const double rinv = lane < cb ? 1.0 / dg : 0.0;
+            for (int i = 0; i < 64; ++i) lv[i] = (lane < i && i < cb) ? lv[i] * rinv : 0.0;
+            wait_word(&done[s], nsub - 1 - s);   // everything owed to sub-block s has landed
+            TRSV_STAMP(1 + 2 * (nsub - 1 - s));
+            double xj = lane < cb ? xb[64 * s + lane] * rinv : 0.0;
 #pragma unroll
             for (int i = 63; i >= 0; --i) {
-                const double xi = gpar_readlane_f64(bj * rinv, i);   // (zero for i >= cb)
-                bj = fma(-xi, lv[i], bj);
+                const double xi = gpar_readlane_f64(xj, i);   // final for lane i: every step above it has been applied (zero for i >= cb)
+                xj = fma(-xi, lv[i], xj);
             }
-            if (lane < cb) xb[64 * s + lane] = bj * rinv;
+            if (lane < cb) xb[64 * s + lane] = xj;
+            post_word(&ready[s], 1);
+            TRSV_STAMP(2 + 2 * (nsub - 1 - s));
+        };
+        load_triangle(nsub - 1, tri[0], dg[0]);
+        if (nsub > 1) load_triangle(nsub - 2, tri[1], dg[1]);
+        __syncthreads();   // xb and the hand-off words are initialised
+        for (int s = nsub - 1; s >= 0; s -= 2) {
+            solve(s, tri[0], dg[0]);
+            if (s > 1) load_triangle(s - 2, tri[0], dg[0]);   // (its registers are free again)
+            if (s == 0) break;
+            solve(s - 1, tri[1], dg[1]);
+            if (s > 2) load_triangle(s - 3, tri[1], dg[1]);
         }
-        __syncthreads();   // x_s is in xb
-        if (w == 0) {
-            if (s > 0) load_triangle(s - 1);   // in flight under the update phase
-        } else {
-            for (int c = myc; c >= 0; c -= 3) {
-                if (c != myc) {
-                    const double* Lp = L + (size_t)cs * ldl + c0 + 64 * c + lane;
+    } else {
+        int gs = nsub - 1, gc = nsub - 2;   // generator of this wave's task sequence: targets it owns, downwards; sources nsub - 1 .. c + 1
+        while (gc >= 0 && gc % 3 != w - 1) --gc;
+        auto take = [&](int& s_, int& c_) {
+            s_ = gs; c_ = gc;
+            if (gc < 0) return;
+            if (gs > gc + 1) { --gs; return; }
+            gc -= 3;
+            gs = nsub - 1;
+        };
+        auto load_tile = [&](int s, int c, double (&lv)[64]) {
+            load_rows(L + (size_t)(c0 + 64 * s) * ldl + c0 + 64 * c, cols_of(s), lane, lv);
+        };
+        int ntask = 0;
+        auto compute = [&](int s, int c, const double (&lv)[64]) {
+            wait_word(&ready[s], 1);   // x_s exists
+            TRSV_STAMP(1 + 2 * ntask);
+            const double xs = xb[64 * s + lane];   // (zero beyond a ragged edge, the clamped rows finite)
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int i = 0; i < 64; ++i) lv[i] = Lp[(size_t)(i < cb ? i : cb - 1) * ldl];
-                }
-                double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int i = 0; i < 64; ++i) acc[i & 3] = fma(i < cb ? xb[64 * s + i] : 0.0, lv[i], acc[i & 3]);
-                xb[64 * c + lane] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            }
+            for (int i = 0; i < 64; ++i) acc[i & 3] = fma(gpar_readlane_f64(xs, i), lv[i], acc[i & 3]);
+            xb[64 * c + lane] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            post_word(&done[c], nsub - s);   // sources nsub - 1 .. s applied: nsub - s of them
+            TRSV_STAMP(2 + 2 * ntask);
+            ++ntask;
+        };
+        double tile[3][64];
+        int ts[3], tc[3];
+        take(ts[0], tc[0]);
+        take(ts[1], tc[1]);
+        if (tc[0] >= 0) load_tile(ts[0], tc[0], tile[0]);
+        if (tc[1] >= 0) load_tile(ts[1], tc[1], tile[1]);
+        __syncthreads();   // xb and the hand-off words are initialised
+        for (;;) {
+            take(ts[2], tc[2]);
+            if (tc[2] >= 0) load_tile(ts[2], tc[2], tile[2]);
+            if (tc[0] < 0) break;
+            compute(ts[0], tc[0], tile[0]);
+            take(ts[0], tc[0]);
+            if (tc[0] >= 0) load_tile(ts[0], tc[0], tile[0]);
+            if (tc[1] < 0) break;
+            compute(ts[1], tc[1], tile[1]);
+            take(ts[1], tc[1]);
+            if (tc[1] >= 0) load_tile(ts[1], tc[1], tile[1]);
+            if (tc[2] < 0) break;
+            compute(ts[2], tc[2], tile[2]);
         }
-        __syncthreads();   // every update of this step has landed
     }
+    __syncthreads();   // every update has landed
+    TRSV_STAMP(63);
     for (int i = t; i < W; i += 256) b[c0 + i] = xb[i];
 }
 
-__global__ __launch_bounds__(256) void trsv_update_kernel(const double* __restrict__ L, int ldl, double* __restrict__ b, int c0, int c1) {
+// b[j] -= sum_k x[k] L[c0 + k][j] for the columns j in [j0, j1), j1 <= c0 (x = b[c0 .. c1), just solved): one 64-column slice per workgroup
+__global__ __launch_bounds__(256) void trsv_update_kernel(const double* __restrict__ L, int ldl, double* __restrict__ b, int c0, int c1, int j0, int j1) {
     __shared__ double xs[TRSV_NB];
     __shared__ double part[4][64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int W = c1 - c0;
     for (int i = t; i < W; i += 256) xs[i] = b[c0 + i];
     __syncthreads();
-    const int j = 64 * blockIdx.x + lane;
-    const int jc = j < c0 ? j : c0 - 1;
+    const int j = j0 + 64 * blockIdx.x + lane;
+    const int jc = j < j1 ? j : j1 - 1;
     const int kw = (W + 3) / 4, k0 = w * kw, k1 = (k0 + kw < W) ? k0 + kw : W;
     const double* Lp = L + (size_t)c0 * ldl + jc;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -886,16 +962,19 @@ __global__ __launch_bounds__(256) void trsv_update_kernel(const double* __restri
     }
     part[w][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (w == 0 && j < c0) b[j] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (w == 0 && j < j1) b[j] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// (Tried: after block k only the next block's 512 columns updated on the caller's stream, everything further left on the look-ahead
+// side stream under block k + 1's chain - three event operations and an extra launch per block cost more than the overlap gains:
+// n = 16384 1.52 -> 1.87 ms.)
 static int trsv_rln_run(const double* L, int n, int ldl, double* b, hipStream_t stream) {
     const int nblk = gpar_ceil_div(n, TRSV_NB);
     for (int blk = nblk - 1; blk >= 0; --blk) {
         const int c0 = blk * TRSV_NB;
         const int c1 = (c0 + TRSV_NB < n) ? c0 + TRSV_NB : n;
         hipLaunchKernelGGL(trsv_block_kernel, dim3(1), dim3(256), 0, stream, L, ldl, b, c0, c1);
-        if (c0 > 0) hipLaunchKernelGGL(trsv_update_kernel, dim3(gpar_ceil_div(c0, 64)), dim3(256), 0, stream, L, ldl, b, c0, c1);
+        if (c0 > 0) hipLaunchKernelGGL(trsv_update_kernel, dim3(gpar_ceil_div(c0, 64)), dim3(256), 0, stream, L, ldl, b, c0, c1, 0, c0);
     }
     GPAR_LAUNCH_CHECK();
     return 0;
