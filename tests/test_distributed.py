@@ -179,3 +179,57 @@ def test_c3_partitioning_world_size_4():
         assert received == [i for i in range(8) if i % size != rank]
         assert out["samples"] == 6
     assert len({results[r]["logpdf"][1] for r in range(size)}) == 1
+
+
+def _worker_random(rank, size, port, results):
+    """Randomly drawn model options / missing patterns / weights / inducing points on an ODD number of ranks, p not a multiple of it."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        from gpar_amd.engine import set_engine
+        from gpar_amd.parallel import sharded_logpdf
+        from gpar_amd.regression import GPARRegressor, _construct_gpar
+        from oracle.engine import OracleEngine
+
+        set_engine(OracleEngine(seed=5))
+        out = []
+        for seed in range(14):
+            rng = np.random.default_rng(300 + seed)   # (every rank draws the same case)
+            n, m, p = int(rng.integers(3, 40)), int(rng.integers(1, 3)), int(rng.integers(1, 6))
+            kw = dict(scale=float(rng.uniform(0.3, 1.2)), noise=float(rng.uniform(0.05, 0.4)), normalise_y=False, linear=bool(rng.integers(2)),
+                      nonlinear=bool(rng.integers(2)), rq=bool(rng.integers(2)), markov=[None, 0, 1, 2][int(rng.integers(4))],
+                      impute=bool(rng.integers(2)), replace=bool(rng.integers(3) == 0))
+            if rng.integers(3) == 0 and n >= 6:
+                kw["x_ind"] = rng.uniform(0, 1, (int(rng.integers(2, 6)), m))
+            x = rng.uniform(0, 1, (n, m))
+            y = np.stack([np.sin(3 * x[:, 0] + i) + 0.1 * rng.standard_normal(n) for i in range(p)], axis=1)
+            if rng.integers(2):
+                y[rng.random(y.shape) < 0.2] = np.nan
+                y[0] = 0.1
+            w = rng.uniform(0.5, 2.0, (n, p))
+            reg = GPARRegressor(**kw)
+            gpar = _construct_gpar(reg, reg.vs, m, p)
+            out.append((float(gpar.logpdf(x, y, w)), float(sharded_logpdf(gpar, x, y, w))))
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_random_configurations_on_three_ranks():
+    size = 3
+    ctx = mp.get_context("spawn")
+    manager = ctx.Manager()
+    results = manager.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_random, args=(r, size, port, results)) for r in range(size)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=570)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for rank in range(size):
+        for serial, sharded in results[rank]:
+            assert abs(serial - sharded) <= 1e-10 * max(abs(serial), 1.0), (rank, serial, sharded)
+    assert [s for _, s in results[0]] == [s for _, s in results[1]] == [s for _, s in results[2]]   # every rank holds the same totals
