@@ -904,8 +904,16 @@ class PseudoObs:
         # A - I = Bs^T Bs: ONE product over the n data points (K = n is cut into slices so that the whole chip works);
         # c = Bs^T ys is a matrix-vector pass; the trace term needs no pass of its own:
         #   sum_a (k_aa - |B_:a|^2) / d_a = sum_a k_aa / d_a - tr(A - I)
-        G = eng.gemm(Bs, Bs, ta=True, c_lower=True)
-        c = eng.gemv_t(Bs, ys).reshape(1, M)
+        # (the matrix-vector pass is bound by memory, the product by the matrix cores: side by side on two streams)
+        side2 = eng.side_stream() if hasattr(eng, "side_stream") and n * M >= (1 << 22) else None
+        if side2 is not None:
+            with _on_side(side2):
+                c = eng.gemv_t(Bs, ys).reshape(1, M)
+            G = eng.gemm(Bs, Bs, ta=True, c_lower=True)
+            _join_side(side2, c)
+        else:
+            G = eng.gemm(Bs, Bs, ta=True, c_lower=True)
+            c = eng.gemv_t(Bs, ys).reshape(1, M)
         yDy = torch.sum(ys * ys)
         trace_term = torch.sum(kdiag / d) - torch.sum(torch.diagonal(G)) if self.method == "vfe" else 0.0
 
