@@ -454,6 +454,7 @@ struct TrsmBlockArgs {
     int nrows, ldb;
     int c0, S;         // columns [c0, c0 + 64 S)
     int upper_tri;     // B is upper triangular on entry: row r has nothing left of column r -> whole steps are skipped
+    int pairs = 0;     // panel2.h: column blocks taken in pairs (p2_row_block_pairs)
 };
 
 __global__ __launch_bounds__(256) void trsm_block_kernel(TrsmBlockArgs a) {

@@ -917,6 +917,91 @@ static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* 
     return 0;
 }
 
+// The row-block task of a triangular solve (no hand-offs: L is final) with the column blocks taken in PAIRS (c, c + 1): the row
+// block's tiles X[rb][u], u < c, are staged once per pair and used against L[c][u] and L[c + 1][u] in turn, and the product
+// (c + 1, c) takes X[rb][c] from the LDS tile the strip of column c has just written - 56 tile movements per 512-column block
+// instead of 72 (the bulk work of this task is bound by operand bytes: lesson 31).  Same sums in the same order: same bits.
+__device__ __forceinline__ void p2_row_block_pairs(const double* __restrict__ L, int ldl, int lrows, int lr0, int lc0, double* __restrict__ B,
+                                                   int ldb, int brows, int r0, int bc0, int ncol, double* __restrict__ psm) {
+    double* Cs = psm;
+    double* Xs = psm + PNL_TILE;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    // Xs holds the row block's tile of column block c (what is to be solved), acc the products owed to it: solve, leave X in Xs, store
+    auto solve_column = [&](int c, pan_d4 (&acc)[4]) {
+        pan_d4 T[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) T[mi][v] = Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] - acc[mi][v];
+        __syncthreads();
+        {
+            pan_d2 lt[8];
+            p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * c, t, lt);
+            p2_sstore(Cs, t, lt);
+        }
+        __syncthreads();
+        p2_inverse_blocks(Cs, w, lane);
+        __syncthreads();
+        p2_strip(Cs, T, l15, lk);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] = T[mi][v];
+        __syncthreads();
+        p2_gstore(B, ldb, brows, r0, bc0 + 64 * c, Xs, t, false);
+    };
+    for (int c = 0; c < ncol; c += 2) {
+        const bool pair = c + 1 < ncol;
+        pan_d4 acc0[4], acc1[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { acc0[mi] = pan_d4{0.0, 0.0, 0.0, 0.0}; acc1[mi] = pan_d4{0.0, 0.0, 0.0, 0.0}; }
+        pan_d2 xa[8];
+        p2_gload(B, ldb, brows, r0, bc0, t, xa);   // X[rb][0] - or, for c = 0, the tile to be solved itself
+        if (c > 0) {
+            pan_d2 la0[8], la1[8];
+            p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0, t, la0);
+            p2_gload(L, ldl, lrows, lr0 + 64 * (pair ? c + 1 : c), lc0, t, la1);
+            for (int u = 0; u < c; ++u) {
+                __syncthreads();   // the previous chunk's operand reads are done
+                p2_sstore(Cs, t, la0);
+                p2_sstore(Xs, t, xa);
+                __syncthreads();
+                const int un = min(u + 1, c - 1);
+                p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * un, t, la0);
+                p2_gload(B, ldb, brows, r0, bc0 + 64 * (u + 1), t, xa);   // (after the last chunk: the tile of column block c)
+                __builtin_amdgcn_sched_barrier(0);
+                p2_chunk(Cs, Xs, acc0, w, l15, lk);
+                if (pair) {
+                    __syncthreads();
+                    p2_sstore(Cs, t, la1);   // X[rb][u] stays where it is
+                    __syncthreads();
+                    p2_gload(L, ldl, lrows, lr0 + 64 * (c + 1), lc0 + 64 * un, t, la1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    p2_chunk(Cs, Xs, acc1, w, l15, lk);
+                }
+            }
+        }
+        __syncthreads();
+        p2_sstore(Xs, t, xa);
+        __syncthreads();
+        solve_column(c, acc0);
+        if (pair) {
+            // the product (c + 1, c): X[rb][c] is in Xs (the strip has just left it there), L[c + 1][c] and the next tile to solve arrive now
+            pan_d2 lc[8];
+            p2_gload(L, ldl, lrows, lr0 + 64 * (c + 1), lc0 + 64 * c, t, lc);
+            p2_gload(B, ldb, brows, r0, bc0 + 64 * (c + 1), t, xa);
+            __syncthreads();   // the strip's reads of Cs and the global store's reads of Xs are done
+            p2_sstore(Cs, t, lc);
+            __syncthreads();
+            p2_chunk(Cs, Xs, acc1, w, l15, lk);
+            __syncthreads();
+            p2_sstore(Xs, t, xa);
+            __syncthreads();
+            solve_column(c + 1, acc1);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fused block of the forward triangular solve  X L^T = B  (gpar_trsm_rlt): one workgroup per 64-row block of B carries
 // it through the S column blocks [c0, c0 + 64 S) - the same left-looking row-block task, without hand-offs.
@@ -928,6 +1013,10 @@ __global__ __launch_bounds__(256, 2) void trsm_block2_kernel(TrsmBlockArgs a) {
     if (a.upper_tri) {
         while (ufirst < a.S && a.c0 + 64 * ufirst + 63 < r0) ++ufirst;
     }
+    if (!a.upper_tri && a.pairs) {
+        p2_row_block_pairs(a.L, a.ldl, a.n, a.c0, a.c0, a.B, a.ldb, a.nrows, r0, a.c0, a.S, psm);
+        return;
+    }
     const PanelArgs none{nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
     p2_row_block<false, false>(none, a.L, a.ldl, a.n, a.c0, a.c0, a.B, a.ldb, a.nrows, r0, a.c0, a.S, ufirst, 0, psm);
 }
@@ -936,6 +1025,7 @@ static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nro
                              hipStream_t stream) {
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&trsm_block2_kernel), P2_LDS_BYTES));
     TrsmBlockArgs a{L, n, ldl, B, nrows, ldb, c0, S, upper_tri};
+    a.pairs = env_int("GPAR_TRSM_PAIRS", 1);
     hipLaunchKernelGGL(trsm_block2_kernel, dim3(gpar_ceil_div(nrows, 64)), dim3(256), P2_LDS_BYTES, stream, a);
     GPAR_LAUNCH_CHECK();
     return 0;
