@@ -44,6 +44,7 @@ struct PanelArgs {
     long long* stamps;   // dev aid (tools/time_panel.hip): cycle stamps of the critical chain, normally null
     long long batch_a = 0;   // batched launch (panel2.h, gridDim.y matrices of the same shape): matrix y starts at A + y * batch_a,
                              // its logdet / info words are logdet[y], info[y]
+    int pairs = 0;           // panel2.h: bulk row blocks take their column blocks in pairs (p2_row_block_pairs)
 };
 
 __device__ __forceinline__ unsigned long long* pnl_flag(const PanelArgs& p, int f) {

@@ -871,61 +871,22 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
 #undef P2_STAMP
 }
 
-// launch bounds (256, 2): at most 256 unified registers, so that a wave fits beside a trailing-update wave (see panel.h)
-__global__ __launch_bounds__(256, 2) void potrf_panel2_kernel(PanelArgs p) {
-    extern __shared__ __attribute__((aligned(16))) double psm[];
-    // Batched launch (gridDim.y matrices).  Workgroups are dispatched x first, then y; the linear dispatch index is dealt so that
-    // the TEAMS of all matrices come first (team row rb of matrix b at index rb * batch + b), then the bulk row blocks, matrices
-    // interleaved: every chain starts at once instead of one matrix's bulk rows holding the slots the next matrix's team needs
-    // (same-box A/B: C3 189.8 -> 187.9 ms, C5 60.4 -> 59.7 ms per evaluation).  A row block still only waits for team rows of its
-    // own matrix with a smaller row index, i.e. a smaller dispatch index: any number of matrices is safe.
-    const int batch = gridDim.y, R = gridDim.x;
-    const int lin = blockIdx.x + R * blockIdx.y;
-    int rb, b;
-    if (lin < p.S * batch) {
-        rb = lin / batch;
-        b = lin - rb * batch;
-    } else {
-        const int idx = lin - p.S * batch;
-        rb = p.S + idx / batch;
-        b = idx % batch;
-    }
-    p.A += (size_t)b * p.batch_a;
-    if (p.logdet) p.logdet += b;
-    if (p.info) p.info += b;
-    const int r0 = p.k0 + 64 * rb;
-    if (rb < p.S) {
-        __builtin_amdgcn_s_setprio(3);   // the chain: never lose an issue arbitration to bulk work on the same compute unit
-        p2_row_block<true, true>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, rb, 0, rb, psm);
-    } else {
-        p2_row_block<true, false>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, p.S, 0, 0, psm);
-    }
-}
-
-static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream,
-                              bool prezeroed = false, int batch, long long batch_a) {
-    PanelArgs p{A, N, lda, k0, W / 64, logdet, info, nullptr};
-    p.batch_a = batch_a;
-    if (p.S > PNL_MAX_S) return GPAR_ARG_ERROR(5);
-    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_panel2_kernel), P2_LDS_BYTES));
-    if (!(prezeroed && potrf_flags_prezeroed(N, k0)))
-        for (int b = 0; b < batch; ++b)
-            GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)b * batch_a + (size_t)k0 * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream));
-    const int R = (N - k0 + 63) / 64;
-    hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R, batch), dim3(256), P2_LDS_BYTES, stream, p);
-    GPAR_LAUNCH_CHECK();
-    return 0;
-}
-
-// The row-block task of a triangular solve (no hand-offs: L is final) with the column blocks taken in PAIRS (c, c + 1): the row
+// The row-block task of a triangular solve (FLAGS = false: L is final) or of a panel's bulk rows (FLAGS = true: L arrives from the
+// team rows of the same launch) with the column blocks taken in PAIRS (c, c + 1): the row
 // block's tiles X[rb][u], u < c, are staged once per pair and used against L[c][u] and L[c + 1][u] in turn, and the product
 // (c + 1, c) takes X[rb][c] from the LDS tile the strip of column c has just written - 56 tile movements per 512-column block
 // instead of 72 (the bulk work of this task is bound by operand bytes: lesson 31).  Same sums in the same order: same bits.
-__device__ __forceinline__ void p2_row_block_pairs(const double* __restrict__ L, int ldl, int lrows, int lr0, int lc0, double* __restrict__ B,
-                                                   int ldb, int brows, int r0, int bc0, int ncol, double* __restrict__ psm) {
+template <bool FLAGS>
+__device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const double* __restrict__ L, int ldl, int lrows, int lr0, int lc0,
+                                                   double* __restrict__ B, int ldb, int brows, int r0, int bc0, int ncol, double* __restrict__ psm) {
     double* Cs = psm;
     double* Xs = psm + PNL_TILE;
+    unsigned long long* seen = reinterpret_cast<unsigned long long*>(psm + 2 * PNL_TILE);   // 16 words (FLAGS: progress cache)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    if (FLAGS) {
+        if (t < 16) seen[t] = 0ull;
+        __syncthreads();
+    }
     // Xs holds the row block's tile of column block c (what is to be solved), acc the products owed to it: solve, leave X in Xs, store
     auto solve_column = [&](int c, pan_d4 (&acc)[4]) {
         pan_d4 T[4];
@@ -933,15 +894,18 @@ __device__ __forceinline__ void p2_row_block_pairs(const double* __restrict__ L,
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int v = 0; v < 4; ++v) T[mi][v] = Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] - acc[mi][v];
-        __syncthreads();
+        if (FLAGS) p2_wait(p, seen, c, (unsigned long long)c + 1);   // the triangle (with its inverse blocks and flags) is out
+        else __syncthreads();
         {
             pan_d2 lt[8];
             p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * c, t, lt);
             p2_sstore(Cs, t, lt);
         }
         __syncthreads();
-        p2_inverse_blocks(Cs, w, lane);
-        __syncthreads();
+        if (!FLAGS) {
+            p2_inverse_blocks(Cs, w, lane);
+            __syncthreads();
+        }
         p2_strip(Cs, T, l15, lk);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -958,6 +922,10 @@ __device__ __forceinline__ void p2_row_block_pairs(const double* __restrict__ L,
         pan_d2 xa[8];
         p2_gload(B, ldb, brows, r0, bc0, t, xa);   // X[rb][0] - or, for c = 0, the tile to be solved itself
         if (c > 0) {
+            if (FLAGS) {   // every L[c][u] and L[c + 1][u], u < c, is out
+                p2_wait(p, seen, c, (unsigned long long)c);
+                if (pair) p2_wait(p, seen, c + 1, (unsigned long long)c);
+            }
             pan_d2 la0[8], la1[8];
             p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0, t, la0);
             p2_gload(L, ldl, lrows, lr0 + 64 * (pair ? c + 1 : c), lc0, t, la1);
@@ -987,6 +955,7 @@ __device__ __forceinline__ void p2_row_block_pairs(const double* __restrict__ L,
         solve_column(c, acc0);
         if (pair) {
             // the product (c + 1, c): X[rb][c] is in Xs (the strip has just left it there), L[c + 1][c] and the next tile to solve arrive now
+            if (FLAGS) p2_wait(p, seen, c + 1, (unsigned long long)c + 1);   // team row c + 1 has solved (and published) its strip of column c
             pan_d2 lc[8];
             p2_gload(L, ldl, lrows, lr0 + 64 * (c + 1), lc0 + 64 * c, t, lc);
             p2_gload(B, ldb, brows, r0, bc0 + 64 * (c + 1), t, xa);
@@ -1002,6 +971,55 @@ __device__ __forceinline__ void p2_row_block_pairs(const double* __restrict__ L,
     }
 }
 
+// launch bounds (256, 2): at most 256 unified registers, so that a wave fits beside a trailing-update wave (see panel.h)
+__global__ __launch_bounds__(256, 2) void potrf_panel2_kernel(PanelArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    // Batched launch (gridDim.y matrices).  Workgroups are dispatched x first, then y; the linear dispatch index is dealt so that
+    // the TEAMS of all matrices come first (team row rb of matrix b at index rb * batch + b), then the bulk row blocks, matrices
+    // interleaved: every chain starts at once instead of one matrix's bulk rows holding the slots the next matrix's team needs
+    // (same-box A/B: C3 189.8 -> 187.9 ms, C5 60.4 -> 59.7 ms per evaluation).  A row block still only waits for team rows of its
+    // own matrix with a smaller row index, i.e. a smaller dispatch index: any number of matrices is safe.
+    const int batch = gridDim.y, R = gridDim.x;
+    const int lin = blockIdx.x + R * blockIdx.y;
+    int rb, b;
+    if (lin < p.S * batch) {
+        rb = lin / batch;
+        b = lin - rb * batch;
+    } else {
+        const int idx = lin - p.S * batch;
+        rb = p.S + idx / batch;
+        b = idx % batch;
+    }
+    p.A += (size_t)b * p.batch_a;
+    if (p.logdet) p.logdet += b;
+    if (p.info) p.info += b;
+    const int r0 = p.k0 + 64 * rb;
+    if (rb < p.S) {
+        __builtin_amdgcn_s_setprio(3);   // the chain: never lose an issue arbitration to bulk work on the same compute unit
+        p2_row_block<true, true>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, rb, 0, rb, psm);
+    } else if (p.pairs) {
+        p2_row_block_pairs<true>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, p.S, psm);
+    } else {
+        p2_row_block<true, false>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, p.S, 0, 0, psm);
+    }
+}
+
+static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream,
+                              bool prezeroed = false, int batch, long long batch_a) {
+    PanelArgs p{A, N, lda, k0, W / 64, logdet, info, nullptr};
+    p.batch_a = batch_a;
+    p.pairs = env_int("GPAR_PANEL_PAIRS", 1);
+    if (p.S > PNL_MAX_S) return GPAR_ARG_ERROR(5);
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_panel2_kernel), P2_LDS_BYTES));
+    if (!(prezeroed && potrf_flags_prezeroed(N, k0)))
+        for (int b = 0; b < batch; ++b)
+            GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)b * batch_a + (size_t)k0 * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream));
+    const int R = (N - k0 + 63) / 64;
+    hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R, batch), dim3(256), P2_LDS_BYTES, stream, p);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fused block of the forward triangular solve  X L^T = B  (gpar_trsm_rlt): one workgroup per 64-row block of B carries
 // it through the S column blocks [c0, c0 + 64 S) - the same left-looking row-block task, without hand-offs.
@@ -1014,7 +1032,8 @@ __global__ __launch_bounds__(256, 2) void trsm_block2_kernel(TrsmBlockArgs a) {
         while (ufirst < a.S && a.c0 + 64 * ufirst + 63 < r0) ++ufirst;
     }
     if (!a.upper_tri && a.pairs) {
-        p2_row_block_pairs(a.L, a.ldl, a.n, a.c0, a.c0, a.B, a.ldb, a.nrows, r0, a.c0, a.S, psm);
+        const PanelArgs nothing{nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
+        p2_row_block_pairs<false>(nothing, a.L, a.ldl, a.n, a.c0, a.c0, a.B, a.ldb, a.nrows, r0, a.c0, a.S, psm);
         return;
     }
     const PanelArgs none{nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
