@@ -666,7 +666,9 @@ static int trsm_rlt_run2(const double* L, int n, int ldl, double* B, int nrows, 
     // Block width: 512-column fused blocks (panel2.h) + one GEMM update each from n = 1024 on.  (Measured on the inducing-point
     // solve of C4, K_xz L_z^-T with 65536 x 1024: 256-column blocks 20.4 ms per evaluation, 512 19.9, the whole factor in one
     // launch 20.6 - the flops are the same and the block kernel runs them at the same ~55 % of the matrix-core rate.)
-    const int NB = env_int("GPAR_TRSM_NB", n >= 1024 ? 512 : 64);
+    // Below n = 1024 the fused blocks serve as well (round 3: the 64-column strips + K = 64 updates they replace were 1.8-2.8x
+    // slower at n = 256 .. 1000 - 20000 rows: 0.18 / 0.48 / 0.83 / 1.31 ms against 0.06 / 0.20 / 0.40 / 0.75).
+    const int NB = env_int("GPAR_TRSM_NB", n >= 128 ? 512 : 64);
     const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && NB > 64 && gpar_aligned16(L) && gpar_aligned16(B) && (ldl % 2 == 0) && (ldb % 2 == 0);
     // As in gpar_potrf, while many columns remain G blocks are solved back to back (each after a narrow update of its own
     // columns by the ones before it) and everything to the right then gets ONE rank-G*NB update instead of G rank-NB ones.
@@ -985,12 +987,12 @@ static int trsv_rln_run(const double* L, int n, int ldl, double* b, hipStream_t 
 static int trsm_rln_run(const double* L, int n, int ldl, double* B, int nrows, int ldb, hipStream_t stream) {
     if (nrows <= 0) return 0;
     if (nrows == 1 && n >= 128 && env_int("GPAR_TRSV", 1)) return trsv_rln_run(L, n, ldl, B, stream);
-    // Many rows and n >= 1024: 512-column blocks from the last to the first, each solved by the fused backward block kernel
+    // From n = 128 on (round 2: 1024): 512-column blocks from the last to the first, each solved by the fused backward block kernel
     // (panel2.h) and followed by ONE K = 512 NN update of everything to its left - instead of 64-column strips with a K = 64
     // update each (16 + 16 launches per 1024 columns, the updates at a fifth of the rate).  A ragged tail (n not a multiple of
     // 64) goes first, by the strip path.
-    const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && env_int("GPAR_PANEL_V", 2) >= 2 && n >= 1024 && nrows >= 64 && gpar_aligned16(L) &&
-                         gpar_aligned16(B) && (ldl % 2 == 0) && (ldb % 2 == 0);
+    const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && env_int("GPAR_PANEL_V", 2) >= 2 && n >= env_int("GPAR_TRSM_BACK_FUSED_MIN", 128) && nrows >= 2 &&
+                         gpar_aligned16(L) && gpar_aligned16(B) && (ldl % 2 == 0) && (ldb % 2 == 0);
     int ntop = n;   // columns [0, ntop) still to be solved
     if (fusable) {
         const int rag = n % 64;
