@@ -34,10 +34,14 @@ typedef double pan_d4 __attribute__((ext_vector_type(4)));
 // for each 8-column block, (1) subtract the contribution of all previous columns (own row entries: lane-private
 // LDS reads; the other row: wave-uniform broadcast reads), (2) factor the 8 columns with pivots and column
 // entries broadcast by v_readlane, scaling by the reciprocal pivot as LAPACK's dpotf2 does.
+// (blockIdx.x selects matrix b of a lock-step batch: A + b * batch_a, logdet[b], info[b])
 __global__ __launch_bounds__(64) void potrf_diag64_kernel(double* __restrict__ A, int lda, int cb, int col0,
-                                                          double* __restrict__ logdet, int* __restrict__ info) {
+                                                          double* __restrict__ logdet, int* __restrict__ info, long long batch_a = 0) {
     __shared__ __attribute__((aligned(16))) double T[64 * PAN_LD];
     const int i = threadIdx.x;
+    A += (size_t)blockIdx.x * batch_a;
+    if (logdet) logdet += blockIdx.x;
+    if (info) info += blockIdx.x;
     {
         double v[64];
 #pragma unroll
@@ -126,12 +130,14 @@ __global__ __launch_bounds__(64) void potrf_diag64_kernel(double* __restrict__ A
 // and all global loads of a phase are issued before the first is consumed.
 template <bool FWD>
 __global__ __launch_bounds__(64) void trsm_strip_kernel(const double* __restrict__ Ld, int ldl, int cb,
-                                                        double* __restrict__ B, int ldb, int nrows) {
+                                                        double* __restrict__ B, int ldb, int nrows, long long batch_stride = 0) {
     __shared__ __attribute__((aligned(16))) double Cs[64 * PAN_LD];   // Cs[j][k]: coefficient of x_k in equation j
     __shared__ __attribute__((aligned(16))) double Xs[64 * PAN_LD];   // Xs[lane][a]: row `lane` of B / X (reversed if !FWD)
     __shared__ double rinvs[64];
     const int lane = threadIdx.x;
     const int row0 = blockIdx.x * 64;
+    Ld += (size_t)blockIdx.y * batch_stride;   // (lock-step batch: triangle and right-hand sides live in the same matrix b)
+    B += (size_t)blockIdx.y * batch_stride;
     {
         // both 64 x 64 tiles are requested before either is consumed (one memory round trip instead of two);
         // loads are unconditional from clamped, always valid addresses (see potrf_diag64_kernel)
@@ -210,9 +216,9 @@ __global__ __launch_bounds__(64) void trsm_strip_kernel(const double* __restrict
 }
 
 template <bool FWD>
-static void launch_strip(const double* Ld, int ldl, int cb, double* B, int ldb, int nrows, hipStream_t stream) {
+static void launch_strip(const double* Ld, int ldl, int cb, double* B, int ldb, int nrows, hipStream_t stream, int batch = 1, long long batch_stride = 0) {
     if (nrows <= 0) return;
-    hipLaunchKernelGGL((trsm_strip_kernel<FWD>), dim3(gpar_ceil_div(nrows, 64)), dim3(64), 0, stream, Ld, ldl, cb, B, ldb, nrows);
+    hipLaunchKernelGGL((trsm_strip_kernel<FWD>), dim3(gpar_ceil_div(nrows, 64), batch), dim3(64), 0, stream, Ld, ldl, cb, B, ldb, nrows, batch_stride);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -326,8 +332,10 @@ static int potrf_panel(const PotrfCtx& c, int c0, int c1, int nb, hipStream_t st
     const int w = c1 - c0;
     if (w <= POTRF_NBI) {
         double* Acc = c.A + (size_t)c0 * c.lda + c0;
-        hipLaunchKernelGGL(potrf_diag64_kernel, dim3(1), dim3(64), 0, stream, Acc, c.lda, w, c0, c.logdet, c.info);
-        launch_strip<true>(Acc, c.lda, w, c.A + (size_t)c1 * c.lda + c0, c.lda, c.N - c1, stream);
+        // (a lock-step batch: one launch for all its matrices - a ragged last panel used to cost `batch` serial single-wave launches,
+        // 11 % of a predict with 50 samples at n* = 1000)
+        hipLaunchKernelGGL(potrf_diag64_kernel, dim3(c.batch), dim3(64), 0, stream, Acc, c.lda, w, c0, c.logdet, c.info, c.batch_a);
+        launch_strip<true>(Acc, c.lda, w, c.A + (size_t)c1 * c.lda + c0, c.lda, c.N - c1, stream, c.batch, c.batch_a);
         return 0;
     }
     if (nb >= w) nb = (w > c.nbm && c.nbm >= POTRF_NBI) ? c.nbm : POTRF_NBI;
@@ -553,7 +561,10 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             if (fused_ok) {
                 rc = potrf_panel_any(A, N, lda, k0, w, logdet, info, stream, prezero, batch, batch_a);
             } else {
-                for (int b = 0; b < batch && !rc; ++b) {   // leaf kernels (a ragged last panel, the unfused path): matrix by matrix
+                if (batch > 1 && w <= POTRF_NBI && !pol.split) {   // a narrow (ragged last) panel of a lock-step batch: batched leaf kernels
+                    rc = potrf_panel(c, k0, kend, nbo, stream);
+                } else
+                for (int b = 0; b < batch && !rc; ++b) {   // leaf kernels (the unfused path): matrix by matrix
                     PotrfCtx cb{A + (size_t)b * batch_a, N, lda, logdet ? logdet + b : nullptr, info ? info + b : nullptr, pol.nbm};
                     rc = pol.split ? potrf_panel_split(cb, k0, kend, nbo, stream) : potrf_panel(cb, k0, kend, nbo, stream);
                 }
