@@ -878,7 +878,8 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
 // instead of 72 (the bulk work of this task is bound by operand bytes: lesson 31).  Same sums in the same order: same bits.
 template <bool FLAGS>
 __device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const double* __restrict__ L, int ldl, int lrows, int lr0, int lc0,
-                                                   double* __restrict__ B, int ldb, int brows, int r0, int bc0, int ncol, double* __restrict__ psm) {
+                                                   double* __restrict__ B, int ldb, int brows, int r0, int bc0, int ncol, double* __restrict__ psm,
+                                                   int ufirst = 0) {   // (ufirst: column blocks before it are zero and stay zero - an upper-triangular right-hand side)
     double* Cs = psm;
     double* Xs = psm + PNL_TILE;
     unsigned long long* seen = reinterpret_cast<unsigned long long*>(psm + 2 * PNL_TILE);   // 16 words (FLAGS: progress cache)
@@ -914,22 +915,22 @@ __device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const dou
         __syncthreads();
         p2_gstore(B, ldb, brows, r0, bc0 + 64 * c, Xs, t, false);
     };
-    for (int c = 0; c < ncol; c += 2) {
+    for (int c = ufirst; c < ncol; c += 2) {
         const bool pair = c + 1 < ncol;
         pan_d4 acc0[4], acc1[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) { acc0[mi] = pan_d4{0.0, 0.0, 0.0, 0.0}; acc1[mi] = pan_d4{0.0, 0.0, 0.0, 0.0}; }
         pan_d2 xa[8];
-        p2_gload(B, ldb, brows, r0, bc0, t, xa);   // X[rb][0] - or, for c = 0, the tile to be solved itself
-        if (c > 0) {
+        p2_gload(B, ldb, brows, r0, bc0 + 64 * ufirst, t, xa);   // X[rb][ufirst] - or, for c = ufirst, the tile to be solved itself
+        if (c > ufirst) {
             if (FLAGS) {   // every L[c][u] and L[c + 1][u], u < c, is out
                 p2_wait(p, seen, c, (unsigned long long)c);
                 if (pair) p2_wait(p, seen, c + 1, (unsigned long long)c);
             }
             pan_d2 la0[8], la1[8];
-            p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0, t, la0);
-            p2_gload(L, ldl, lrows, lr0 + 64 * (pair ? c + 1 : c), lc0, t, la1);
-            for (int u = 0; u < c; ++u) {
+            p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * ufirst, t, la0);
+            p2_gload(L, ldl, lrows, lr0 + 64 * (pair ? c + 1 : c), lc0 + 64 * ufirst, t, la1);
+            for (int u = ufirst; u < c; ++u) {
                 __syncthreads();   // the previous chunk's operand reads are done
                 p2_sstore(Cs, t, la0);
                 p2_sstore(Xs, t, xa);
@@ -1031,9 +1032,9 @@ __global__ __launch_bounds__(256, 2) void trsm_block2_kernel(TrsmBlockArgs a) {
     if (a.upper_tri) {
         while (ufirst < a.S && a.c0 + 64 * ufirst + 63 < r0) ++ufirst;
     }
-    if (!a.upper_tri && a.pairs) {
+    if (a.pairs) {
         const PanelArgs nothing{nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
-        p2_row_block_pairs<false>(nothing, a.L, a.ldl, a.n, a.c0, a.c0, a.B, a.ldb, a.nrows, r0, a.c0, a.S, psm);
+        p2_row_block_pairs<false>(nothing, a.L, a.ldl, a.n, a.c0, a.c0, a.B, a.ldb, a.nrows, r0, a.c0, a.S, psm, ufirst);
         return;
     }
     const PanelArgs none{nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};

@@ -6,7 +6,7 @@ from gpar_amd.engine import HipEngine, set_engine
 from gpar_amd.regression import GPARRegressor
 from gpar_amd import optimise
 set_engine(HipEngine(seed=3))
-for n in (1000, 1500, 3000, 5000):
+for n in [int(a) for a in sys.argv[1:]] or (1000, 1500, 3000, 5000):
     x, y = synthetic(n, 2, 3)
     reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1)
     reg.fit(x, y, iters=3)
