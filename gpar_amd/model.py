@@ -306,7 +306,7 @@ class GPAR:
         # after the other, when the posterior is first used) are issued now on alternating streams.
         pipe = eng.pipeline(rows=int(x.shape[0])) if self._independent(items) else None
         # ... or, when they are small, together in lock-step
-        lockstep = pipe is not None and hasattr(eng, "factor_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
+        lockstep = pipe is not None and self._same_rows(items) and hasattr(eng, "factor_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
         pending = []
         with eng.defer_checks(), _joining(pipe):  # streams are joined BEFORE the deferred info words are read
             for stage, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, self.layers))):
@@ -350,7 +350,7 @@ class GPAR:
         pipe = eng.pipeline(rows=int(x.shape[0])) if self._independent(items) and not return_inputs else None
         values, stage = [], 0
         # ... or, when they are small enough for a factorisation to be one latency-bound chain, factored together in lock-step
-        lockstep = pipe is not None and hasattr(eng, "logpdf_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
+        lockstep = pipe is not None and self._same_rows(items) and hasattr(eng, "logpdf_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
         pending = []
         with eng.defer_checks(), _joining(pipe):  # streams are joined BEFORE the deferred info words are read
             for is_last, ((yi, wi, mask), model) in last(zip(items, self.layers), select=outputs):
@@ -400,12 +400,21 @@ class GPAR:
         return total.cpu() if total.is_cuda and not total.requires_grad else total
 
     def _independent(self, items):
-        """No layer needs anything a previous layer computes: complete data (slice masks), no `replace`, no
-        inducing points - the design matrix of layer i is just [x, y_<i]."""
-        def all_rows(mask):  # slices on the GPU (per_output); an all-True boolean mask on the CPU (free to test there)
-            return isinstance(mask, slice) or (not mask.is_cuda and bool(mask.all()))
+        """No layer needs anything a previous layer computes: no `replace`, no inducing points, and nothing to impute - complete
+        data (slice masks), or rows dropped per layer with every kept row observed (`impute=False` with missing data; known
+        without a synchronisation when the NaN pattern was planned on the host) - the design matrix of layer i is just [x, y_<i]."""
+        def nothing_missing(item):
+            yi, _, mask = item
+            if isinstance(mask, slice) or getattr(yi, "_n_missing", None) == 0:
+                return True
+            return not mask.is_cuda and mask.dtype == torch.bool and bool(mask.all())   # an all-True mask on the CPU (free to test there)
 
-        return not self.replace and not self.sparse and len(items) > 1 and all(all_rows(mask) for _, _, mask in items)
+        return not self.replace and not self.sparse and len(items) > 1 and all(nothing_missing(item) for item in items)
+
+    @staticmethod
+    def _same_rows(items):
+        """Every layer sees all rows (what lock-step batches need: one matrix size)."""
+        return all(isinstance(mask, slice) or (not mask.is_cuda and mask.dtype == torch.bool and bool(mask.all())) for _, _, mask in items)
 
     # ---- sampling ----------------------------------------------------------------------------------
     def sample(self, x, w, latent=False):

@@ -71,7 +71,7 @@ def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
     # this rank's layers alternate over two streams when no layer feeds another (see HipEngine.pipeline) ...
     pipe = eng.pipeline(rows=int(x.shape[0])) if gpar._independent(items) else None
     # ... or are factored together in lock-step
-    lockstep = pipe is not None and hasattr(eng, "logpdf_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
+    lockstep = pipe is not None and gpar._same_rows(items) and hasattr(eng, "logpdf_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
     pending = []
     values, stage = [], 0
     with _joining(pipe):
@@ -201,7 +201,7 @@ def sharded_condition(reg, group=None):
     post = gpar.copy()
     pipe = eng.pipeline(rows=int(x.shape[0]))
     # this rank's layers: in lock-step when they are small enough, else over its streams
-    lockstep = pipe is not None and hasattr(eng, "factor_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
+    lockstep = pipe is not None and gpar._same_rows(items) and hasattr(eng, "factor_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
     factors, mine = [], []
     with eng.defer_checks(), joining(pipe):
         for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, gpar.layers))):
