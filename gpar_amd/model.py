@@ -19,6 +19,14 @@ from .gp import Obs, PseudoObs, PseudoObsDTC, PseudoObsFITC, Stacked
 __all__ = ["GPAR", "merge", "construct_model", "last", "per_output"]
 
 
+def host_masks():
+    """GPAR_HOST_MASKS=0: missing-data masks as boolean device tensors, computed layer by layer (the first implementation: it
+    synchronises about ten times per layer); default: planned once on the host (per_output)."""
+    import os
+
+    return os.environ.get("GPAR_HOST_MASKS", "1") != "0"
+
+
 def _is_torch(a):
     return isinstance(a, torch.Tensor)
 
@@ -279,7 +287,7 @@ class GPAR:
                 host_nan = np.isnan(y)
             y = eng.tensor(y)
             w = eng.tensor(w)
-            if _is_torch(y) and y.is_cuda and y.dim() == 2:
+            if _is_torch(y) and y.is_cuda and y.dim() == 2 and host_masks():
                 if host_nan is None:
                     host_nan = torch.isnan(y).cpu().numpy()
                 y._host_nan = host_nan if host_nan.ndim == 2 else None

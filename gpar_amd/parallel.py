@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 
 from .engine import get_engine
-from .model import last, per_output
+from .model import host_masks, last, per_output
 
 __all__ = ["world", "sharded_logpdf", "sharded_fit", "sharded_condition", "sharded_sample"]
 
@@ -149,6 +149,8 @@ def sharded_fit(reg, x, y, w=None, group=None, **kw_args):
     eng = get_engine()
     reg.condition(x, y, w)
     x_dev, y_dev, w_dev = eng.tensor(reg.x), eng.tensor(reg.y), eng.tensor(reg.w)
+    if isinstance(reg.y, np.ndarray) and y_dev.is_cuda and host_masks():
+        y_dev._host_nan = np.isnan(reg.y)   # (masks planned on the host, see GPAR._prep)
     y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
     if not layers_train_independently(reg, y_dev):
         # inputs of layer pi depend on the trained layers < pi: the chain is sequential; train replicated

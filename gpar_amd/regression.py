@@ -16,7 +16,7 @@ import torch
 from .engine import get_engine
 from .gp import GP, Measure
 from .kernels import EQ, RQ, Linear, ZeroKernel
-from .model import GPAR, per_output
+from .model import GPAR, host_masks, per_output
 from .optimise import minimise_l_bfgs_b
 from .vars import Vars
 
@@ -273,6 +273,8 @@ class GPARRegressor:
         self._x_ind_trainable = bool(optimise_x_ind) or getattr(self, "_x_ind_trainable", False)
         eng = get_engine()
         x_dev, y_dev, w_dev = eng.tensor(self.x), eng.tensor(self.y), eng.tensor(self.w)
+        if isinstance(self.y, np.ndarray) and y_dev.is_cuda and host_masks():
+            y_dev._host_nan = np.isnan(self.y)   # (per_output then plans the masks on the host: no synchronisation per layer and evaluation)
         y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
         self._prepare_kernels(self.m, self.p, self.n, training=True, inputs=not fix or bool(optimise_x_ind))
 

@@ -73,10 +73,15 @@ def _run(kind, kw, x, y, w, xs):
         set_engine(previous)
 
 
-@pytest.mark.parametrize("seed", range(96))
-def test_random_configuration(seed):
+@pytest.mark.parametrize("seed", [-s - 1 for s in range(24)] + list(range(96)))
+def test_random_configuration(seed, monkeypatch):
+    """(negative seeds: case -seed - 1 once more with GPAR_HOST_MASKS=0 - boolean device masks computed layer by layer, the
+    path every engine but the HIP one still takes - so that both ways through the missing-data bookkeeping stay covered)"""
     from oracle import gpar_ref
 
+    if seed < 0:
+        monkeypatch.setenv("GPAR_HOST_MASKS", "0")
+        seed = -seed - 1
     kw, x, y, w, xs = _case(seed)
     sparse = "x_ind" in kw
     prior, post, sample, hypers, config = _run("hip", kw, x, y, w, xs)

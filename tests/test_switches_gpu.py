@@ -34,6 +34,7 @@ CALL_TIME = [
     ("GPAR_TRSM_GROUP", "2"),
     ("GPAR_TRSM_PAIRS", "0"),
     ("GPAR_PANEL_PAIRS", "0"),
+    ("GPAR_HOST_MASKS", "0"),
     ("GPAR_TRSM_PAIR_COLS", "1024"),
     ("GPAR_LAYER_PIPELINE", "0"),
     ("GPAR_LAYER_PIPELINE", "3"),
