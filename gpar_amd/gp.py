@@ -412,7 +412,7 @@ class GP:
         """One draw of f (+ noise) at each input set in `xs` (a list of n* x D matrices, e.g. the per-sample design
         matrices of ancestral sampling): returns an n* x len(xs) matrix.  For a dense posterior the expensive step -
         V_s = K(x_s, X) L^-T for every s - is ONE stacked triangular solve instead of len(xs) separate ones."""
-        if self.is_posterior and self._obs.fast_dense:
+        if self.is_posterior and (self._obs.fast_dense or getattr(self._obs, "fast_sparse", False)):
             return self._obs.posterior_sample_batch(xs, noise)
         return torch.cat([self(x_s, noise).sample() for x_s in xs], dim=1)
 
@@ -423,7 +423,7 @@ class GP:
         eng = self.engine
         S = len(xs)
         ns = int(xs[0].shape[0])
-        if self.is_posterior and self._obs.fast_dense:
+        if self.is_posterior and (self._obs.fast_dense or getattr(self._obs, "fast_sparse", False)):
             mean, var = self._obs.posterior_marginals_batch(xs)
         else:
             moments = [self.marginal_moments(x_s) for x_s in xs]
@@ -436,7 +436,7 @@ class GP:
         return mean + torch.sqrt(torch.clamp(var + eng.epsilon, min=0.0)) * eng.randn(ns, S)
 
     def mean_batch(self, xs):
-        if self.is_posterior and self._obs.fast_dense and len(xs) > 1:
+        if self.is_posterior and (self._obs.fast_dense or getattr(self._obs, "fast_sparse", False)) and len(xs) > 1:
             return self._obs.posterior_mean_batch(xs)
         return [self.mean(x_s) for x_s in xs]
 
@@ -1138,6 +1138,97 @@ class PseudoObs:
         out = self.base._diag(p) - eng.rownorm2(P)
         eng.trsm_rlt_(st["La"], P)
         return out + eng.rownorm2(P)
+
+    # ---- batched sampling (ancestral sampling hands every layer S input sets of one size: GPAR.sample_many) ----------------
+    @property
+    def fast_sparse(self):
+        """The batched routines below are written for inducing-point observations of a PRIOR process (what GPAR builds)."""
+        return not self.base.is_posterior
+
+    def _stacked_P(self, xs):
+        """For the input sets stacked by rows: (features, K(x_s, Z), P_s = K(x_s, Z) L_z^-T), ONE launch each."""
+        eng, st = self.eng, self._compute()
+        ck, zu = self.u.features()
+        stacked = xs.matrix if isinstance(xs, Stacked) else torch.cat([_as_matrix(eng, x_s) for x_s in xs], dim=0)
+        z_all = eng.features(ck, _as_matrix(eng, stacked))
+        Kz = eng.new_matrix(z_all.shape[0], self.u.n)
+        eng.gram(ck, z_all, zu, out=Kz)
+        P = Kz.clone()
+        eng.trsm_rlt_(st["Lz"], P)
+        return ck, z_all, Kz, P
+
+    def _sparse_chunk(self, ns):
+        return max(1, min(16384, int(16e9 // max(1, ns * max(self.u.n, ns, 1) * 8))))
+
+    def posterior_mean_batch(self, xs):
+        """Posterior means K(x_s, Z) v at several input sets with one stacked cross-Gram product."""
+        eng, st = self.eng, self._compute()
+        ck, zu = self.u.features()
+        sizes = [int(x_s.shape[0]) for x_s in xs]
+        stacked = xs.matrix if isinstance(xs, Stacked) else torch.cat([_as_matrix(eng, x_s) for x_s in xs], dim=0)
+        Kz = eng.new_matrix(sum(sizes), self.u.n)
+        eng.gram(ck, eng.features(ck, _as_matrix(eng, stacked)), zu, out=Kz)
+        return list(torch.split(eng.gemm(Kz, st["v"], tb=True), sizes, dim=0))
+
+    def posterior_marginals_batch(self, xs):
+        """(means, variances), each n* x S (no noise):  k_aa - |P_a|^2 + |P_a L_A^-T|^2  per point."""
+        eng, st = self.eng, self._compute()
+        S, ns = len(xs), int(xs[0].shape[0])
+        dev = self.y.device
+        mean = torch.zeros(ns, S, dtype=torch.float64, device=dev)
+        var = torch.empty(ns, S, dtype=torch.float64, device=dev)
+        chunk = self._sparse_chunk(ns)
+        for s0 in range(0, S, chunk):
+            s1 = min(S, s0 + chunk)
+            ck, z_all, Kz, P = self._stacked_P(xs[s0:s1])
+            mean[:, s0:s1] = eng.gemm(Kz, st["v"], tb=True).reshape(s1 - s0, ns).T
+            kd = eng.gram_diag(ck, z_all) - eng.rownorm2(P)
+            eng.trsm_rlt_(st["La"], P)
+            var[:, s0:s1] = (kd + eng.rownorm2(P)).reshape(s1 - s0, ns).T
+        return mean, var
+
+    def posterior_sample_batch(self, xs, noise):
+        """One joint draw at each input set: mean_s + chol(K_ss - P_s P_s^T + R_s R_s^T + noise + eps I) z_s with P_s = K(x_s, Z) L_z^-T,
+        R_s = P_s L_A^-T - the stacked cross-Gram, both triangular solves, the per-sample Gram builds, the two rank-M corrections
+        and the n* x n* factorisations each ONE (batched / lock-step) launch sequence for all samples, as the dense posterior's
+        sampler does it.  (Until round 3 every sample went through `f(x_s).sample()` on its own: `predict` with 50 samples at
+        n* = 1000, M = 300 took 85 ms - four times the DENSE posterior's 21 ms.)"""
+        eng, st = self.eng, self._compute()
+        S, ns = len(xs), int(xs[0].shape[0])
+        out = torch.empty(ns, S, dtype=torch.float64, device=self.y.device)
+        if ns == 0:
+            return out
+        noise_vec = _noise_vector(eng, noise, ns)
+        zr = eng.randn(ns, S)
+        chunk = self._sparse_chunk(ns)
+        for s0 in range(0, S, chunk):
+            s1 = min(S, s0 + chunk)
+            K = s1 - s0
+            ck, z_all, Kz, P = self._stacked_P(xs[s0:s1])
+            means = eng.gemm(Kz, st["v"], tb=True)
+            batched = K > 1 and hasattr(eng, "potrf_batch_") and ns <= eng.batch_rows() and not getattr(eng._tls, "safe", False)
+            if batched:
+                covs = eng.new_matrix(K * ns, ns)
+                eng.gram_batch_(ck, z_all, K, covs, lower=True, diag_add=noise_vec, diag_const=eng.epsilon)
+                eng.gemm_batch_(P, P, covs, K, tb=True, alpha=-1.0, beta=1.0, c_lower=True)
+                eng.trsm_rlt_(st["La"], P)
+                eng.gemm_batch_(P, P, covs, K, tb=True, alpha=1.0, beta=1.0, c_lower=True)
+                _, info = eng.potrf_batch_(covs, K)
+                eng.check_info(info)
+                eng.trmv_lower_batch_(covs, K, zr[:, s0:s1], out[:, s0:s1], add=means)
+                continue
+            R = P.clone()
+            eng.trsm_rlt_(st["La"], R)
+            for k in range(K):
+                rows = slice(k * ns, (k + 1) * ns)
+                cov = eng.new_matrix(ns, ns)
+                eng.gram(ck, z_all[rows], lower=True, diag_add=noise_vec, diag_const=eng.epsilon, out=cov)
+                eng.gemm(P[rows], P[rows], tb=True, alpha=-1.0, beta=1.0, out=cov, c_lower=True)
+                eng.gemm(R[rows], R[rows], tb=True, alpha=1.0, beta=1.0, out=cov, c_lower=True)
+                _, info = eng.potrf_(cov)
+                eng.check_info(info)
+                out[:, s0 + k : s0 + k + 1] = eng.trmv_lower(cov, zr[:, s0 + k : s0 + k + 1]) + means[rows]
+        return out
 
     def moments_into(self, p, block, diag_add, jitter):
         eng, st = self.eng, self._compute()
