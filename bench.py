@@ -362,11 +362,11 @@ def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=20, num_samples=1
     default of 100 joint posterior samples, at n* = 2048 held-out inputs) on the same data - the other half of
     BASELINE.json's metric, at the stated size.  One rank: GPARRegressor.fit / predict.  Several ranks: layer pi is trained
     on rank pi mod N (parallel.sharded_fit, hyper-parameters broadcast afterwards), the conditioning is layer-parallel and
-    the posterior samples are split over the ranks (parallel.sharded_sample)."""
+    the posterior samples are split over the ranks and reduced on the device (parallel.sharded_predict)."""
     import torch
 
     from gpar_amd import optimise
-    from gpar_amd.parallel import sharded_fit, sharded_sample
+    from gpar_amd.parallel import sharded_fit, sharded_predict
 
     def sync():
         torch.cuda.synchronize()
@@ -381,21 +381,22 @@ def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=20, num_samples=1
     evals_before = optimise.evaluation_count()
     sync()
     t0 = time.perf_counter()
+    fit_mode = "single process"
     if world == 1:
         reg.fit(x_np, y_np, iters=fit_iters)
     else:
-        sharded_fit(reg, x_np, y_np, iters=fit_iters)
+        fit_mode = sharded_fit(reg, x_np, y_np, iters=fit_iters)
     sync()
     t1 = time.perf_counter()
     if world == 1:
         mean = reg.predict(xs, num_samples=num_samples, latent=True)
     else:
-        mean = np.mean(sharded_sample(reg, xs, num_samples=num_samples, latent=True), axis=0)
+        mean = sharded_predict(reg, xs, num_samples=num_samples, latent=True)   # (samples stay on the device; gpar_sample_stats)
     sync()
     t2 = time.perf_counter()
     leg = {"fit_ms": 1e3 * (t1 - t0), "fit_iters": fit_iters, "fit_evaluations": optimise.evaluation_count() - evals_before,
            "predict_ms": 1e3 * (t2 - t1), "num_samples": num_samples, "n_star": n_star,
-           "fit_predict_ms": 1e3 * (t2 - t0), "predict_mean_abs": float(np.mean(np.abs(mean))), "n_gpus": world,
+           "fit_predict_ms": 1e3 * (t2 - t0), "predict_mean_abs": float(np.mean(np.abs(mean))), "n_gpus": world, "fit_parallelism": fit_mode,
            "timing": "barrier-bracketed wall-clock on rank 0; predict = joint ancestral sampling exactly as the reference's "
                      "predict (conditioning + num_samples posterior draws + Monte-Carlo reduction)"}
     if world == 1 and hasattr(reg, "predict") and "marginal" in reg.predict.__code__.co_varnames:

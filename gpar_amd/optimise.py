@@ -35,8 +35,11 @@ def minimise_l_bfgs_b(f, vs, names=None, iters=1000, f_calls=10000, trace=False)
         return vs.match(patterns) if patterns is not None else vs.names
 
     names = select()
-    if not names:
-        # the objective creates its variables lazily (reference regression.py:92-180): evaluate once
+    unmatched = patterns is not None and any(not vs.match(p) for p in ([patterns] if isinstance(patterns, str) else patterns))
+    if not names or unmatched:
+        # The objective creates its variables lazily (reference regression.py:92-180), and varz evaluates it once before it
+        # resolves the names: with fix=False the patterns "0/*" .. "{pi}/*" must pick up layer pi's variables, which do not
+        # exist before the first evaluation of the (pi + 1)-layer model.  Evaluated once here whenever a pattern matches nothing.
         with torch.no_grad():
             f(vs)
         names = select()

@@ -10,9 +10,19 @@ ranks is decided by the model, exactly as in /root/reference/gpar/model.py:291-3
   * otherwise (posterior means are fed forward): the owner of layer i computes the new input column (and the new
     inducing-input column) and broadcasts it — n x 8 bytes per layer, latency-bound — before layer i+1 can start.
 
+With `markov=k` a forwarded column is read by the next k layers only (reference regression.py:49-59: the kernel of layer j
+selects the last k outputs), so it is SENT to the owners of those layers alone (point-to-point) instead of broadcast; ranks
+that never read a column hold NaN in its place (a violation would be loud).
+
 `fit(fix=True)` trains each layer on its owner (the optimiser only touches names "{i}/*", reference
 regression.py:453-454) and then broadcasts the trained latent variables so every rank holds the same `Vars`.
-`predict` conditions every layer on every rank and splits the Monte-Carlo samples across ranks.
+`fit(fix=False)` (the joint objective, reference regression.py:447-456) shards the sum over layers the same way: every rank
+evaluates its layers' terms and their gradients, one all-reduce adds values and gradient vectors (the slices "{i}/*" are
+disjoint, the tied "0/input/scales" receives every layer's contribution), and ONE L-BFGS-B driver on rank 0 broadcasts the
+iterates.  Where layer inputs are posterior means of earlier layers (`replace`, imputation, inducing points) training is
+REPLICATED: every rank runs the serial `fit` (`sharded_fit` returns which of the three it did).
+`predict` conditions layer-parallel (`sharded_condition`), splits the Monte-Carlo samples across ranks, all-gathers the
+device-resident sample stacks once and reduces them with `gpar_sample_stats` (`sharded_predict`).
 """
 import numpy as np
 import torch
@@ -21,7 +31,7 @@ import torch.distributed as dist
 from .engine import get_engine
 from .model import host_masks, last, per_output
 
-__all__ = ["world", "sharded_logpdf", "sharded_fit", "sharded_condition", "sharded_sample"]
+__all__ = ["world", "sharded_logpdf", "sharded_fit", "sharded_condition", "sharded_sample", "sharded_predict", "forward_plan"]
 
 
 def world(group=None):
@@ -63,11 +73,73 @@ def sharded_logpdf(gpar, x, y, w, group=None, timing=None):
     return local
 
 
+def _columns_read(kernel, width):
+    """Design-matrix columns a layer kernel reads (a factor without a selection reads all `width` of them)."""
+    cols = set()
+    for term in kernel.terms:
+        for factor in term.factors:
+            cols.update(range(width) if factor.cols is None else (int(c) for c in factor.cols))
+    return cols
+
+
+def forward_plan(gpar, m, size):
+    """needs[i] = ranks that read output column i (design-matrix column m + i): the owners (j mod size) of the layers j > i whose
+    kernel selects it - all later layers without `markov`, the next k with `markov=k` (reference regression.py:49-59).  The
+    owner of layer j also evaluates layer j's posterior mean when it forwards column j, through the same kernel."""
+    import os
+
+    count = len(gpar.layers)
+    if os.environ.get("GPAR_MARKOV_SENDS", "1") == "0":
+        return [set(range(size)) for _ in range(count)]
+    needs = [set() for _ in range(count)]
+    for j, model in enumerate(gpar.layers):
+        f, _ = model()
+        for c in _columns_read(f.kernel, m + j):
+            if m <= c < m + j:
+                needs[c - m].add(j % size)
+    return needs
+
+
+def _forward(col, ind_col, mine, owner, receivers, rank, size, group):
+    """The forwarded column (and its inducing-input counterpart) from `owner` to `receivers` (group ranks): one broadcast when
+    every other rank reads it, point-to-point sends otherwise; ranks that do not read it get NaN."""
+    others = set(range(size)) - {owner}
+    targets = set(receivers) - {owner}
+    if not targets:
+        if not mine:
+            col.fill_(float("nan"))
+            if ind_col is not None:
+                ind_col.fill_(float("nan"))
+        return
+    if targets == others:
+        dist.broadcast(col, src=_global_rank(owner, group), group=group)
+        if ind_col is not None:
+            dist.broadcast(ind_col, src=_global_rank(owner, group), group=group)
+        return
+    # one message per receiver: [column; inducing column]
+    packed = col.reshape(-1) if ind_col is None else torch.cat([col.reshape(-1), ind_col.reshape(-1)])
+    if mine:
+        packed = packed.contiguous()
+        for work in [dist.isend(packed, dst=_global_rank(r, group), group=group) for r in sorted(targets)]:
+            work.wait()
+    elif rank in targets:
+        buf = torch.empty_like(packed)
+        dist.recv(buf, src=_global_rank(owner, group), group=group)
+        col.copy_(buf[: col.numel()].reshape(col.shape))
+        if ind_col is not None:
+            ind_col.copy_(buf[col.numel():].reshape(ind_col.shape))
+    else:
+        col.fill_(float("nan"))
+        if ind_col is not None:
+            ind_col.fill_(float("nan"))
+
+
 def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
     from .model import _differentiable, _joining, _lockstep_values
 
     items = list(per_output(y, w, keep=gpar.impute))
     eng = get_engine()
+    needs = forward_plan(gpar, int(x.shape[1]), size) if size > 1 else None
     # this rank's layers alternate over two streams when no layer feeds another (see HipEngine.pipeline) ...
     pipe = eng.pipeline(rows=int(x.shape[0])) if gpar._independent(items) else None
     # ... or are factored together in lock-step (DESIGN 3.7b)
@@ -111,9 +183,7 @@ def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
                 if ind_col is not None:
                     ind_col.copy_(x_ind_new[:, -1:])
             if size > 1:
-                dist.broadcast(col, src=_global_rank(i % size, group), group=group)
-                if ind_col is not None:
-                    dist.broadcast(ind_col, src=_global_rank(i % size, group), group=group)
+                _forward(col, ind_col, mine, i % size, needs[i], rank, size, group)
             x = torch.cat([x, col], dim=1)
             if ind_col is not None:
                 x_ind = torch.cat([x_ind, ind_col], dim=1)
@@ -136,12 +206,29 @@ def layers_train_independently(reg, y):
     """With `fix=True`, is the training of layer pi independent of the training of the other layers?  Its inputs must be
     data only (no `replace`, no inducing points, nothing to impute) and it must not share a hyper-parameter with
     another layer (`scale_tie` reads "0/input/scales", which only layer 0 trains)."""
-    return not (reg.replace or reg.sparse or reg.model_config.get("scale_tie", False)
-                or (reg.impute and bool(torch.isnan(y).any())))
+    return inputs_are_data(reg, y) and not reg.model_config.get("scale_tie", False)
 
 
-def sharded_fit(reg, x, y, w=None, group=None, **kw_args):
-    """`GPARRegressor.fit(x, y, w, fix=True)` with layer pi trained on rank pi mod G, then synchronised."""
+def inputs_are_data(reg, y):
+    """Every layer's design matrix is [x, observed y_<i]: nothing a layer computes is fed to a later one (no `replace`, no
+    inducing points, nothing to impute), so the terms of the log-likelihood are separate functions of the hyper-parameters."""
+    return not (reg.replace or reg.sparse or (reg.impute and bool(torch.isnan(y).any())))
+
+
+def _tag_host_nan(reg, y_dev):
+    """The NaN pattern of the (host-resident) training outputs, attached for per_output: masks planned on the host (GPAR._prep)."""
+    if y_dev.is_cuda and host_masks():
+        y_dev._host_nan = torch.isnan(reg.y).numpy()
+
+
+def sharded_fit(reg, x, y, w=None, group=None, fix=True, **kw_args):
+    """`GPARRegressor.fit(x, y, w, fix=fix)` over the ranks of `group`; every rank ends up with the same hyper-parameters.
+    Returns what it did:
+      "layer-parallel"  fix=True, inputs are data, no tied scales: layer pi trained on rank pi mod G, results broadcast;
+      "joint-sharded"   fix=False, inputs are data: the reference's p successive joint optimisations (layers 0..pi together,
+                        regression.py:447-456) with the sum over layers divided over the ranks - see `_minimise_sharded`;
+      "replicated"      layer inputs are posterior means of earlier layers (or, with fix=True, scales are tied): the chain is
+                        sequential, every rank runs the serial `fit`."""
     from .optimise import minimise_l_bfgs_b
     from .regression import _construct_gpar
 
@@ -149,27 +236,40 @@ def sharded_fit(reg, x, y, w=None, group=None, **kw_args):
     eng = get_engine()
     reg.condition(x, y, w)
     x_dev, y_dev, w_dev = eng.tensor(reg.x), eng.tensor(reg.y), eng.tensor(reg.w)
-    if isinstance(reg.y, np.ndarray) and y_dev.is_cuda and host_masks():
-        y_dev._host_nan = np.isnan(reg.y)   # (masks planned on the host, see GPAR._prep)
-    y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
-    if not layers_train_independently(reg, y_dev):
+    _tag_host_nan(reg, y_dev)
+    if not inputs_are_data(reg, y_dev) or (fix and not layers_train_independently(reg, y_dev)):
         # inputs of layer pi depend on the trained layers < pi: the chain is sequential; train replicated
-        reg.fit(x, y, w, fix=True, **kw_args)
-        return
+        reg.fit(x, y, w, fix=fix, **kw_args)
+        return "replicated"
+    y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
     # instantiate every variable on every rank (lazy creation, reference regression.py:92-180)
     with torch.no_grad():
         _construct_gpar(reg, reg.vs, reg.m, reg.p).logpdf(x_dev[:2], y_dev[:2], w_dev[:2])
+    # the design matrix of an owned layer, [x, y_<pi] with its rows: data only, so it is formed once
+    fixed = {}
     for pi in range(reg.p):
-        if pi % size != rank:
-            continue
-        gpar = _construct_gpar(reg, reg.vs, reg.m, pi + 1)
-        fixed_x, fixed_x_ind = gpar.logpdf(x_dev, y_cached, None, only_last_layer=True, outputs=list(range(pi)), return_inputs=True)
+        if pi % size == rank:
+            gpar = _construct_gpar(reg, reg.vs, reg.m, pi + 1)
+            fixed[pi] = gpar.logpdf(x_dev, y_cached, None, only_last_layer=True, outputs=list(range(pi)), return_inputs=True)
 
-        def objective(vs, pi=pi, fixed_x=fixed_x, fixed_x_ind=fixed_x_ind):
-            g = _construct_gpar(reg, vs, reg.m, pi + 1)
-            return -g.logpdf(fixed_x, y_cached, None, only_last_layer=True, outputs=[pi], x_ind=fixed_x_ind)
+    def term(vs, pi):
+        g = _construct_gpar(reg, vs, reg.m, pi + 1)
+        return -g.logpdf(fixed[pi][0], y_cached, None, only_last_layer=True, outputs=[pi], x_ind=fixed[pi][1])
 
-        minimise_l_bfgs_b(objective, reg.vs, names=[f"{pi}/*"], **kw_args)
+    if not fix:
+        for pi in range(reg.p):
+            owned = [i for i in range(pi + 1) if i % size == rank]
+
+            def local_objective(vs, owned=owned):
+                total = torch.zeros((), dtype=torch.float64)
+                for i in owned:
+                    total = total + term(vs, i)
+                return total
+
+            _minimise_sharded(local_objective, reg.vs, [f"{i}/*" for i in range(pi + 1)], group, **kw_args)
+        return "joint-sharded"
+    for pi in fixed:
+        minimise_l_bfgs_b(lambda vs, pi=pi: term(vs, pi), reg.vs, names=[f"{pi}/*"], **kw_args)
     if size > 1:
         for pi in range(reg.p):
             names = reg.vs.match([f"{pi}/*"])
@@ -178,6 +278,84 @@ def sharded_fit(reg, x, y, w=None, group=None, **kw_args):
             vec = torch.as_tensor(reg.vs.get_vector(names), dtype=torch.float64).to(eng.device)
             dist.broadcast(vec, src=_global_rank(pi % size, group), group=group)
             reg.vs.set_vector(vec.cpu().numpy(), names)
+    return "layer-parallel"
+
+
+def _minimise_sharded(local_objective, vs, patterns, group, iters=1000, f_calls=10000, trace=False):
+    """L-BFGS-B over the variables matching `patterns` of an objective that is a SUM of per-rank terms: `local_objective(vs)`
+    is this rank's share.  One evaluation = every rank evaluates its share and back-propagates, then ONE all-reduce adds
+    [value, gradient] over the ranks (a variable only this rank's layers read gets zeros from the others; a tied variable gets
+    every layer's contribution).  The optimiser itself runs on rank 0 only and broadcasts each iterate - [1, x] to evaluate,
+    [0, x_opt] to finish - so the ranks cannot drift apart, whatever their arithmetic.  Returns the final objective value."""
+    import logging
+
+    import scipy.optimize
+
+    from . import optimise
+    from .engine import NotPositiveDefiniteError
+
+    rank, size = world(group)
+    eng = get_engine()
+    names = vs.match(patterns)
+    latents = vs.get_vars(*names)
+    if not latents:
+        raise ValueError("no variables to optimise")
+    x0 = vs.get_vector(names)
+    dim = x0.size
+
+    def evaluate(xvec):
+        optimise._evaluations += 1
+        vs.set_vector(xvec, names)
+        previous = [t.requires_grad for t in latents]
+        for t in latents:
+            t.requires_grad_(True)
+            t.grad = None
+        try:
+            value = local_objective(vs)
+            if value.requires_grad:
+                value.backward()
+            grad = np.concatenate([(t.grad if t.grad is not None else torch.zeros_like(t)).detach().numpy().reshape(-1) for t in latents])
+            val = float(value.detach())
+        except (NotPositiveDefiniteError, ArithmeticError) as e:  # as varz: report NaN and let the line search back off
+            logging.getLogger(__name__).warning("objective evaluation failed (%s); returning NaN", e)
+            val, grad = np.nan, np.zeros(dim)
+        finally:
+            for t, r in zip(latents, previous):
+                t.requires_grad_(r)
+                t.grad = None
+        buf = torch.as_tensor(np.concatenate([[val], grad]), dtype=torch.float64).to(eng.device)
+        if size > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        out = buf.cpu().numpy()
+        val, grad = float(out[0]), out[1:].copy()
+        if not np.isfinite(val):
+            val, grad = np.nan, np.zeros(dim)   # some rank's share failed: a failed evaluation for everybody
+        if trace and rank == 0:
+            print(f"  objective {val:.6e}  |grad| {np.linalg.norm(grad):.3e}")
+        return val, grad
+
+    def announce(flag, xvec):
+        ctrl = torch.as_tensor(np.concatenate([[flag], np.asarray(xvec, dtype=np.float64)]), dtype=torch.float64).to(eng.device)
+        if size > 1:
+            dist.broadcast(ctrl, src=_global_rank(0, group), group=group)
+        return ctrl.cpu().numpy()
+
+    if rank == 0:
+        def fg(xvec):
+            announce(1.0, xvec)
+            return evaluate(xvec)
+
+        x_opt, val, _ = scipy.optimize.fmin_l_bfgs_b(fg, x0, maxiter=iters, maxfun=f_calls)
+        announce(0.0, x_opt)
+        vs.set_vector(x_opt, names)
+        return val
+    val = np.nan
+    while True:
+        ctrl = announce(0.0, np.zeros(dim))
+        if ctrl[0] == 0.0:
+            vs.set_vector(ctrl[1:], names)
+            return val
+        val, _ = evaluate(ctrl[1:])
 
 
 def sharded_condition(reg, group=None):
@@ -194,7 +372,9 @@ def sharded_condition(reg, group=None):
     gpar = _construct_gpar(reg, reg.vs, reg.m, reg.p)
     x, y, w = gpar._prep(reg.x, reg.y, reg.w)
     items = list(per_output(y, w, keep=gpar.impute))
-    if size == 1 or not gpar._independent(items):
+    if size == 1 or not gpar._independent(items) or not gpar._same_rows(items):
+        # (layers whose rows differ - `impute=False` with missing data - are independent too, but their factors do not share a
+        # shape: they are conditioned locally rather than exchanged)
         return gpar | (reg.x, reg.y, reg.w)
     from .engine import joining
 
@@ -242,7 +422,8 @@ def _exchange_factors(eng, factors, rank, size, group):
         mine = first + rank
         sizes = [f.n + 1 for f in factors[first : first + size]]
         if len(set(sizes)) != 1:
-            # ragged layers (cannot happen in the independent regime this is used for): one broadcast per layer
+            # ragged layers (sharded_condition only exchanges layers that share their rows; kept for direct callers): one
+            # broadcast per layer
             for i in range(first, min(first + size, count)):
                 buf = factors[i].A._base if factors[i].A._base is not None else factors[i].A
                 dist.broadcast(buf, src=_global_rank(i % size, group), group=group)
@@ -262,27 +443,47 @@ def _exchange_factors(eng, factors, rank, size, group):
                 eng.unpack_lower_(recv[r], factors[i].A)
 
 
-def sharded_sample(reg, x, w=None, num_samples=100, latent=False, group=None):
-    """Posterior samples split over ranks: the conditioning is layer-parallel (`sharded_condition`), each rank then draws
-    its share with its own Philox stream, and the shares are all-gathered.  Returns the full list of `num_samples` arrays
-    on every rank."""
+def _sharded_sample_stack(reg, x, w, num_samples, latent, group, marginal=False):
+    """(S x n* x p device tensor holding every rank's draws, in rank order; the per-rank counts): the conditioning is
+    layer-parallel (`sharded_condition`), each rank draws its share with its own Philox stream, and the device-resident stacks
+    are all-gathered ONCE - no sample visits the host."""
     rank, size = world(group)
     eng = get_engine()
     counts = [num_samples // size + (1 if r < num_samples % size else 0) for r in range(size)]
     eng.seed(getattr(eng, "_seed", 0) * 1000003 + rank + 1)
     post = sharded_condition(reg, group) if size > 1 else None
-    mine = reg.sample(x, w, posterior=True, num_samples=max(counts[rank], 1), latent=latent, _conditioned=post)
-    mine = [mine] if isinstance(mine, np.ndarray) else list(mine)
-    mine = mine[: counts[rank]]
-    if size == 1:
-        return mine
+    mine = reg._sample_device(x, w, None, True, max(counts[rank], 1), latent, conditioned=post, marginal=marginal)[: counts[rank]]
     rows = int(np.shape(x)[0])
     local = torch.zeros(max(counts), rows, reg.p, dtype=torch.float64, device=eng.device)
-    for k, s in enumerate(mine):
-        local[k] = torch.as_tensor(s, dtype=torch.float64)
+    if mine:
+        local[: len(mine)] = torch.stack([s.to(eng.device) for s in mine])
+    if size == 1:
+        return local[: counts[0]], counts
     gathered = [torch.empty_like(local) for _ in range(size)]
     dist.all_gather(gathered, local, group=group)
-    out = []
-    for r in range(size):
-        out.extend(gathered[r][k].cpu().numpy() for k in range(counts[r]))
-    return out
+    return torch.cat([gathered[r][: counts[r]] for r in range(size)], dim=0), counts
+
+
+def sharded_sample(reg, x, w=None, num_samples=100, latent=False, group=None):
+    """Posterior samples split over ranks (`_sharded_sample_stack`).  Returns the full list of `num_samples` arrays on every
+    rank (the reference's return type: host arrays, regression.py:564)."""
+    stack, _ = _sharded_sample_stack(reg, x, w, num_samples, latent, group)
+    host = stack.cpu().numpy()
+    return [host[k] for k in range(host.shape[0])]
+
+
+def sharded_predict(reg, x, w=None, num_samples=100, latent=False, credible_bounds=False, marginal=False, group=None):
+    """`GPARRegressor.predict` with the samples drawn across the ranks and the Monte-Carlo reduction (mean, central 95 %
+    bounds; reference regression.py:589-595) done on the device by `gpar_sample_stats` over the gathered stack - only the
+    n* x p results cross to the host.  Every rank returns the same arrays."""
+    stack, _ = _sharded_sample_stack(reg, x, w, num_samples, latent, group, marginal=marginal)
+    eng = get_engine()
+    if num_samples == 1:
+        # the reference hands np.mean a single (n*, p) array here, so axis 0 is the input axis (regression.py:589-595); kept
+        one = stack[0].cpu().numpy()
+        mean = np.mean(one, axis=0)
+        return (mean, np.percentile(one, 2.5, axis=0), np.percentile(one, 100 - 2.5, axis=0)) if credible_bounds else mean
+    if credible_bounds:
+        mean, lower, upper = eng.sample_stats(stack.contiguous(), 2.5, 100 - 2.5)
+        return mean.cpu().numpy(), lower.cpu().numpy(), upper.cpu().numpy()
+    return eng.sample_stats(stack.contiguous())[0].cpu().numpy()

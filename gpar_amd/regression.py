@@ -232,13 +232,13 @@ class GPARRegressor:
         # more elements opens an OpenMP region whose workers (one per core) spin afterwards, which in a container with a CPU
         # quota throttles the evaluations that follow (fit(iters=3) at n = 8192: 0.68 -> 0.60 s) - and changing torch's
         # global thread count around the call instead would be visible to other threads of the process.
-        self.x = _uprank(_to_torch(x))
-        self.y = self._transform_y(_uprank(_to_torch(y)))
+        self.x = _uprank(_to_torch(x)).detach().cpu()
+        self.y = self._transform_y(_uprank(_to_torch(y))).detach().cpu()
         self.w = _init_weights(w, self.y, attribute=True)
         self.n, self.m = self.x.shape
         self.p = self.y.shape[1]
         if self.normalise_y:
-            y_np = self.y.detach().numpy()
+            y_np = self.y.detach().cpu().numpy()   # (a device tensor handed to fit / condition comes to the host here)
             means = np.empty((1, self.p), dtype=y_np.dtype)
             stds = np.empty((1, self.p), dtype=y_np.dtype)
             for i in range(self.p):
@@ -273,8 +273,10 @@ class GPARRegressor:
         self._x_ind_trainable = bool(optimise_x_ind) or getattr(self, "_x_ind_trainable", False)
         eng = get_engine()
         x_dev, y_dev, w_dev = eng.tensor(self.x), eng.tensor(self.y), eng.tensor(self.w)
-        if isinstance(self.y, np.ndarray) and y_dev.is_cuda and host_masks():
-            y_dev._host_nan = np.isnan(self.y)   # (per_output then plans the masks on the host: no synchronisation per layer and evaluation)
+        if y_dev.is_cuda and host_masks():
+            # self.y is a host tensor (condition): its NaN pattern costs nothing here, and per_output then plans the masks on the
+            # host - index tensors, no synchronisation per layer and evaluation
+            y_dev._host_nan = torch.isnan(self.y).numpy()
         y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
         self._prepare_kernels(self.m, self.p, self.n, training=True, inputs=not fix or bool(optimise_x_ind))
 

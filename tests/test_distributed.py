@@ -233,3 +233,88 @@ def test_random_configurations_on_three_ranks():
         for serial, sharded in results[rank]:
             assert abs(serial - sharded) <= 1e-10 * max(abs(serial), 1.0), (rank, serial, sharded)
     assert [s for _, s in results[0]] == [s for _, s in results[1]] == [s for _, s in results[2]]   # every rank holds the same totals
+
+
+def _worker_joint(rank, size, port, results):
+    """`fit(fix=False)` with the sum over layers divided over the ranks; Markov-limited forwarding; device-side predict."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        from gpar_amd.engine import get_engine, set_engine
+        from gpar_amd.parallel import forward_plan, sharded_fit, sharded_logpdf, sharded_predict, sharded_sample
+        from gpar_amd.regression import GPARRegressor, _construct_gpar
+        from oracle.engine import OracleEngine
+
+        set_engine(OracleEngine(seed=5))
+        out = {}
+        x, y, w = _data(n=16)
+        for name, kw in [("joint", dict(nonlinear=True, noise=0.1, impute=False)),
+                         ("joint-tied", dict(nonlinear=True, noise=0.1, impute=False, scale_tie=True, markov=1))]:
+            a, b = GPARRegressor(**kw), GPARRegressor(**kw)
+            a.fit(x, y, w, fix=False, iters=6)
+            mode = sharded_fit(b, x, y, w, fix=False, iters=6)
+            va, vb = a.get_variables(), b.get_variables()
+            out[name] = (mode, sorted(va) == sorted(vb), max(float(np.max(np.abs(va[k] - vb[k]))) for k in va),
+                         {k: vb[k].tolist() for k in vb})
+        # dependent regimes train replicated, and say so
+        c = GPARRegressor(nonlinear=True, noise=0.1, replace=True)
+        out["replicated"] = (sharded_fit(c, x, y, w, fix=False, iters=2), sharded_fit(GPARRegressor(noise=0.1, scale_tie=True, impute=False), x, y, w, iters=2))
+        # Markov-limited forwarding: p = 5, markov = 1, dependent chain (replace): column i goes to the owner of layer i + 1 only
+        rng = np.random.default_rng(11)
+        x5 = rng.uniform(-1, 1, (14, 2))
+        y5 = np.stack([np.sin(2 * x5[:, 0] + i) + 0.1 * rng.standard_normal(14) for i in range(5)], axis=1)
+        w5 = np.ones_like(y5)
+        plans = {}
+        for name, kw in [("markov1", dict(replace=True, markov=1)), ("markov2-sparse", dict(markov=2, x_ind=rng.uniform(-1, 1, (5, 2)))),
+                         ("markov0", dict(replace=True, markov=0)), ("full", dict(replace=True))]:
+            reg = GPARRegressor(nonlinear=True, noise=0.05, normalise_y=False, **kw)
+            gpar = _construct_gpar(reg, reg.vs, 2, 5)
+            plans[name] = [sorted(s) for s in forward_plan(gpar, 2, size)]
+            out[name] = (float(gpar.logpdf(x5, y5, w5)), float(sharded_logpdf(gpar, x5, y5, w5)))
+        out["plans"] = plans
+        # predict: the device-side reduction over the gathered stack == numpy over the gathered samples
+        get_engine().seed(21)
+        mean, lo, hi = sharded_predict(b, x[:6], num_samples=7, credible_bounds=True)
+        get_engine().seed(21)
+        samples = np.stack(sharded_sample(b, x[:6], num_samples=7))
+        out["predict"] = (float(np.max(np.abs(mean - samples.mean(axis=0)))), float(np.max(np.abs(lo - np.percentile(samples, 2.5, axis=0)))),
+                          float(np.max(np.abs(hi - np.percentile(samples, 97.5, axis=0)))), mean.tolist())
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("size", [2, 3])
+def test_joint_fit_markov_sends_and_device_predict(size):
+    ctx = mp.get_context("spawn")
+    manager = ctx.Manager()
+    results = manager.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_joint, args=(r, size, port, results)) for r in range(size)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=850)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for rank in range(size):
+        out = results[rank]
+        for name in ("joint", "joint-tied"):
+            mode, same, maxdiff, _ = out[name]
+            assert mode == "joint-sharded" and same and maxdiff < 1e-9, (rank, name, mode, maxdiff)
+        assert out["replicated"] == ("replicated", "replicated")
+        for name in ("markov1", "markov2-sparse", "markov0", "full"):
+            serial, sharded = out[name]
+            assert abs(serial - sharded) <= 1e-10 * abs(serial), (rank, name, serial, sharded)
+        plans = out["plans"]
+        assert plans["markov1"] == [[(i + 1) % size] for i in range(4)] + [[]]
+        assert plans["markov0"] == [[] for _ in range(5)]
+        assert plans["markov2-sparse"][0] == sorted({1 % size, 2 % size})
+        assert plans["full"][0] == sorted({j % size for j in range(1, 5)})
+        dm, dl, dh, _ = out["predict"]
+        assert dm < 1e-12 and dl < 1e-12 and dh < 1e-12
+    # every rank ends up with the same hyper-parameters and the same predictions, bit for bit
+    for name in ("joint", "joint-tied"):
+        assert all(results[r][name][3] == results[0][name][3] for r in range(size))
+    assert all(results[r]["predict"][3] == results[0]["predict"][3] for r in range(size))

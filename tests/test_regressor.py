@@ -218,6 +218,23 @@ def test_condition_normalises_and_fit_runs(engine, x, w):
         reg.fit(x, y, w, greedy=True)
 
 
+def test_joint_fit_trains_every_layer(engine):
+    """fit(fix=False): step pi optimises the variables of layers 0 .. pi TOGETHER (reference gpar/regression.py:447-456), and the
+    last layer's variables - created lazily by the first evaluation of the (pi + 1)-layer model - are among them (varz evaluates
+    the objective once before it resolves the name patterns; a driver that resolves them first never trains the newest layer)."""
+    rng = np.random.default_rng(2)
+    x = np.linspace(0, 1, 24)
+    y = np.stack([np.sin(5 * x), np.cos(4 * x) + x, x ** 2 - np.sin(5 * x)], axis=1) + 0.05 * rng.standard_normal((24, 3))
+    reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.3, impute=False)
+    initial = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.3, impute=False)
+    initial.logpdf(x, y)   # instantiates the initial values
+    reg.fit(x, y, fix=False, iters=10)
+    trained, start = reg.get_variables(), initial.get_variables()
+    for layer in range(3):
+        moved = [float(np.max(np.abs(trained[k] - start[k]))) for k in trained if k.startswith(f"{layer}/")]
+        assert moved and max(moved) > 1e-3, (layer, moved)
+
+
 def test_fit_increases_the_training_objective(engine):
     rng = np.random.default_rng(4)
     x = np.linspace(0, 1, 30)
