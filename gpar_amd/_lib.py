@@ -24,7 +24,7 @@ POTRF_UNFUSED = 2
 WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE, WS_INPUT_GRAD = 1, 2, 3, 4, 5
 GRAD_NACC = GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 LIB_NAME = "libgpar_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -57,6 +57,17 @@ class KSpec(ctypes.Structure):
         ("nfactors", ctypes.c_int32),
         ("coef", ctypes.c_double * GPAR_MAX_TERMS),
         ("factor", Factor * GPAR_MAX_FACTORS),
+    ]
+
+
+class Layer(ctypes.Structure):
+    """gpar_layer_t: one layer of a lock-step evaluation (pointers to host-side specifications)."""
+    _fields_ = [
+        ("fs", ctypes.POINTER(FSpec)),
+        ("ks", ctypes.POINTER(KSpec)),
+        ("noise", ctypes.c_double),
+        ("y_col", ctypes.c_int32),
+        ("pad_", ctypes.c_int32),
     ]
 
 
@@ -109,6 +120,12 @@ SIGNATURES = {
         _c_int,
         [ctypes.POINTER(FSpec), ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, ctypes.c_long, _ptr, _c_dbl, _ptr, _c_int, _ptr, _c_int,
          _ptr, _ptr, _ptr],
+    ),
+    "gpar_sizeof_layer": (ctypes.c_size_t, []),
+    "gpar_logpdf_lockstep": (
+        _c_int,
+        [ctypes.POINTER(Layer), _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _c_dbl, _ptr, _c_int, _ptr, _ptr, _c_int,
+         ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr, _c_int, _ptr],
     ),
     "gpar_potrf_batch": (_c_int, [_ptr, _c_int, ctypes.c_longlong, _c_int, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr]),
     "gpar_logpdf_dense_finish": (_c_int, [_ptr, _c_int, ctypes.c_longlong, _c_int, _c_int, _ptr, _ptr, _ptr]),
@@ -183,6 +200,8 @@ def load():
         raise HipLibraryError(f"ABI version mismatch: library {lib.gpar_abi_version()}, binding {ABI_VERSION}")
     if lib.gpar_sizeof_fspec() != ctypes.sizeof(FSpec) or lib.gpar_sizeof_kspec() != ctypes.sizeof(KSpec):
         raise HipLibraryError("struct layout mismatch between include/gpar_hip.h and gpar_amd/_lib.py")
+    if lib.gpar_sizeof_layer() != ctypes.sizeof(Layer):
+        raise HipLibraryError("gpar_layer_t layout mismatch between include/gpar_hip.h and gpar_amd/_lib.py")
     if lib.gpar_grad_nacc() != GRAD_NACC:
         raise HipLibraryError(f"gradient accumulator layout mismatch: library {lib.gpar_grad_nacc()}, binding {GRAD_NACC}")
     _lib = lib

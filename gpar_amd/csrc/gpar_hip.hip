@@ -233,11 +233,57 @@ __global__ void logpdf_value_kernel(const double* __restrict__ A, int lda, int n
     value[0] = -0.5 * ((logdet[0] + n_log_2pi) - A[(size_t)n * lda + n]);
 }
 
+
+// ---- one call for a whole lock-step evaluation (gpar_logpdf_lockstep) ---------------------------------------------------------
+// observation-noise variance and observed column of up to LOCKSTEP_CHUNK layers, by value
+constexpr int LOCKSTEP_CHUNK = 64;
+struct LockstepCols {
+    double noise[LOCKSTEP_CHUNK];
+    int ycol[LOCKSTEP_CHUNK];
+};
+
+// For layer b = blockIdx.y of the chunk: row n of its augmented matrix <- its observations, its noise diagonal noise_b / w (an IEEE
+// division, as the host-side tensor expression it replaces) when weights are given, corner / log-determinant / info word <- 0.
+__global__ __launch_bounds__(256) void lockstep_prepare_kernel(LockstepCols lc, const double* __restrict__ y, int ldy, const double* __restrict__ w,
+                                                               int ldw, int n, double* __restrict__ nd, double* __restrict__ A, int lda,
+                                                               long long stride_a, double* __restrict__ logdet, int* __restrict__ info) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double* Ab = A + (size_t)b * stride_a;
+    const int col = lc.ycol[b];
+    if (i < n) {
+        Ab[(size_t)n * lda + i] = y[(size_t)i * ldy + col];
+        if (nd) nd[(size_t)b * n + i] = lc.noise[b] / w[(size_t)i * ldw + col];
+    }
+    if (i == n) {
+        Ab[(size_t)n * lda + n] = 0.0;
+        logdet[b] = 0.0;
+        info[b] = 0;
+    }
+}
+
+// value[b] as logpdf_value_kernel computes it, then total = ((0 + value[0]) + value[1]) + ... in layer order (the host-side sum it replaces)
+__global__ __launch_bounds__(64) void lockstep_finish_kernel(const double* __restrict__ A, int lda, long long stride_a, int n, double n_log_2pi,
+                                                             const double* __restrict__ logdet, double* __restrict__ value, int batch,
+                                                             double* __restrict__ total) {
+    for (int b = threadIdx.x; b < batch; b += 64) {
+        const double* Ab = A + (size_t)b * stride_a;
+        value[b] = -0.5 * ((logdet[b] + n_log_2pi) - Ab[(size_t)n * lda + n]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && total) {
+        double t = 0.0;
+        for (int b = 0; b < batch; ++b) t = t + value[b];
+        total[0] = t;
+    }
+}
+
 extern "C" {
 
 int gpar_abi_version(void) { return GPAR_ABI_VERSION; }
 size_t gpar_sizeof_fspec(void) { return sizeof(gpar_fspec_t); }
 size_t gpar_sizeof_kspec(void) { return sizeof(gpar_kspec_t); }
+size_t gpar_sizeof_layer(void) { return sizeof(gpar_layer_t); }
 
 // Everything the library creates lazily, created now: the look-ahead side stream paired with `stream`, the event ring and
 // every kernel's dynamic-LDS attribute on the device that owns `stream`.  After it, entry points called
@@ -410,6 +456,42 @@ int gpar_logpdf_dense_finish(const double* A, int batch, long long stride_a, int
     if (!A || !logdet || !value || n < 0) return GPAR_ARG_ERROR(1);
     hipLaunchKernelGGL(logpdf_value_kernel, dim3(batch), dim3(1), 0, (hipStream_t)stream, A, lda, n, (double)n * 1.8378770664093453, logdet,
                        value, stride_a);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_logpdf_lockstep(const gpar_layer_t* layers, int batch, const double* x, int n, int ldx, const double* y, int ldy, const double* w,
+                         int ldw, double jitter, double* z, int ldz, double* nd, double* A, int lda, long long stride_a, double* logdet,
+                         int* info, double* value, double* total, int potrf_flags, void* stream) {
+    GPAR_API_GUARD;
+    if (batch <= 0) return 0;
+    if (!layers || !A || !logdet || !info || !value || stride_a < 0 || (n > 0 && (!x || !y || !z)) || (w && !nd)) return GPAR_ARG_ERROR(1);
+    hipStream_t st = (hipStream_t)stream;
+    for (int b = 0; b < batch; ++b)
+        if (!layers[b].fs || !layers[b].ks || layers[b].y_col < 0) return GPAR_ARG_ERROR(2);
+    for (int b0 = 0; b0 < batch; b0 += LOCKSTEP_CHUNK) {
+        const int cnt = batch - b0 < LOCKSTEP_CHUNK ? batch - b0 : LOCKSTEP_CHUNK;
+        LockstepCols lc;
+        for (int b = 0; b < cnt; ++b) { lc.noise[b] = layers[b0 + b].noise; lc.ycol[b] = layers[b0 + b].y_col; }
+        hipLaunchKernelGGL(lockstep_prepare_kernel, dim3(gpar_ceil_div(n + 1, 256), cnt), dim3(256), 0, st, lc, y, ldy, w, ldw, n,
+                           w ? nd + (size_t)b0 * n : nullptr, A + (size_t)b0 * stride_a, lda, stride_a, logdet + b0, info + b0);
+    }
+    GPAR_LAUNCH_CHECK();
+    for (int b = 0; b < batch && n > 0; ++b) {
+        const gpar_layer_t& L = layers[b];
+        double* zb = z + (size_t)b * n * ldz;
+        int rc = featurize_launch(L.fs, x, n, ldx, zb, ldz, st);
+        // unit weights: the diagonal is noise + jitter, added exactly as the kernel adds diag_add[row] + diag_const
+        if (!rc) rc = gram_launch(L.ks, zb, n, ldz, zb, n, ldz, L.fs->dz, A + (size_t)b * stride_a, lda, GPAR_GRAM_LOWER, w ? nd + (size_t)b * n : nullptr,
+                                  w ? jitter : L.noise + jitter, nullptr, st);
+        if (rc) return rc;
+    }
+    if (n > 0) {
+        const int rc = potrf_run_batch(A, batch, stride_a, n + 1, n, lda, logdet, info, st, potrf_flags);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(lockstep_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)A, lda, stride_a, n, (double)n * 1.8378770664093453,
+                       (const double*)logdet, value, batch, total);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

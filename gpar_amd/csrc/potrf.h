@@ -317,10 +317,38 @@ struct PotrfCtx {
     long long batch_a = 0;   // are batched launches
 };
 
+// The trailing update when only a few rows are left - the augmented rows under the last panel: [y^T, 0] of the log marginal
+// likelihood, whose corner becomes -|L^-1 y|^2 - one wave per stored element (i, j), j <= i: lanes stride K, butterfly sum.
+// A 64 x 64 tile of the GEMM kernel for ONE element is all latency (42 us per evaluation at every size; this: ~4 us).
+constexpr int POTRF_SMALL_ROWS = 16;
+__global__ __launch_bounds__(64) void potrf_small_update_kernel(double* __restrict__ A, int lda, int kend, int k0, int rows, int cols, long long batch_a) {
+    const int i = blockIdx.x / cols, j = blockIdx.x - i * cols;
+    if (j > i) return;
+    A += (size_t)blockIdx.y * batch_a;
+    const double* Pi = A + (size_t)(kend + i) * lda + k0;
+    const double* Pj = A + (size_t)(kend + j) * lda + k0;
+    const int K = kend - k0;
+    double a0 = 0.0, a1 = 0.0;
+    int k = threadIdx.x;
+    for (; k + 64 < K; k += 128) {
+        a0 = fma(Pi[k], Pj[k], a0);
+        a1 = fma(Pi[k + 64], Pj[k + 64], a1);
+    }
+    if (k < K) a0 = fma(Pi[k], Pj[k], a0);
+    double s = a0 + a1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) A[(size_t)(kend + i) * lda + kend + j] -= s;
+}
+
 static int potrf_gemm_update(const PotrfCtx& c, int k0, int kend, int col_end, hipStream_t stream, int role = 0) {
     // A[kend:N, kend:col_end] -= A[kend:N, k0:kend] A[kend:col_end, k0:kend]^T   (lower part only)
     const int rows = c.N - kend, cols = col_end - kend;
     if (rows <= 0 || cols <= 0) return 0;
+    if (rows <= POTRF_SMALL_ROWS && env_int("GPAR_POTRF_SMALL_UPDATE", 1)) {
+        hipLaunchKernelGGL(potrf_small_update_kernel, dim3(rows * cols, c.batch), dim3(64), 0, stream, c.A, c.lda, kend, k0, rows, cols, c.batch_a);
+        return 0;
+    }
     const double* P = c.A + (size_t)kend * c.lda + k0;
     return gemm_launch(0, 1, rows, cols, kend - k0, -1.0, P, c.lda, P, c.lda, 1.0, c.A + (size_t)kend * c.lda + kend, c.lda,
                        GPAR_GEMM_C_LOWER, stream, role, c.batch, c.batch_a, c.batch_a, c.batch_a);
@@ -597,7 +625,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         if (trail_done) GPAR_HIP_TRY(hipStreamWaitEvent(stream, trail_done, 0));
         const bool next_grouped = next_end - kend > nbo && groupable(kend);
         const int la_end = (next_grouped && env_int("GPAR_POTRF_LA_SPLIT", 0)) ? kend + nbo : next_end;
-        const bool rest_after_la = batch == 1 && (N - kend) < env_int("GPAR_POTRF_REST_AFTER_LA", 0);
+        const bool rest_after_la = (N - kend) < env_int(batch == 1 ? "GPAR_POTRF_REST_AFTER_LA" : "GPAR_POTRF_BATCH_REST_AFTER_LA", 0);
         hipEvent_t panel_done = la_event();
         if (!rest_after_la) GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
         prof_begin(stream, pa);

@@ -220,6 +220,11 @@ class HipEngine:
         safe = getattr(self._tls, "safe", False)
         return hip.logpdf_dense_batch([(ck, self._mat(x), y, nd) for ck, x, y, nd in items], jitter, fused=not safe)
 
+    def logpdf_lockstep(self, layers, x, y, w, jitter):
+        """The whole lock-step evaluation in one library call: (values, their sum in layer order, info words)."""
+        safe = getattr(self._tls, "safe", False)
+        return hip.logpdf_lockstep(layers, self._mat(x), self._mat(y), None if w is None else self._mat(w), jitter, fused=not safe)
+
     def factor_dense_batch(self, items, jitter):
         """The lock-step factorisations alone: (buffer of the `batch` augmented factors, logdets, info words)."""
         safe = getattr(self._tls, "safe", False)

@@ -166,6 +166,48 @@ def logpdf_dense_batch(items, jitter, fused=True):
     return values, info
 
 
+def logpdf_lockstep(layers, x, y, w, jitter, fused=True):
+    """The log marginal likelihoods of layers that share their rows and do not feed one another, and their sum, in ONE library
+    call (gpar_logpdf_lockstep).  `layers`: (compiled kernel, noise variance, column of y / w) per layer; x: n x width, the widest
+    design matrix ([inputs, y_0 .. y_(p-2)] for a GPAR) - every layer's feature map selects its own columns; y, w: n x p device
+    matrices (w None: unit weights).  Returns (values, total, info): `batch` words, one word, `batch` words, all on the device."""
+    lib = _lib.load()
+    _check_mat(x, "x")
+    _check_mat(y, "y")
+    batch = len(layers)
+    n, dev = x.shape[0], x.device
+    if y.dim() != 2 or y.shape[0] != n or (w is not None and (w.shape != y.shape or w.dtype != torch.float64 or not w.is_cuda)):
+        raise ValueError("y (and w) must be n x p fp64 device matrices")
+    if w is not None and w.stride(1) != 1:
+        w = w.contiguous()
+    arr = (_lib.Layer * batch)()
+    dz = 1
+    for b, (ck, noise, col) in enumerate(layers):
+        if not 0 <= col < y.shape[1]:
+            raise ValueError("observed column out of range")
+        arr[b].fs = ctypes.pointer(ck.fspec)
+        arr[b].ks = ctypes.pointer(ck.kspec)
+        arr[b].noise = float(noise)
+        arr[b].y_col = int(col)
+        dz = max(dz, ck.dz)
+    A = alloc_matrix(batch * (n + 1), n + 1, dev)
+    lda = _ld(A)
+    z = alloc_matrix(batch * max(n, 1), dz, dev)
+    nd = torch.empty(batch * max(n, 1), dtype=torch.float64, device=dev) if w is not None else None
+    words = torch.empty(2 * batch + 1, dtype=torch.float64, device=dev)   # logdet[batch], value[batch], total
+    info = torch.empty(batch, dtype=torch.int32, device=dev)
+    _lib.check(
+        lib.gpar_logpdf_lockstep(
+            arr, batch, x.data_ptr(), n, _ld(x), y.data_ptr(), _ld(y), None if w is None else w.data_ptr(), 0 if w is None else _ld(w),
+            float(jitter), z.data_ptr(), _ld(z), None if nd is None else nd.data_ptr(), A.data_ptr(), lda, (n + 1) * lda,
+            words.data_ptr(), info.data_ptr(), words[batch:].data_ptr(), words[2 * batch:].data_ptr(), 0 if fused else _lib.POTRF_UNFUSED,
+            stream_ptr(dev),
+        ),
+        "gpar_logpdf_lockstep",
+    )
+    return words[batch:2 * batch], words[2 * batch], info
+
+
 def gram(ck, z1, z2=None, out=None, lower=False, diag_add=None, diag_const=0.0, row_scale=None):
     """K = k(z1, z2) (z2 None: symmetric, optionally lower-only, + diag_add + diag_const on the diagonal); with `row_scale`
     (n1 weights) row a is multiplied by row_scale[a]."""

@@ -27,6 +27,13 @@ def host_masks():
     return os.environ.get("GPAR_HOST_MASKS", "1") != "0"
 
 
+def one_call_enabled():
+    """GPAR_ONE_CALL=0: lock-step evaluations through the per-layer build calls (the round-3 route; same bits)."""
+    import os
+
+    return os.environ.get("GPAR_ONE_CALL", "1") != "0"
+
+
 def _is_torch(a):
     return isinstance(a, torch.Tensor)
 
@@ -215,6 +222,35 @@ def _lockstep_values(eng, pending):
     return values
 
 
+def _lockstep_total(eng, x, y, w, entries):
+    """Sum of the log marginal likelihoods of layers that do not feed one another and see all rows, by the one-call path
+    (HipEngine.logpdf_lockstep), as a list of device scalars to be added in order: `entries` holds (layer index, process, noise) per layer; layer i's design matrix is the first
+    m + i columns of [x, y_0 .. y_(p-2)] and its kernel selects among them, so ONE widest matrix serves every layer - no design
+    matrix per layer, no per-layer tensor for the noise diagonal, no observation objects.  None when the workspace does not fit
+    (the caller falls back to the layer-by-layer route)."""
+    m = int(x.shape[1])
+    n = int(x.shape[0])
+    widest = max(i for i, _, _ in entries)
+    x_full = x if widest == 0 else torch.cat([x, y[:, :widest]], dim=1)
+    layers = []
+    for i, f, noise in entries:
+        value = float(noise.detach()) if _is_torch(noise) else float(noise)
+        layers.append((eng.compile(f.kernel, m + i), value, i))
+    cap = max(1, eng.batch_bytes() // (8 * (n + 1) * (n + 17)))   # layers per batch within the workspace budget
+    out = []
+    for s0 in range(0, len(layers), cap):
+        try:
+            values, part, info = eng.logpdf_lockstep(layers[s0:s0 + cap], x_full, y, w, eng.epsilon)
+        except torch.cuda.OutOfMemoryError:
+            torch.cuda.empty_cache()
+            return None
+        eng.check_info(info)
+        if len(layers) <= cap:
+            return [part]   # one batch: the device-side sum in layer order is the sum the caller would form
+        out.extend(values[b] for b in range(values.shape[0]))
+    return out
+
+
 def _lockstep_factors(eng, obs):
     """Factor the observations of layers that do not feed one another in lock-step batches (HipEngine.factor_dense_batch) and
     hand each its factor; whatever does not qualify is factored on its own."""
@@ -360,6 +396,17 @@ class GPAR:
         # ... or, when they are small enough for a factorisation to be one latency-bound chain, factored together in lock-step
         lockstep = pipe is not None and self._same_rows(items) and hasattr(eng, "logpdf_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
         pending = []
+        # ... and then, when y and w are whole device matrices and every layer is a prior process outside autograd, through ONE
+        # library call (_lockstep_total)
+        onecall = (lockstep and outputs is None and hasattr(eng, "logpdf_lockstep") and _is_torch(y) and y.is_cuda and y.dim() == 2
+                   and _is_torch(w) and w.shape == y.shape and getattr(eng, "cholesky_retry_factor", 1.0) <= 1.0 and one_call_enabled())
+        if onecall:
+            for model in self.layers[:len(items)]:
+                f, noise = model()
+                if f.is_posterior or _differentiable(f, noise):
+                    onecall = False
+                    break
+        fast, visited = [], 0
         with eng.defer_checks(), _joining(pipe):  # streams are joined BEFORE the deferred info words are read
             for is_last, ((yi, wi, mask), model) in last(zip(items, self.layers), select=outputs):
                 complete = isinstance(mask, slice)
@@ -368,6 +415,12 @@ class GPAR:
                 if pipe is not None and _differentiable(f, noise):
                     pipe.join()
                     pipe = None  # an objective under autograd: keep everything on the caller's stream
+                if pipe is not None and onecall:
+                    # the one-call route: nothing is built per layer; the design matrix [x, y_<i] is a prefix of one widest matrix
+                    if not only_last_layer or is_last:
+                        fast.append((visited, f, noise))
+                    visited += 1
+                    continue
                 if pipe is not None and lockstep:
                     if not only_last_layer or is_last:
                         obs = self._obs(x, x_ind, yi, wi, f, noise, complete=True)
@@ -399,6 +452,16 @@ class GPAR:
                     x, x_ind = self._update_inputs(x, x_ind, yi, f, obs, complete=complete)
             if pipe is not None:
                 pipe.join()
+            if fast:
+                got = _lockstep_total(eng, x, y, w, fast)
+                if got is None:   # no room for the batch: layer by layer
+                    xw = torch.cat([x, y[:, :visited]], dim=1)
+                    for j, fj, nj in fast:
+                        obs = self._obs(xw[:, :int(x.shape[1]) + j], x_ind, y[:, j:j + 1], w[:, j], fj, nj, complete=True)
+                        obs.transient = True
+                        pending.append((fj, obs))
+                else:
+                    values.extend(got)
             if pending:
                 values.extend(_lockstep_values(eng, pending))
             for v in values:

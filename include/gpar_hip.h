@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPAR_ABI_VERSION 4
+#define GPAR_ABI_VERSION 5
 
 /* ---- kernel specification -------------------------------------------------------------------
  * A GPAR layer kernel (gpar/regression.py:92-180) is a sum of products of elementary kernels applied
@@ -239,6 +239,30 @@ int gpar_logpdf_dense_build(const gpar_fspec_t* fs, const gpar_kspec_t* ks, cons
 int gpar_potrf_batch(double* A, int batch, long long stride_a, int N, int nf, int lda, double* logdet, int* info, int flags, void* stream);
 int gpar_logpdf_dense_finish(const double* A, int batch, long long stride_a, int n, int lda, const double* logdet, double* value,
                              void* stream);
+
+/* A whole lock-step evaluation in ONE call (ABI v5): the log marginal likelihoods of `batch` layers over one set of n rows, and
+ * their sum.  Layer b is described by layers[b] (HOST memory, read during the call): its feature map and kernel, its observation-
+ * noise variance, and the column y_col of y (and of w) that holds its observations.  x: n x width, the widest design matrix -
+ * for a GPAR [inputs, y_0 .. y_(p-2)] - from which every layer's feature map selects its own columns (gpar/model.py:320: layer i
+ * sees [x, y_<i]); y: n x (>= max y_col + 1), ldy; w: weights laid out as y (ldw) or NULL for unit weights - the noise diagonal
+ * of layer b is noise_b / w[:, y_col], an IEEE division per row.  Workspaces: z: batch * n rows of ldz >= max dz doubles;
+ * nd: batch * n doubles (only read when w != NULL); A / lda / stride_a / logdet / info as for gpar_potrf_batch ((n + 1) x (n + 1)
+ * matrices); value: `batch` words; total: one word or NULL, = ((0 + value[0]) + value[1]) + ... in layer order.
+ * The same kernels, in the same order per matrix, as gpar_logpdf_dense_build / gpar_potrf_batch / gpar_logpdf_dense_finish: the
+ * results are bit-identical; what it removes is the caller's side - a Python host spends ~0.1 ms per layer on tensor bookkeeping
+ * and ~25 small launches per evaluation around those calls, which is most of an evaluation at n <= 1024.
+ * [sum over layers of f.measure.logpdf(Obs(f(x_i, noise_i / w_i), y_i)), gpar/model.py:221-243 with :286-289, complete data] */
+typedef struct {
+    const gpar_fspec_t* fs;
+    const gpar_kspec_t* ks;
+    double noise;
+    int32_t y_col;
+    int32_t pad_;
+} gpar_layer_t;
+size_t gpar_sizeof_layer(void);
+int gpar_logpdf_lockstep(const gpar_layer_t* layers, int batch, const double* x, int n, int ldx, const double* y, int ldy, const double* w,
+                         int ldw, double jitter, double* z, int ldz, double* nd, double* A, int lda, long long stride_a, double* logdet,
+                         int* info, double* value, double* total, int potrf_flags, void* stream);
 
 /* B <- B L^-T  (right side, lower, transposed: forward substitution on the rows of B; B is nrows x n).
  * [solve_triangular inside matrix.iqf_diag / PosteriorKernel, reached from gpar/model.py:226,264,298] */

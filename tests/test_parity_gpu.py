@@ -267,6 +267,47 @@ def test_lockstep_layers_equal_layer_by_layer_evaluation(monkeypatch, n, p):
         assert abs(got["lockstep"] - ref) <= 1e-9 * abs(ref), (got, ref)
 
 
+@pytest.mark.parametrize("n,p,weights", [(700, 4, False), (512, 3, True), (1300, 5, True), (40, 70, True), (2100, 2, False)])
+def test_one_call_lockstep_evaluation_returns_the_same_bits(monkeypatch, n, p, weights):
+    """gpar_logpdf_lockstep (ABI v5): the whole lock-step evaluation in one library call - no design matrix, noise tensor or
+    observation object per layer - returns bit for bit what the per-layer build calls return (GPAR_ONE_CALL=0), with weights
+    (noise / w divided on the device), with more layers than one launch of the preparing kernel takes (70 > 64), in chunks,
+    and for `only_last_layer`."""
+    import torch
+
+    from gpar_amd.engine import get_engine
+    from gpar_amd.regression import GPARRegressor, _construct_gpar
+
+    x, y = _problem(n, 2, min(p, 6), seed=n + p)
+    if p > 6:
+        y = np.concatenate([y] * (p // y.shape[1] + 1), axis=1)[:, :p] + 0.01 * np.random.default_rng(0).standard_normal((n, p))
+    w = np.random.default_rng(1).uniform(0.5, 2.0, y.shape) if weights else None
+
+    def run():
+        eng = get_engine()
+        kw = dict(scale=0.5, linear=True, nonlinear=True, noise=0.1, markov=3 if p > 6 else None, normalise_y=False)
+        out = {}
+        for mode in ["1", "0"]:
+            monkeypatch.setenv("GPAR_ONE_CALL", mode)
+            reg = GPARRegressor(**kw)
+            out[mode] = float(reg.logpdf(x, y, w))
+            gpar = _construct_gpar(reg, reg.vs, 2, p)
+            wd = eng.tensor(np.ones_like(y) if w is None else w)
+            out[mode + "last"] = float(gpar.logpdf(eng.tensor(x), eng.tensor(y), wd, only_last_layer=True))
+            monkeypatch.setenv("GPAR_LAYER_BATCH_BYTES", str(8 * (n + 1) * (n + 17) * 3))   # three layers per batch
+            out[mode + "chunks"] = float(reg.logpdf(x, y, w))
+            monkeypatch.delenv("GPAR_LAYER_BATCH_BYTES")
+        monkeypatch.delenv("GPAR_ONE_CALL")
+        return out
+
+    got = _on("hip", run)
+    assert got["1"] == got["0"] and got["1last"] == got["0last"] and got["1chunks"] == got["0chunks"], got
+    if n <= 600:
+        ref = _on("oracle", lambda: float(GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, markov=3 if p > 6 else None,
+                                                        normalise_y=False).logpdf(x, y, w)))
+        assert abs(got["1"] - ref) <= 1e-9 * abs(ref), (got, ref)
+
+
 @pytest.mark.parametrize("n,p", [(1500, 4), (300, 3)])
 def test_lockstep_conditioning_equals_layer_by_layer(monkeypatch, n, p):
     """Conditioning on complete data factors the (independent) layers in lock-step (HipEngine.factor_dense_batch): the posterior

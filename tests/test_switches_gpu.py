@@ -42,6 +42,9 @@ CALL_TIME = [
     ("GPAR_LAYER_BATCH_BYTES", str(8 * 1301 * 1317 * 2)),
     ("GPAR_POTRF_BATCH_LOOKAHEAD", "0"),
     ("GPAR_POTRF_PREZERO", "0"),
+    ("GPAR_POTRF_SMALL_UPDATE", "0"),
+    ("GPAR_ONE_CALL", "0"),
+    ("GPAR_POTRF_BATCH_REST_AFTER_LA", "100000"),
     ("GPAR_FIT_THREADS", "1"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "0"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "-1"),
