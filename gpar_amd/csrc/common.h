@@ -46,6 +46,17 @@ static inline hipError_t gpar_set_max_lds(const void* fn, int bytes) {
 
 static inline int gpar_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Device-side predication of a solve (gpar_trsm_rlt_if): while `flag` is set, the kernels the triangular-solve path launches
+// (block kernels, strips, their role-0 GEMM updates) return at once unless (flag[0] != 0) == (sense != 0) - the decision is
+// taken on the device, from a word an earlier kernel of the stream wrote, without a host synchronisation.  Entry points run under
+// the library's mutex, so one context serves.
+struct GparPredicate {
+    const int* flag = nullptr;
+    int sense = 0;
+};
+static GparPredicate g_pred;
+__device__ __forceinline__ bool gpar_pred_skip(const int* flag, int sense) { return flag && ((*flag != 0) != (sense != 0)); }
+
 __host__ __device__ static inline bool gpar_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // Broadcast lane `src` (compile-time constant after unrolling) of a double to the whole wave through SGPRs

@@ -66,6 +66,8 @@ struct GemmArgs {
     int sblock;          // > 0: the square lower triangle's tiles are enumerated in sblock x sblock super-blocks (see gemm_tile_body)
     long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memrealtime stamps + hardware ids, normally null
     long long* stage_stamps;   // dev aid (tools/time_gemm_stages.hip, compiled with GPAR_GEMM_STAGE_STAMPS): 3 stamps per K stage
+    const int* pred;     // role-0 launches inside a predicated solve (common.h: GparPredicate): return at once unless (*pred != 0) == pred_sense
+    int pred_sense;
 };
 
 typedef double gpar_d2 __attribute__((ext_vector_type(2)));
@@ -554,6 +556,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs& p, double* smem, const 
 template <bool TA, bool TB, int ROLE, int BM = 128>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (ROLE == 0 && gpar_pred_skip(p.pred, p.pred_sense)) return;   // (the trailing update of a factorisation, ROLE 1, is never predicated)
     if (ROLE == 1 && BM == GEMM_BM && p.ntail > 0 && (int)blockIdx.x >= p.nfull)
         gemm_tile_body<TA, TB, 64>(p, smem, (int)blockIdx.x - p.nfull, 2 * p.ntail, p.nfull);
     else
@@ -590,6 +593,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
     p.fastC = gpar_aligned16(C) && (ldc % 2 == 0);
     p.stamps = nullptr; p.stage_stamps = nullptr;
+    p.pred = role == 0 ? g_pred.flag : nullptr; p.pred_sense = g_pred.sense;
     p.ksplit = 0;
     p.part_stride = 0;
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
@@ -669,6 +673,7 @@ static int gemm_splitk_launch(int ta, int tb, int m, int n, int k, double alpha,
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
     p.fastC = gpar_aligned16(workspace) && (n % 2 == 0) && (((long long)m * n) % 2 == 0);
     p.stamps = nullptr; p.stage_stamps = nullptr; p.sblock = 0;
+    p.pred = nullptr; p.pred_sense = 0;
     const int len = gpar_ceil_div(gpar_ceil_div(k, splits), GEMM_BK) * GEMM_BK;
     p.ksplit = len;
     p.nfull = 0; p.ntail = 0;

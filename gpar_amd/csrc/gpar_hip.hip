@@ -610,6 +610,25 @@ int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb
     return trsm_rlt_run(L, n, ldl, B, nrows, ldb, (hipStream_t)stream);
 }
 
+int gpar_trsm_rlt_if(const double* L, int n, int ldl, double* B, int nrows, int ldb, const int* flag, int run_if, void* stream) {
+    GPAR_API_GUARD;
+    g_pred.flag = flag;
+    g_pred.sense = run_if;
+    const int rc = trsm_rlt_run(L, n, ldl, B, nrows, ldb, (hipStream_t)stream);
+    g_pred.flag = nullptr;
+    g_pred.sense = 0;
+    return rc;
+}
+
+int gpar_chol_spread(const double* L, int n, int ldl, double limit, double* spread, int* flag, void* stream) {
+    GPAR_API_GUARD;
+    if (n <= 0 || (!spread && !flag)) return 0;
+    if (!L) return GPAR_ARG_ERROR(1);
+    hipLaunchKernelGGL(chol_spread_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, L, n, ldl, limit, spread, flag);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
 int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream) {
     GPAR_API_GUARD;
     return trsm_rln_run(L, n, ldl, B, nrows, ldb, (hipStream_t)stream);

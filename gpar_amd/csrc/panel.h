@@ -456,10 +456,13 @@ struct TrsmBlockArgs {
     int c0, S;         // columns [c0, c0 + 64 S)
     int upper_tri;     // B is upper triangular on entry: row r has nothing left of column r -> whole steps are skipped
     int pairs = 0;     // panel2.h: column blocks taken in pairs (p2_row_block_pairs)
+    const int* pred = nullptr;   // predicated solve (common.h: GparPredicate): return at once unless (*pred != 0) == pred_sense
+    int pred_sense = 0;
 };
 
 __global__ __launch_bounds__(256) void trsm_block_kernel(TrsmBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
+    if (gpar_pred_skip(a.pred, a.pred_sense)) return;
     double* Cs = psm;
     double* Xs = psm + PNL_TILE;
     double* Bs = psm;
@@ -494,6 +497,7 @@ static int trsm_block_fused(const double* L, int n, int ldl, double* B, int nrow
                             hipStream_t stream) {
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&trsm_block_kernel), PNL_LDS_BYTES));
     TrsmBlockArgs a{L, n, ldl, B, nrows, ldb, c0, S, upper_tri};
+    a.pred = g_pred.flag; a.pred_sense = g_pred.sense;
     hipLaunchKernelGGL(trsm_block_kernel, dim3(gpar_ceil_div(nrows, 64)), dim3(256), PNL_LDS_BYTES, stream, a);
     GPAR_LAUNCH_CHECK();
     return 0;

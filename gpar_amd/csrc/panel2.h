@@ -1026,6 +1026,7 @@ static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* 
 // it through the S column blocks [c0, c0 + 64 S) - the same left-looking row-block task, without hand-offs.
 __global__ __launch_bounds__(256, 2) void trsm_block2_kernel(TrsmBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
+    if (gpar_pred_skip(a.pred, a.pred_sense)) return;
     const int r0 = 64 * blockIdx.x;
     // upper_tri: row r has nothing left of column r, so column blocks that end before r0 are still zero - and stay zero
     int ufirst = 0;
@@ -1046,6 +1047,7 @@ static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nro
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&trsm_block2_kernel), P2_LDS_BYTES));
     TrsmBlockArgs a{L, n, ldl, B, nrows, ldb, c0, S, upper_tri};
     a.pairs = env_int("GPAR_TRSM_PAIRS", 1);
+    a.pred = g_pred.flag; a.pred_sense = g_pred.sense;
     hipLaunchKernelGGL(trsm_block2_kernel, dim3(gpar_ceil_div(nrows, 64)), dim3(256), P2_LDS_BYTES, stream, a);
     GPAR_LAUNCH_CHECK();
     return 0;

@@ -130,10 +130,12 @@ __global__ __launch_bounds__(64) void potrf_diag64_kernel(double* __restrict__ A
 // and all global loads of a phase are issued before the first is consumed.
 template <bool FWD>
 __global__ __launch_bounds__(64) void trsm_strip_kernel(const double* __restrict__ Ld, int ldl, int cb,
-                                                        double* __restrict__ B, int ldb, int nrows, long long batch_stride = 0) {
+                                                        double* __restrict__ B, int ldb, int nrows, long long batch_stride = 0,
+                                                        const int* pred = nullptr, int pred_sense = 0) {
     __shared__ __attribute__((aligned(16))) double Cs[64 * PAN_LD];   // Cs[j][k]: coefficient of x_k in equation j
     __shared__ __attribute__((aligned(16))) double Xs[64 * PAN_LD];   // Xs[lane][a]: row `lane` of B / X (reversed if !FWD)
     __shared__ double rinvs[64];
+    if (gpar_pred_skip(pred, pred_sense)) return;   // (predicated solve, common.h)
     const int lane = threadIdx.x;
     const int row0 = blockIdx.x * 64;
     Ld += (size_t)blockIdx.y * batch_stride;   // (lock-step batch: triangle and right-hand sides live in the same matrix b)
@@ -218,7 +220,8 @@ __global__ __launch_bounds__(64) void trsm_strip_kernel(const double* __restrict
 template <bool FWD>
 static void launch_strip(const double* Ld, int ldl, int cb, double* B, int ldb, int nrows, hipStream_t stream, int batch = 1, long long batch_stride = 0) {
     if (nrows <= 0) return;
-    hipLaunchKernelGGL((trsm_strip_kernel<FWD>), dim3(gpar_ceil_div(nrows, 64), batch), dim3(64), 0, stream, Ld, ldl, cb, B, ldb, nrows, batch_stride);
+    hipLaunchKernelGGL((trsm_strip_kernel<FWD>), dim3(gpar_ceil_div(nrows, 64), batch), dim3(64), 0, stream, Ld, ldl, cb, B, ldb, nrows, batch_stride,
+                       g_pred.flag, g_pred.sense);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -255,6 +258,40 @@ static void profile_collect() {
     }
     g_prof.ms_busy += ce - cs;
     g_prof.nev = 0;
+}
+
+// Conditioning estimate of a Cholesky factor that comes for free: the spread of its pivots, (max L_jj / min L_jj)^2 - a lower
+// bound of cond(L L^T).  spread[0] <- the estimate, flag[0] <- 1 if it exceeds `limit` or a pivot is not positive (a failed
+// factorisation), 0 otherwise: the word a predicated solve (gpar_trsm_rlt_if) dispatches on.
+__global__ __launch_bounds__(256) void chol_spread_kernel(const double* __restrict__ L, int n, int ldl, double limit, double* __restrict__ spread,
+                                                          int* __restrict__ flag) {
+    __shared__ double smax[256], smin[256];
+    double mx = 0.0, mn = __builtin_inf();
+    bool bad = false;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const double v = L[(size_t)j * ldl + j];
+        if (!(v > 0.0)) bad = true;   // (also NaN)
+        mx = fmax(mx, v);
+        mn = fmin(mn, v);
+    }
+    smax[threadIdx.x] = mx;
+    smin[threadIdx.x] = bad ? -1.0 : mn;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + off]);
+            smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double lo = smin[0], hi = smax[0];
+        const bool ok = lo > 0.0;
+        const double r = ok ? hi / lo : __builtin_inf();
+        const double s = r * r;
+        if (spread) spread[0] = s;
+        if (flag) flag[0] = (ok && s <= limit) ? 0 : 1;
+    }
 }
 
 // ---- blocking policy (overridable for experiments: GPAR_POTRF_NBO / GPAR_POTRF_NBM / GPAR_POTRF_LOOKAHEAD) ----------

@@ -254,8 +254,27 @@ class HipEngine:
         finally:
             self._tls.safe = outer
 
-    def trsm_rlt_(self, L, B):
-        return hip.trsm_rlt_(L, B)
+    def trsm_rlt_(self, L, B, when=None):
+        return hip.trsm_rlt_(L, B, when=when)
+
+    def chol_spread(self, L, limit):
+        return hip.chol_spread(L, limit)
+
+    def vfe_spread_limit(self, n, M):
+        """Pivot spread of L_z = chol(K_zz) up to which the inducing-point bound forms K_zx D^-1 K_xz first and solves the M x M
+        result against L_z from both sides, instead of solving the n x M cross-Gram - GPAR_VFE_SPREAD_MAX, DEFAULT 0 = never (the
+        order stheno uses, backward stable whatever cond(K_zz)).  Opt-in because of what it costs in digits: the product-first
+        order loses ~cond(K_zz), and the pivot spread only bounds cond(K_zz) from below (M = 512 uniform points in 8 dimensions:
+        spread 53, cond 7.7e3).  Measured against 80-bit arithmetic (tools/exp_vfe_routes.py, profiles/r04_vfe_routes.txt):
+        relative error of the bound 2e-16 .. 8e-13 for spread <= 3e3 at M = 96, 8e-13 at M = 512 / n = 8192; C4 (M = 1024,
+        n = 65536) differs from the solve-first value by 2.2e-10 - where solve-first stays at 1e-15 .. 1e-14 throughout.  With a
+        limit set (1e3 is what the measurements used) the order is decided on the device per evaluation (gpar_trsm_rlt_if: no
+        host synchronisation, a failed or ill-conditioned factor takes the solve-first order, same bits as without the switch);
+        C4 15.2 -> 12.2 ms.  Only offered where the n x M solve is large; gradient passes and FITC always solve first."""
+        limit = float(os.environ.get("GPAR_VFE_SPREAD_MAX", "0"))
+        if limit <= 0.0 or n * M < (1 << 24) or M < 128:
+            return 0.0
+        return limit
 
     def trsm_rln_(self, L, B):
         return hip.trsm_rln_(L, B)

@@ -869,18 +869,36 @@ class PseudoObs:
         n, M = self.fdd.n, self.u.n
         px, pz = self.fdd.pts(), self.u.pts()
         d = self.fdd.noise
+        # Which ORDER forms A - I = L_z^-1 K_zx D^-1 K_xz L_z^-T is decided on the device, from the pivot spread of L_z
+        # (HipEngine.vfe_spread_limit): the n x M solve against L_z first (backward stable whatever cond(K_zz); M^2 n
+        # flops), or the product first and the M x M result solved from both sides (2 M^3 flops; loses ~cond(K_zz) digits).
+        # The gradient pass and FITC need the solved cross-Gram itself: they always take the first.
+        limit = 0.0
+        if self.method != "fitc" and not getattr(self, "_force_solve", False) and hasattr(eng, "vfe_spread_limit"):
+            limit = eng.vfe_spread_limit(n, M)
         # L_z = chol(K_zz + eps I): a latency-bound chain of panel kernels on an M x M matrix (0.3 ms at M = 1024) that nothing
         # below needs before the triangular solve - on a side stream it runs beside the n x M cross-Gram build
         side = eng.side_stream() if hasattr(eng, "side_stream") and not base.is_posterior and n * M >= (1 << 22) else None
-        with (_on_side(side) if side is not None else contextlib.nullcontext()):
-            Lz = eng.new_matrix(M, M)
-            mean_z = base._moments_into(pz, Lz, None, eng.epsilon)
-            del mean_z  # the bound only involves the mean at the observed inputs
-            _, info = eng.potrf_(Lz)
+        Lz = eng.new_matrix(M, M)   # (allocated on the caller's stream: its lifetime follows that stream, whatever happens on the side)
+        ill = None
+        try:
+            with (_on_side(side) if side is not None else contextlib.nullcontext()):
+                mean_z = base._moments_into(pz, Lz, None, eng.epsilon)
+                del mean_z  # the bound only involves the mean at the observed inputs
+                _, info = eng.potrf_(Lz)
+                if limit > 0.0:
+                    _, ill = eng.chol_spread(Lz, limit)   # device word: 1 = K_zz too ill-conditioned for the product-first order
+        except BaseException:
+            if side is not None:   # whatever went wrong, the caller's stream is ordered after the side stream again
+                torch.cuda.current_stream(side.device).wait_stream(side)
+            raise
+        pending_join = side is not None
 
         def joined():   # the factor is needed from here on (and its info word may only be read once it has been written)
-            if side is not None:
-                _join_side(side, Lz, info)
+            nonlocal pending_join
+            if pending_join:
+                _join_side(side, info, ill)
+                pending_join = False
             eng.check_info(info)
 
         kdiag = base._diag(px)
@@ -898,7 +916,10 @@ class PseudoObs:
             # Bs = D^-1/2 K_xz L_z^-T (n x M): the row scaling rides along in the Gram kernel
             Bs = base._cross(px, pz, row_scale=rs)
             joined()
-            eng.trsm_rlt_(Lz, Bs)
+            if ill is None:
+                eng.trsm_rlt_(Lz, Bs)
+            else:
+                eng.trsm_rlt_(Lz, Bs, when=(ill, True))   # (product-first order: Bs stays D^-1/2 K_xz)
         resid = self.y if not base.is_posterior else self.y - base._mean_at(px)
         ys = resid.reshape(-1) * rs
         # A - I = Bs^T Bs: ONE product over the n data points (K = n is cut into slices so that the whole chip works);
@@ -914,6 +935,19 @@ class PseudoObs:
         else:
             G = eng.gemm(Bs, Bs, ta=True, c_lower=True)
             c = eng.gemv_t(Bs, ys).reshape(1, M)
+        if ill is not None:
+            # product-first order (skipped on the device when K_zz is ill-conditioned): [S; c^T] <- [S; c^T] L_z^-T, then the
+            # transposed M x M block once more - L_z^-1 S L_z^-T and L_z^-1 c.  S enters symmetrised, so that the transposition
+            # is the identity when the solves are skipped.
+            W = eng.new_matrix(M + 1, M)
+            low = torch.tril(G)
+            W[:M].copy_(low + torch.tril(low, -1).T)
+            W[M:].copy_(c)
+            eng.trsm_rlt_(Lz, W, when=(ill, False))
+            c = W[M:].clone()
+            G = eng.new_matrix(M, M)
+            G.copy_(W[:M].T)
+            eng.trsm_rlt_(Lz, G, when=(ill, False))
         yDy = torch.sum(ys * ys)
         trace_term = torch.sum(kdiag / d) - torch.sum(torch.diagonal(G)) if self.method == "vfe" else 0.0
 
@@ -930,12 +964,21 @@ class PseudoObs:
         eng.trsm_rln_(Lz, v)
         deferring = getattr(eng, "_deferred", None) is not None
         self._state = {"Lz": Lz, "La": facA.L, "v": v, "elbo": elbo.detach() if deferring else elbo.detach().cpu(),
-                       "Bs": Bs, "G": G, "facA": facA, "kdiag": kdiag, "ys": ys, "d": d,
+                       "Bs": Bs, "G": G, "facA": facA, "kdiag": kdiag, "ys": ys, "d": d, "solved": ill is None,
                        "moves": (excess > 0).to(d.dtype) if self.method == "fitc" else None}
         return self._state
 
     def _value(self):
         return self._compute()["elbo"]
+
+    def _solved_state(self):
+        """The state with Bs = D^-1/2 K_xz L_z^-T in it (what the gradient pass differentiates): computed again, cross-Gram solve
+        first, should a value-only evaluation have left the order to the device."""
+        st = self._compute()
+        if not st["solved"]:
+            self._state, self._force_solve = None, True
+            st = self._compute()
+        return st
 
     def logpdf(self):
         """The VFE bound; differentiable with respect to kernel parameters and noise when they carry a graph."""
@@ -947,6 +990,7 @@ class PseudoObs:
             if params or noise is not None or X is not None or Z is not None:
                 self._params = params
                 self._noise_device = None if noise is None else noise.device
+                self._force_solve = True   # (the gradient pass needs the solved cross-Gram)
                 return _LogMarginal.apply(self, noise, X, Z, *[p[3] for p in params])
         return self._value()
 
@@ -967,7 +1011,7 @@ class PseudoObs:
         derivatives are one fused device pass each (`kernel_grads_vfe`)."""
         vfe, fitc = self.method == "vfe", self.method == "fitc"
         eng = self.eng
-        st = self._compute()
+        st = self._solved_state()
         n, M = self.fdd.n, self.u.n
         d = st["d"]  # the observation noise; FITC: the effective noise d + k_aa - q_aa
         rs = torch.rsqrt(d)

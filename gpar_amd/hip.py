@@ -319,16 +319,35 @@ def potrf_batch_(A, batch, nf=None, fused=True):
     return logdet, info
 
 
-def trsm_rlt_(L, B):
-    """B <- B L^-T (rows of B solved by forward substitution)."""
+def trsm_rlt_(L, B, when=None):
+    """B <- B L^-T (rows of B solved by forward substitution).  `when` = (flag, sense): predicated on the device word flag[0] - the
+    solve happens iff (flag[0] != 0) == sense (gpar_trsm_rlt_if); B is left untouched otherwise."""
     lib = _lib.load()
     _check_mat(L, "L")
     _check_mat(B, "B")
     n = L.shape[0]
     if B.shape[1] != n:
         raise ValueError("B must have as many columns as L has rows")
+    if when is not None:
+        flag, sense = when
+        if flag.dtype != torch.int32 or not flag.is_cuda:
+            raise TypeError("the predicate of a solve is an int32 device word")
+        _lib.check(lib.gpar_trsm_rlt_if(L.data_ptr(), n, _ld(L), B.data_ptr(), B.shape[0], _ld(B), flag.data_ptr(), int(bool(sense)),
+                                        stream_ptr(B.device)), "gpar_trsm_rlt_if")
+        return B
     _lib.check(lib.gpar_trsm_rlt(L.data_ptr(), n, _ld(L), B.data_ptr(), B.shape[0], _ld(B), stream_ptr(B.device)), "gpar_trsm_rlt")
     return B
+
+
+def chol_spread(L, limit):
+    """(spread, flag) device words of a Cholesky factor: (max L_jj / min L_jj)^2 and whether it exceeds `limit` (gpar_chol_spread)."""
+    lib = _lib.load()
+    _check_mat(L, "L")
+    spread = torch.empty(1, dtype=torch.float64, device=L.device)
+    flag = torch.empty(1, dtype=torch.int32, device=L.device)
+    _lib.check(lib.gpar_chol_spread(L.data_ptr(), L.shape[0], _ld(L), float(limit), spread.data_ptr(), flag.data_ptr(), stream_ptr(L.device)),
+               "gpar_chol_spread")
+    return spread, flag
 
 
 def trsm_rln_(L, B):

@@ -267,6 +267,17 @@ int gpar_logpdf_lockstep(const gpar_layer_t* layers, int batch, const double* x,
 /* B <- B L^-T  (right side, lower, transposed: forward substitution on the rows of B; B is nrows x n).
  * [solve_triangular inside matrix.iqf_diag / PosteriorKernel, reached from gpar/model.py:226,264,298] */
 int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);
+/* The same solve, PREDICATED on a device word (ABI v5): it happens iff (flag[0] != 0) == (run_if != 0), decided on the device when
+ * the kernels start - flag is written by an earlier kernel of the stream (gpar_chol_spread), and no host synchronisation is
+ * involved; a solve that is skipped costs its (empty) launches, B is left untouched.  flag == NULL: unconditional.
+ * gpar_chol_spread: spread[0] <- (max L_jj / min L_jj)^2, a lower bound of cond(L L^T) that the factor holds for free;
+ * flag[0] <- 1 if the spread exceeds `limit` or a pivot is not positive, else 0 (either pointer may be NULL).
+ * [The inducing-point bound (stheno PseudoObs, gpar/model.py:286-287) needs A = I + L_z^-1 K_zx D^-1 K_xz L_z^-T.  Solving the
+ *  n x M cross-Gram against L_z first (M^2 n flops) is backward stable whatever cond(K_zz); forming K_zx D^-1 K_xz first and
+ *  solving the M x M result from both sides (2 M^3 flops) loses a factor ~cond(K_zz) and is only taken when the pivot spread of
+ *  L_z says that this is harmless - each of the two orders is predicated on the same word, one of them runs.] */
+int gpar_trsm_rlt_if(const double* L, int n, int ldl, double* B, int nrows, int ldb, const int* flag, int run_if, void* stream);
+int gpar_chol_spread(const double* L, int n, int ldl, double limit, double* spread, int* flag, void* stream);
 /* B <- B L^-1  (right side, lower, not transposed: backward substitution on the rows of B). */
 int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);
 

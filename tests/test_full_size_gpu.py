@@ -141,6 +141,45 @@ def test_c5_full_size_predict_with_200_samples(hip):
     assert np.abs((lmean - mean) / (np.sqrt(2.0 / S) * sd)).max() < 8.0
 
 
+@pytest.mark.parametrize("dims,M", [(8, 1024), (8, 840), (1, 512)])
+def test_inducing_point_bound_order_is_chosen_on_the_device(hip, monkeypatch, dims, M):
+    """A - I = L_z^-1 K_zx D^-1 K_xz L_z^-T of the inducing-point bound (gp.PseudoObs._compute): where the pivot spread of L_z
+    allows (GPAR_VFE_SPREAD_MAX: opt-in, see HipEngine.vfe_spread_limit for what it costs in digits), the n x M product is formed
+    first and the M x M result solved from both sides; otherwise - and by default - the n x M cross-Gram is solved first.  Inducing inputs in 8 dimensions are well-conditioned (the first
+    order runs: same bound to 1e-11 - tools/exp_vfe_routes.py has the error against 80-bit arithmetic -, same posterior means);
+    inducing inputs on a line are not (cond ~1e13: the second order runs, decided on the device: the same BITS as with the
+    switch off).  The gradient pass always works on the solved cross-Gram."""
+    from gpar_amd.regression import GPARRegressor
+
+    n, p = 40000, 3
+    x, y = _data(n, dims, p)
+    z = np.random.default_rng(3).uniform(0, 1, (M, dims))
+    xs = np.random.default_rng(4).uniform(0, 1, (50, dims))
+
+    def run():
+        reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False, x_ind=z)
+        value = float(reg.logpdf(hip.tensor(x), hip.tensor(y)))
+        reg.condition(x, y)
+        hip.seed(11)
+        mean = reg.predict(xs, num_samples=3, latent=True)
+        return value, mean
+
+    solved = run()   # the default: the cross-Gram is solved first, always
+    monkeypatch.setenv("GPAR_VFE_SPREAD_MAX", "1e3")
+    auto = run()
+    if dims == 1:
+        assert auto[0] == solved[0] and np.array_equal(auto[1], solved[1])
+    else:
+        assert auto[0] != solved[0]   # (the other order did run)
+        assert abs(auto[0] - solved[0]) <= 2e-10 * abs(solved[0]), (auto[0], solved[0])   # what the product-first order costs at this size
+        np.testing.assert_allclose(auto[1], solved[1], rtol=1e-6, atol=1e-7)
+    # training differentiates the solved cross-Gram whatever the value path chose
+    reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False, x_ind=z)
+    reg.fit(x[:20000], y[:20000, :2], iters=1)
+    assert all(np.all(np.isfinite(v)) for v in reg.get_variables().values())
+    monkeypatch.delenv("GPAR_VFE_SPREAD_MAX")
+
+
 def test_c4_full_size_inducing_point_bound_against_the_dense_nystrom_route(hip):
     from gpar_amd import hip as H
     from gpar_amd.gp import PseudoObs
@@ -163,7 +202,7 @@ def test_c4_full_size_inducing_point_bound_against_the_dense_nystrom_route(hip):
     d = torch.full((n,), noise, dtype=torch.float64, device=hip.device)
     obs = PseudoObs(f(zd), f(design, d), yd[:, p - 1])
     elbo = float(obs.logpdf())
-    st = obs._compute()
+    st = obs._solved_state()
     Bs, G = st["Bs"], st["G"]
 
     # split-K Bs^T Bs against the vendor library's product of the same operands

@@ -155,6 +155,30 @@ def test_trsm(env, n, rows):
     assert np.allclose(X, scipy.linalg.solve_triangular(L, B.T, lower=True, trans="T").T, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("n,rows", [(50, 3), (333, 130), (1024, 300), (1100, 64), (840, 841), (5000, 70)])
+def test_predicated_solve_and_pivot_spread(env, n, rows):
+    """gpar_trsm_rlt_if: the solve happens iff (flag != 0) == run_if, decided on the device - either exactly the unconditional
+    solve (same bits) or nothing at all (B untouched), through every kernel the path launches (fused blocks, their GEMM updates,
+    ragged strips, paired blocks).  gpar_chol_spread: (max L_jj / min L_jj)^2 and the flag against a limit."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n * 7 + rows)
+    L = np.linalg.cholesky(_spd(rng, n))
+    B = rng.standard_normal((rows, n))
+    dL = to_dev(L + np.triu(np.full((n, n), np.nan), 1))
+    want = hip.trsm_rlt_(dL, to_dev(B)).cpu().numpy()
+    diag = np.diag(L)
+    true_spread = (diag.max() / diag.min()) ** 2
+    for limit, expect in ((true_spread * 1.0001, 0), (true_spread * 0.9999, 1)):
+        spread, flag = hip.chol_spread(dL, limit)
+        assert int(flag.item()) == expect and abs(float(spread) - true_spread) <= 1e-12 * true_spread
+        for sense in (False, True):
+            X = hip.trsm_rlt_(dL, to_dev(B), when=(flag, sense)).cpu().numpy()
+            assert np.array_equal(X, want if bool(expect) == sense else B), (limit, sense)
+    bad = to_dev(L + np.triu(np.full((n, n), np.nan), 1))
+    bad[n // 2, n // 2] = float("nan")   # a failed factorisation counts as ill-conditioned
+    assert int(hip.chol_spread(bad, 1e300)[1].item()) == 1
+
+
 @pytest.mark.parametrize("n,rows", [(5000, 130), (6145, 70)])
 def test_trsm_forward_with_paired_blocks(env, n, rows):
     """n >= 4096 + 1024: the forward solve pairs 512-column blocks (one rank-1024 update per pair), also with a ragged
