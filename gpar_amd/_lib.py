@@ -84,6 +84,9 @@ SIGNATURES = {
     "gpar_jit_compile_check": (_c_int, [_c_int, ctypes.POINTER(KSpec), _c_int, ctypes.c_char_p, ctypes.c_char_p, _c_int]),
     "gpar_init": (_c_int, [_ptr]),
     "gpar_jit_prepare": (_c_int, [_c_int, ctypes.POINTER(KSpec), _c_int, _ptr]),
+    "gpar_jit_compile": (ctypes.c_longlong, [_c_int, ctypes.POINTER(KSpec), _c_int, ctypes.c_char_p, _ptr, ctypes.c_longlong, ctypes.c_char_p, _c_int,
+                                             ctypes.c_char_p, _c_int]),
+    "gpar_aot_stats": (_c_int, [ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "gpar_jit_stats": (_c_int, [ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "gpar_featurize": (_c_int, [ctypes.POINTER(FSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "gpar_gram": (

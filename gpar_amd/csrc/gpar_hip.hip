@@ -328,6 +328,41 @@ int gpar_jit_compile_check(int kind, const gpar_kspec_t* ks, int dz, const char*
     return ok ? (int)code.size() : -1;
 }
 
+// Compile the kernel of `kind` for this structure and hand back the code object together with its archive key: the build step
+// (gpar_amd/aot.py) collects these into gpar_aot_<arch>.bin.  Needs no GPU.  Returns the code size (> capacity: nothing copied), or -1.
+long long gpar_jit_compile(int kind, const gpar_kspec_t* ks, int dz, const char* arch, void* code_out, long long capacity, char* key_out,
+                           int key_len, char* log, int log_len) {
+    if (!ks || !arch || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS || dz < 0 ||
+        dz > GPAR_MAX_DIMS)
+        return GPAR_ARG_ERROR(1);
+    std::string source, entry;
+    int jkind = 0, extra = 0;
+    if (!jit_request(kind, *ks, dz, jkind, extra, entry, source, true)) return GPAR_ARG_ERROR(2);
+    std::string code, text;
+    const bool ok = jit_compile(source, entry.c_str(), arch, code, text);
+    if (log && log_len > 0) {
+        const size_t n = text.size() < (size_t)(log_len - 1) ? text.size() : (size_t)(log_len - 1);
+        memcpy(log, text.data(), n);
+        log[n] = '\0';
+    }
+    if (!ok) return -1;
+    const std::string key = aot_key(jkind, *ks, dz, extra);
+    if (key_out && key_len > 0) {
+        const size_t n = key.size() < (size_t)(key_len - 1) ? key.size() : (size_t)(key_len - 1);
+        memcpy(key_out, key.data(), n);
+        key_out[n] = '\0';
+    }
+    if (code_out && (long long)code.size() <= capacity) memcpy(code_out, code.data(), code.size());
+    return (long long)code.size();
+}
+
+int gpar_aot_stats(int* entries, int* loaded) {
+    GPAR_API_GUARD_NOSTREAM;
+    if (entries) *entries = (int)g_aot.entries.size();
+    if (loaded) *loaded = g_aot.loaded;
+    return 0;
+}
+
 // (kind, structure) -> what the launch paths would ask jit_get for: cache key ingredients, entry point, source
 static bool jit_request(int kind, const gpar_kspec_t& ks, int dz, int& jkind, int& extra, std::string& entry, std::string& source, bool want_source) {
     if (kind == JIT_GRAM) {
@@ -366,6 +401,7 @@ int gpar_jit_prepare(int kind, const gpar_kspec_t* ks, int dz, void* stream) {
         auto it = g_jit.cache.find(key);
         if (it != g_jit.cache.end()) return it->second.failed ? 1 : 0;
         arch = jit_device_arch();
+        if (aot_install(jkind, *ks, dz, extra, key, entry.c_str(), arch)) return 0;   // compiled when the library was built
     }
     jit_request(kind, *ks, dz, jkind, extra, entry, source, true);
     std::string code, log;

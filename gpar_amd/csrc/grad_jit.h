@@ -229,11 +229,12 @@ static long long grad_jit_min_entries() {
 static bool grad_jit_launch(const gpar_kspec_t* ks, const double* z1, const double* zd1, int n1, int ldz1, const double* z2, const double* zd2,
                             int n2, int ldz2, int dz, const double* W, int ldw, int mode, double* workspace, int nblocks, hipStream_t stream) {
     const long long min_entries = grad_jit_min_entries();
-    if (mode == GPAR_GRAD_DIAG || min_entries < 0 || (long long)n1 * n2 < min_entries) return false;
+    if (mode == GPAR_GRAD_DIAG || min_entries < 0) return false;
     const bool has_zd = zd1 != nullptr;
     const size_t lds = ((size_t)(has_zd ? 4 : 2) * (dz > 0 ? dz : 1) * GRAM_LD + GRAM_TAB_DOUBLES + 4 * GPAR_GRAD_NACC) * sizeof(double);
     if (lds > 64 * 1024) return false;   // static LDS limit of a generated kernel: very wide kernels stay on the interpreter
     const int extra = 100 + mode * 2 + (has_zd ? 1 : 0);
+    if ((long long)n1 * n2 < min_entries && ((long long)n1 * n2 < aot_min_entries() || !aot_has(JIT_GRAD, *ks, dz, extra))) return false;   // small: only a build-time compiled kernel
     hipFunction_t fn = jit_get(JIT_GRAD, *ks, dz, extra, "gram_grad_jit", [&]() { return grad_jit_source(*ks, dz, mode, has_zd); });
     if (!fn) return false;
     GradJitArgs a{*ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2, W, ldw, workspace};
@@ -361,7 +362,8 @@ static bool input_grad_jit_launch(const gpar_kspec_t* ks, const double* z1, int 
                                   const double* W, int ldw, int mode, int nsplit, double* workspace, hipStream_t stream) {
     const long long min_entries = grad_jit_min_entries();
     // (4 x dz partial sums per thread in registers: up to 20 dims)
-    if (min_entries < 0 || (long long)n1 * n2 < min_entries || dz < 1 || dz > 20) return false;
+    if (min_entries < 0 || dz < 1 || dz > 20) return false;
+    if ((long long)n1 * n2 < min_entries && ((long long)n1 * n2 < aot_min_entries() || !aot_has(JIT_INPUT_GRAD, *ks, dz, 200 + mode))) return false;
     hipFunction_t fn = jit_get(JIT_INPUT_GRAD, *ks, dz, 200 + mode, "gram_input_grad_jit", [&]() { return input_grad_jit_source(*ks, dz, mode); });
     if (!fn) return false;
     InputGradJitArgs a{*ks, z1, n1, ldz1, z2, n2, ldz2, W, ldw, nsplit, workspace};

@@ -234,7 +234,10 @@ static bool gram_jit_launch(const gpar_kspec_t* ks, const double* z1, int n1, in
                             double* K, int ldk, int flags, const double* diag_add, double diag_const, const double* row_scale, int sym,
                             dim3 grid, hipStream_t stream, long long batch_z, long long batch_k) {
     const long long min_entries = gram_jit_min_entries();
-    if (min_entries < 0 || (long long)n1 * n2 * grid.z < min_entries) return false;
+    if (min_entries < 0) return false;
+    // (below the threshold only a kernel compiled at build time is used: it costs no compilation)
+    if ((long long)n1 * n2 * grid.z < min_entries && ((long long)n1 * n2 * grid.z < aot_min_entries() || dz > GRAM_JIT_MAX_DZ || !aot_has(JIT_GRAM, *ks, dz, 1)))
+        return false;
     // (the interpreter's grid enumerates tiles; this kernel takes tile rows x strips of column tiles)
     const int nt1 = gpar_ceil_div(n1, GRAM_T), nt2 = gpar_ceil_div(n2, GRAM_T);
     const long long tiles = ((flags & GPAR_GRAM_LOWER) ? (long long)nt1 * (nt1 + 1) / 2 : (long long)nt1 * nt2) * grid.z;

@@ -10,10 +10,14 @@
 // both paths call the same arithmetic helpers in the same order.
 #pragma once
 #include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <map>
 #include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -79,11 +83,82 @@ static bool jit_compile(const std::string& source, const char* name, const std::
     return ok;
 }
 
+// ---- kernels compiled at BUILD time --------------------------------------------------------------------------------------------
+// The same generated sources, compiled by the same compiler with the same options when the library is built
+// (__graft_entry__.build() -> gpar_amd/aot.py -> gpar_jit_compile) for the layer structures GPARRegressor's common configurations
+// produce, and kept as an archive of code objects next to the library (gpar_aot_<arch>.bin).  A structure found there costs a
+// hipModuleLoadData (~1 ms) instead of 0.3-0.6 s of hiprtc at first use - so it is used at EVERY problem size, not only where a
+// training run repays a compilation: below n = 4096 the interpreting gradient kernels run at 397 / 380 registers with spills.
+// Archive: "GPARAOT1", u32 arch length + arch, u32 count, then per entry u32 key length + key ("<kind>#<signature>"), u64 code
+// size + code object.  Anything unreadable is ignored (hiprtc then serves, as before).
+struct AotState {
+    bool tried = false;
+    std::string arch;
+    std::vector<char> blob;
+    std::map<std::string, std::pair<size_t, size_t>> entries;   // key -> (offset, size) into blob
+    int loaded = 0;
+};
+static AotState g_aot;
+
+static std::string aot_dir() {
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void*>(&aot_dir), &info) || !info.dli_fname) return ".";
+    std::string path(info.dli_fname);
+    const size_t slash = path.find_last_of('/');
+    return slash == std::string::npos ? "." : path.substr(0, slash);
+}
+
+static void aot_init(const std::string& arch) {
+    if (g_aot.tried) return;
+    g_aot.tried = true;
+    if (const char* e = getenv("GPAR_AOT")) { if (atoi(e) == 0) return; }
+    std::string base = arch.substr(0, arch.find(':'));   // "gfx950:sramecc+:xnack-" -> "gfx950"
+    const std::string path = aot_dir() + "/gpar_aot_" + base + ".bin";
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return;
+    fseek(f, 0, SEEK_END);
+    const long size = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<char> blob(size > 0 ? (size_t)size : 0);
+    const bool read_ok = size > 0 && fread(blob.data(), 1, (size_t)size, f) == (size_t)size;
+    fclose(f);
+    if (!read_ok || blob.size() < 16 || memcmp(blob.data(), "GPARAOT1", 8) != 0) return;
+    size_t at = 8;
+    auto u32 = [&](uint32_t& v) { if (at + 4 > blob.size()) return false; memcpy(&v, &blob[at], 4); at += 4; return true; };
+    auto u64 = [&](uint64_t& v) { if (at + 8 > blob.size()) return false; memcpy(&v, &blob[at], 8); at += 8; return true; };
+    uint32_t alen = 0, count = 0;
+    if (!u32(alen) || at + alen > blob.size()) return;
+    const std::string built_for(&blob[at], alen);
+    at += alen;
+    if (built_for != base || !u32(count)) return;
+    std::map<std::string, std::pair<size_t, size_t>> entries;
+    for (uint32_t i = 0; i < count; ++i) {
+        uint32_t klen = 0;
+        uint64_t csize = 0;
+        if (!u32(klen) || at + klen > blob.size()) return;
+        std::string key(&blob[at], klen);
+        at += klen;
+        if (!u64(csize) || at + csize > blob.size()) return;
+        entries[key] = {at, (size_t)csize};
+        at += csize;
+    }
+    g_aot.arch = base;
+    g_aot.blob.swap(blob);
+    g_aot.entries.swap(entries);
+}
+
+static std::string aot_key(int kind, const gpar_kspec_t& ks, int dz, int extra) { return std::to_string(kind) + "#" + jit_signature(ks, dz, extra); }
+
 static std::string jit_device_arch() {
+    static std::string known[16];   // (asked on every small launch: the property query is made once per device)
     int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return "";
+    if (dev >= 0 && dev < 16 && !known[dev].empty()) return known[dev];
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return "";
-    return std::string(prop.gcnArchName);
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return "";
+    const std::string arch(prop.gcnArchName);
+    if (dev >= 0 && dev < 16) known[dev] = arch;
+    return arch;
 }
 
 static std::string jit_key(int kind, const gpar_kspec_t& ks, int dz, int extra) {
@@ -107,6 +182,37 @@ static hipFunction_t jit_install(const std::string& key, const std::string& code
     return e.failed ? nullptr : e.fn;
 }
 
+// Launches below this many entries stay on the interpreter even when the archive holds their structure (GPAR_AOT_MIN_ENTRIES): a
+// handful of 64 x 64 tiles is all launch latency either way, and there the interpreter's is the shorter one - fit(iters=20), three
+// layers at n = 400: 87 ms interpreted, 104 ms generated; from n = 1024 on the generated kernels win (138 -> 123 ms; 3000: 298 -> 268).
+static long long aot_min_entries() {
+    static long long v = -1;
+    if (v < 0) { const char* e = getenv("GPAR_AOT_MIN_ENTRIES"); v = e ? atoll(e) : (1LL << 19); }
+    return v;
+}
+
+// Is there a build-time compiled kernel for (kind, structure) on the current device?  (Callers hold the library mutex.)
+static bool aot_has(int kind, const gpar_kspec_t& ks, int dz, int extra) {
+    const std::string arch = jit_device_arch();
+    if (arch.empty()) return false;
+    aot_init(arch);
+    return !g_aot.entries.empty() && g_aot.entries.count(aot_key(kind, ks, dz, extra)) > 0;
+}
+
+// Load the build-time compiled kernel of (kind, structure), if the archive holds one, under cache key `key`.
+static hipFunction_t aot_install(int kind, const gpar_kspec_t& ks, int dz, int extra, const std::string& key, const char* entry, const std::string& arch) {
+    if (arch.empty()) return nullptr;
+    aot_init(arch);
+    auto it = g_aot.entries.find(aot_key(kind, ks, dz, extra));
+    if (it == g_aot.entries.end()) return nullptr;
+    JitEntry e;
+    if (hipModuleLoadData(&e.module, g_aot.blob.data() + it->second.first) != hipSuccess || hipModuleGetFunction(&e.fn, e.module, entry) != hipSuccess)
+        return nullptr;   // (unusable entry: hiprtc serves)
+    g_jit.cache[key] = e;
+    g_aot.loaded++;
+    return e.fn;
+}
+
 // The compiled function for (kind, structure) on the current device, or nullptr (never compiled twice: a failure is cached too).
 // `make_source` is only called on a cache miss.  Callers hold the library mutex.
 template <typename MakeSource>
@@ -117,6 +223,7 @@ static hipFunction_t jit_get(int kind, const gpar_kspec_t& ks, int dz, int extra
     if (it != g_jit.cache.end()) return it->second.failed ? nullptr : it->second.fn;
     std::string code, log;
     const std::string arch = jit_device_arch();
+    if (hipFunction_t fn = aot_install(kind, ks, dz, extra, key, entry, arch)) return fn;
     const bool ok = !arch.empty() && jit_compile(make_source(), entry, arch, code, log);
     return jit_install(key, code, entry, ok, log);
 }

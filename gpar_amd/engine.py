@@ -136,7 +136,7 @@ class HipEngine:
         cache[width] = (stamp, ck)
         return ck
 
-    def prepare(self, kernels, rows, training=False, sparse=False, inputs=False):
+    def prepare(self, kernels, rows, training=False, sparse=False, inputs=False, cols=None):
         """Compile, NOW and concurrently, the run-time specialised device kernels that evaluating (and, with `training`,
         differentiating) layers with these `(kernel, width)` pairs on `rows` data points will ask for (csrc/jit.h): each structure
         costs 0.3-0.6 s of hiprtc time at first use, and left to the first evaluation the p layers' structures compile one after
@@ -149,7 +149,7 @@ class HipEngine:
         lib = _lib.load()
         gram_min = int(os.environ.get("GPAR_GRAM_JIT_MIN_ENTRIES", str(GRAM_JIT_MIN_ENTRIES)))
         grad_min = int(os.environ.get("GPAR_GRAD_JIT_MIN_ENTRIES", str(GRAD_JIT_MIN_ENTRIES)))
-        entries = int(rows) * int(rows)
+        entries = int(rows) * int(cols if cols else rows)
         todo = {}
         for kernel, width in kernels:
             ck = self.compile(kernel, width)
@@ -466,7 +466,12 @@ class HipEngine:
         pipeline stage, or when disabled (GPAR_SIDE_STREAM=0)."""
         if getattr(self._tls, "safe", False) or getattr(self._tls, "pipe_depth", 0) or os.environ.get("GPAR_SIDE_STREAM", "1") == "0":
             return None
-        return _device_streams(self.device, 1)[0]
+        # a stream of its own (not one of the layer / worker streams: from a worker thread whose current stream is that pool
+        # entry the "side" work would silently serialise with the caller's)
+        side = _SIDE.get(str(self.device))
+        if side is None:
+            side = _SIDE[str(self.device)] = torch.cuda.Stream(device=self.device)
+        return None if side == torch.cuda.current_stream(self.device) else side
 
     def worker_streams(self, depth=None):
         """The same streams, for callers that drive them from separate host threads (GPARRegressor.fit trains
@@ -511,6 +516,7 @@ class HipEngine:
                 raise NotPositiveDefiniteError(int(code))
 
 
+_SIDE = {}     # device -> the one side stream of HipEngine.side_stream
 _STREAMS = {}  # device -> extra streams, shared by every engine of the process (the library pairs each caller stream
                # with an internal side stream, so the set of caller streams is kept small and stable)
 

@@ -322,12 +322,13 @@ class GPARRegressor:
         """Have the engine compile the layers' run-time specialised device kernels up front and concurrently (HipEngine.prepare);
         the layer constructors instantiate their hyper-parameters on the way, as the first evaluation would."""
         eng = get_engine()
-        if not hasattr(eng, "prepare") or rows * rows < (1 << 22) or os.environ.get("GPAR_JIT_PREPARE", "1") == "0":   # (prepare applies the thresholds)
+        cols = int(self.x_ind.shape[0]) if self.sparse else rows   # (inducing points: the launches are rows x M)
+        if not hasattr(eng, "prepare") or rows * cols < (1 << 22) or os.environ.get("GPAR_JIT_PREPARE", "1") == "0":   # (prepare applies the thresholds)
             return
         with torch.no_grad():
             layers = _construct_gpar(self, self.vs, m, p).layers
             eng.prepare([(model()[0].kernel, m + pi) for pi, model in enumerate(layers)], rows, training=training, sparse=self.sparse,
-                        inputs=inputs)
+                        inputs=inputs, cols=cols)
 
     def logpdf(self, x, y, w=None, sample_missing=False, posterior=False):
         """Log-density of observations under the prior (or, with `posterior`, the conditioned model).  Returns a

@@ -130,6 +130,16 @@ int gpar_jit_prepare(int kind, const gpar_kspec_t* ks, int dz, void* stream);
  * kernel structure must have been launched once before the capture).  Optional: everything still initialises lazily without it. */
 int gpar_init(void* stream);
 int gpar_jit_stats(int* compiled, int* failures, int* cached);
+/* Kernels compiled at BUILD time (ABI v5).  gpar_jit_compile compiles the kernel of `kind` (codes as above) for a structure and
+ * architecture and returns its code object (code_out / capacity; the return value is the size, -1 on a compilation failure with the
+ * compiler's log in `log`) and the key under which an archive holds it (key_out); needs no GPU.  The library's build step collects
+ * the common layer structures into gpar_aot_<arch>.bin next to the library; a structure found there is loaded instead of compiled -
+ * and, costing nothing, is then used at every problem size (GPAR_AOT=0: ignore the archive).  gpar_aot_stats: entries the archive of
+ * the current device's architecture holds (0 before the first lookup) / kernels loaded from it so far.
+ * [the structures are those gpar/regression.py:92-180 builds for the reference's keyword combinations] */
+long long gpar_jit_compile(int kind, const gpar_kspec_t* ks, int dz, const char* arch, void* code_out, long long capacity, char* key_out,
+                           int key_len, char* log, int log_len);
+int gpar_aot_stats(int* entries, int* loaded);
 
 int gpar_abi_version(void);
 size_t gpar_sizeof_fspec(void);

@@ -7,14 +7,6 @@ import pytest
 # the product asks for 8 hardware queues when its engine is created before the GPU is touched; the test session touches the GPU
 # earlier (torch.cuda.is_available() below), so the request is made here, as an application would export it
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# The kernels compiled at run time for a layer's structure are used from 2^26 (Gram) / 2^24 (gradient passes) entries per launch
-# on - where a training run repays the half second each costs.  The mid-size tests (n = 1024 .. 3000: some seventy gradient and
-# parity cases) would all stay on the ahead-of-time interpreter with those defaults; the session lowers the thresholds so that the
-# generated kernels see them too.  The interpreter keeps every case below n = 1024, the cases that switch the generated kernels
-# off explicitly (tests/test_hip_primitives.py, tests/test_switches_gpu.py) and bench.py's C2 leg.
-os.environ.setdefault("GPAR_GRAM_JIT_MIN_ENTRIES", str(1 << 22))
-os.environ.setdefault("GPAR_GRAD_JIT_MIN_ENTRIES", str(1 << 20))
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

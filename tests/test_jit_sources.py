@@ -1,6 +1,7 @@
 """The run-time specialised kernels are generated source (csrc/gram_jit.h): `gpar_jit_compile_check` compiles - without loading,
 so without a GPU - the kernel of a given layer structure for gfx950.  Every kernel family GPARRegressor can build must compile."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -66,3 +67,19 @@ def test_bad_arguments_are_refused():
     assert lib.gpar_jit_compile_check(99, ctypes.byref(ck.kspec), ck.dz, b"gfx950", log, len(log)) < -1000   # unknown kind
     assert lib.gpar_jit_compile_check(0, ctypes.byref(ck.kspec), 1000, b"gfx950", log, len(log)) < -1000     # more dims than the spec holds
     assert lib.gpar_jit_compile_check(0, None, ck.dz, b"gfx950", log, len(log)) < -1000
+
+
+def test_build_time_archive_covers_the_baseline_configurations():
+    """gpar_amd/aot.py: the archive next to the library holds the Gram / gradient kernels of the common layer structures - among
+    them every layer of BASELINE C2, C3 and C4 and the gradient passes of C5 - under the keys the library derives at run time."""
+    from gpar_amd import aot
+
+    assert os.path.exists(aot.ARCHIVE), "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    arch, keys = aot.read_keys()
+    assert arch == "gfx950" and len(keys) == len(set(keys)) >= 300
+    kinds = {k.split("#")[0] for k in keys}
+    assert kinds == {"0", "1", "2"}   # Gram, parameter-gradient, input-gradient
+    wanted = {(kind, bytes(ck.kspec), ck.dz) for kind, ck in aot.jobs()}
+    assert len(wanted) == len(keys)
+    # a structure that no keyword family produces is not there: the library compiles it at run time, as before
+    assert not any("d90x" in k for k in keys)
