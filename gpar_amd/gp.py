@@ -31,6 +31,7 @@ cases - observations of the prior, dense observations of a dense posterior - kee
 All heavy steps are engine primitives (HIP kernels); torch is used here only for O(n) vector plumbing.
 """
 import contextlib
+import os
 import math
 
 import numpy as np
@@ -450,13 +451,14 @@ class Stacked:
     (each sample's design matrix differs in its last columns).  Behaves like the list of its blocks; the batched posterior
     routines take the matrix as it is (one featurize / cross-Gram launch) instead of concatenating a list again."""
 
-    def __init__(self, matrix, count):
+    def __init__(self, matrix, count, shared_cols=0):
         self.matrix, self.count = matrix, int(count)
         self.rows = int(matrix.shape[0]) // max(self.count, 1)
+        self.shared_cols = int(shared_cols)   # the leading columns that are the same in every set (Stacked.repeat: all of x)
 
     @classmethod
     def repeat(cls, x, count):
-        return cls(x.repeat(count, 1), count)
+        return cls(x.repeat(count, 1), count, shared_cols=int(x.shape[1]))
 
     def __len__(self):
         return self.count
@@ -466,7 +468,7 @@ class Stacked:
             a, b, step = s.indices(self.count)
             if step != 1:
                 raise IndexError("contiguous slices only")
-            return Stacked(self.matrix[a * self.rows : b * self.rows], max(b - a, 0))
+            return Stacked(self.matrix[a * self.rows : b * self.rows], max(b - a, 0), self.shared_cols)
         if s < 0:
             s += self.count
         return self.matrix[s * self.rows : (s + 1) * self.rows]
@@ -479,7 +481,7 @@ class Stacked:
         ((count rows) x k)."""
         if cols.shape[0] == self.rows and cols.shape[0] != self.matrix.shape[0]:
             cols = cols.T.reshape(-1, 1)
-        return Stacked(torch.cat([self.matrix, cols], dim=1), self.count)
+        return Stacked(torch.cat([self.matrix, cols], dim=1), self.count, self.shared_cols)
 
 
 class FDD:
@@ -776,6 +778,74 @@ class Obs:
             var[:, s0:s1] = kd
         return mean, var
 
+    def _sample_batch_linear_tail(self, xs, noise_vec, zr, out):
+        """posterior_sample_batch when the columns that differ between the sets only enter the kernel through linear factors
+        standing alone in their terms (kernels.linear_tail) - GPAR's DEFAULT output dependence (reference
+        gpar/regression.py:141-146, 276-278: `linear=True, nonlinear=False`).  Then, with c_s the weighted features of those columns
+        at set s and Z_c the same at the training inputs,
+            K(x_s, X)   = K0(x, X) + c_s Z_c^T                       (K0: those features zeroed - the same for every s)
+            V_s         = K(x_s, X) L^-T = V0 + c_s U^T,              U = L^-1 Z_c      (n x q, q = number of such features)
+            mean_s      = V0 r + c_s (U^T r),                          r = L^-1 y
+            cov_s       = [K0(x, x) + D - V0 V0^T] + c_s E_s^T + E_s c_s^T,    E_s = c_s (I - U^T U) / 2 - V0 U
+        so the S stacked n* x n solves and the S rank-n downdates of the general routine become ONE of each plus a rank-2q update
+        per set; what stays per set is the n* x n* factorisation (lock-step) and the draw.  Same law, same random numbers, same
+        samples up to rounding.  Returns False (nothing done) when the structure or the sizes do not qualify."""
+        from .kernels import linear_tail
+
+        eng, fac = self.eng, self.factor()
+        if os.environ.get("GPAR_LINEAR_TAIL", "1") == "0" or not isinstance(xs, Stacked) or xs.shared_cols <= 0:
+            return False
+        ck, z = self.fdd.features()
+        n, S, ns = self.fdd.n, len(xs), xs.rows
+        if n == 0 or S < 2 or not hasattr(eng, "potrf_batch_") or ns > eng.batch_rows() or getattr(eng._tls, "safe", False):
+            return False
+        tail = linear_tail(ck, xs.shared_cols)
+        if tail is None:
+            return False
+        idx, weight = tail
+        q = len(idx)
+        dev = z.device
+        sel = torch.as_tensor(idx, dtype=torch.long, device=dev)
+        wts = torch.as_tensor(weight, dtype=torch.float64, device=dev)
+        # shared part: the first set with the varying features zeroed
+        z0 = eng.features(ck, _as_matrix(eng, xs[0])).clone()
+        z0.index_fill_(1, sel, 0.0)
+        V0 = eng.new_matrix(ns, n)
+        eng.gram(ck, z0, z, out=V0)
+        eng.trsm_rlt_(fac.L, V0)
+        Ut = eng.new_matrix(q, n)                      # U^T = Z_c^T L^-T
+        Ut.copy_((z.index_select(1, sel) * wts).T)
+        eng.trsm_rlt_(fac.L, Ut)
+        base = eng.new_matrix(ns, ns)
+        eng.gram(ck, z0, lower=True, diag_add=noise_vec, diag_const=eng.epsilon, out=base)
+        eng.gemm(V0, V0, tb=True, alpha=-1.0, beta=1.0, out=base, c_lower=True)
+        H = eng.gemm(V0, Ut, tb=True)                  # V0 U: n* x q
+        T = eng.gemm(Ut, Ut, tb=True)                  # U^T U: q x q
+        mean0 = eng.gemm(V0, fac.zrow, tb=True)        # n* x 1
+        beta = eng.gemm(Ut, fac.zrow, tb=True)         # q x 1
+        half = 0.5 * (torch.eye(q, dtype=torch.float64, device=dev) - T)
+        half = 0.5 * (half + half.T)                   # (symmetric to the last bit: c E^T + E c^T then is, too)
+        chunk = max(1, min(16384, int(16e9 // max(1, ns * ns * 8))))
+        for s0 in range(0, S, chunk):
+            s1 = min(S, s0 + chunk)
+            K = s1 - s0
+            z_all = eng.features(ck, _as_matrix(eng, xs[s0:s1].matrix))
+            C = eng.new_matrix(K * ns, q)
+            C.copy_(z_all.index_select(1, sel) * wts)  # (K n*) x q
+            E = eng.gemm(C, half) - H.repeat(K, 1)
+            means = mean0.repeat(K, 1) + eng.gemm(C, beta)
+            left = eng.new_matrix(K * ns, 2 * q)
+            right = eng.new_matrix(K * ns, 2 * q)
+            left[:, :q], left[:, q:] = C, E
+            right[:, :q], right[:, q:] = E, C
+            covs = eng.new_matrix(K * ns, ns)
+            covs.unflatten(0, (K, ns)).copy_(base.unsqueeze(0))   # (a view: the rows of `covs` are padded)
+            eng.gemm_batch_(left, right, covs, K, tb=True, alpha=1.0, beta=1.0, c_lower=True)
+            _, info = eng.potrf_batch_(covs, K)
+            eng.check_info(info)
+            eng.trmv_lower_batch_(covs, K, zr[:, s0:s1], out[:, s0:s1], add=means)
+        return True
+
     def posterior_sample_batch(self, xs, noise):
         eng, fac = self.eng, self.factor()
         ck, z = self.fdd.features()
@@ -786,6 +856,8 @@ class Obs:
             return out
         noise_vec = _noise_vector(eng, noise, ns)
         zr = eng.randn(ns, S)
+        if self._sample_batch_linear_tail(xs, noise_vec, zr, out):
+            return out
         chunk = self._chunk(ns)
         for s0 in range(0, S, chunk):
             s1 = min(S, s0 + chunk)

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["Kernel", "EQ", "RQ", "Linear", "ZeroKernel", "OneKernel", "compile_kernel", "CompiledKernel"]
+__all__ = ["Kernel", "EQ", "RQ", "Linear", "ZeroKernel", "OneKernel", "compile_kernel", "CompiledKernel", "linear_tail"]
 
 
 def _value(v):
@@ -221,6 +221,33 @@ class CompiledKernel:
 
     def __init__(self, fspec, kspec, dz, width, kernel, layout):
         self.fspec, self.kspec, self.dz, self.width, self.kernel, self.layout = fspec, kspec, dz, width, kernel, layout
+
+
+def linear_tail(ck, shared_cols):
+    """Does every factor of the compiled kernel `ck` that reads a design-matrix column >= `shared_cols` stand ALONE in its product
+    term and is it linear, with a positive coefficient?  Then
+        k(a, b) = k_base(a, b) + <c(a), c(b)>,   c = sqrt(coef) * (the features of those columns),
+    where k_base is the kernel with those features set to zero - what GPAR's default output dependence looks like (reference
+    gpar/regression.py:141-146: `linear=True, nonlinear=False` adds (y / s)(y' / s)^T over the previous outputs and nothing
+    else).  Returns (feature indices, their sqrt(coef) weights) or None."""
+    fs, ks = ck.fspec, ck.kspec
+    per_term = {}
+    for ti, fi, off, nd in ck.layout:
+        per_term[ti] = per_term.get(ti, 0) + 1
+    idx, weight = [], []
+    for ti, fi, off, nd in ck.layout:
+        cols = [int(fs.col[q]) for q in range(off, off + nd)]
+        if not any(c >= shared_cols for c in cols):
+            continue
+        f = ck.kernel.terms[ti].factors[fi]
+        coef = float(ks.coef[ti])
+        if f.type != "linear" or per_term[ti] != 1 or not coef > 0.0:
+            return None
+        for q, c in zip(range(off, off + nd), cols):
+            if c >= shared_cols:
+                idx.append(q)
+                weight.append(math.sqrt(coef))
+    return (idx, weight) if idx else None
 
 
 def compile_kernel(kernel, width):

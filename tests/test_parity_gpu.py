@@ -267,6 +267,46 @@ def test_lockstep_layers_equal_layer_by_layer_evaluation(monkeypatch, n, p):
         assert abs(got["lockstep"] - ref) <= 1e-9 * abs(ref), (got, ref)
 
 
+@pytest.mark.parametrize("kw,latent", [(dict(), True), (dict(), False), (dict(markov=1), True), (dict(input_linear=True, rq=True), True),
+                                       (dict(linear_scale=3.0, scale=0.3), False), (dict(nonlinear=True), True)])
+def test_linear_output_dependence_samples_with_one_shared_solve(monkeypatch, kw, latent):
+    """The reference's DEFAULT output dependence (linear=True, nonlinear=False: gpar/regression.py:141-146, 276-278) makes the
+    sample-dependent part of K(X, x*_s) a rank-q matrix; gp.Obs._sample_batch_linear_tail then draws all samples of a layer from
+    ONE triangular solve and ONE rank-n downdate plus a rank-2q update per sample.  Same random numbers in, the same samples out
+    as the general routine (GPAR_LINEAR_TAIL=0) up to rounding; a kernel with a nonlinear output part does not qualify (same bits)."""
+    from gpar_amd.engine import get_engine
+    from gpar_amd.regression import GPARRegressor
+
+    n, m, p, S, ns = 900, 2, 4, 7, 300
+    x, y = _problem(n, m, p, seed=5)
+    xs = np.random.default_rng(6).uniform(0, 1, (ns, m))
+    w = np.random.default_rng(7).uniform(0.5, 2.0, (ns, p))
+
+    def run():
+        out = {}
+        for mode in ["1", "0"]:
+            monkeypatch.setenv("GPAR_LINEAR_TAIL", mode)
+            reg = GPARRegressor(**dict(dict(scale=0.5, linear=True, nonlinear=False, noise=0.1), **kw))
+            reg.condition(x, y)
+            get_engine().seed(33)
+            out[mode] = np.stack(reg.sample(xs, w=w, posterior=True, num_samples=S, latent=latent))
+        monkeypatch.delenv("GPAR_LINEAR_TAIL")
+        return out
+
+    got = _on("hip", run)
+    assert got["1"].shape == (S, ns, p) and np.all(np.isfinite(got["1"]))
+    if kw.get("nonlinear"):
+        assert np.array_equal(got["1"], got["0"])
+    else:
+        assert not np.array_equal(got["1"], got["0"])   # (the other routine did run)
+        # With observation noise in the covariance the two routines agree to rounding.  A LATENT draw factors K** - V^T V + 1e-12 I,
+        # which is numerically singular at 300 points: two algebraically equal ways of forming it differ by ~1e-11, and a draw
+        # moves by that over sqrt(jitter) in the directions the data pin down - the same for any reordering of the general
+        # routine's sums.  The law is the same; the tolerance says what "the same samples" can mean there.
+        err = np.max(np.abs(got["1"] - got["0"]))
+        assert err < (1e-4 if latent else 1e-10), err
+
+
 @pytest.mark.parametrize("n,p,weights", [(700, 4, False), (512, 3, True), (1300, 5, True), (40, 70, True), (2100, 2, False)])
 def test_one_call_lockstep_evaluation_returns_the_same_bits(monkeypatch, n, p, weights):
     """gpar_logpdf_lockstep (ABI v5): the whole lock-step evaluation in one library call - no design matrix, noise tensor or
