@@ -146,12 +146,30 @@ def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
     lockstep = pipe is not None and gpar._same_rows(items) and hasattr(eng, "logpdf_dense_batch") and 0 < int(x.shape[0]) <= eng.batch_rows()
     pending = []
     values, stage = [], 0
+    # ... through ONE library call when y and w are whole device matrices and the layers are prior processes (model._lockstep_total)
+    from .model import _is_torch, _lockstep_total, one_call_enabled
+
+    onecall = (lockstep and hasattr(eng, "logpdf_lockstep") and _is_torch(y) and y.is_cuda and y.dim() == 2 and _is_torch(w)
+               and w.shape == y.shape and getattr(eng, "cholesky_retry_factor", 1.0) <= 1.0 and one_call_enabled())
+    if onecall:
+        for i, model in enumerate(gpar.layers[:len(items)]):
+            if i % size == rank:
+                f, noise = model()
+                if f.is_posterior or _differentiable(f, noise):
+                    onecall = False
+                    break
+    fast, x0 = [], x
     with _joining(pipe):
         for i, (is_last, ((yi, wi, mask), model)) in enumerate(last(zip(items, gpar.layers))):
             complete = isinstance(mask, slice)
             x = x[mask]
             mine = (i % size) == rank
             f = obs = None
+            if onecall:   # (independent layers, complete data: nothing is forwarded, no design matrix is formed per layer)
+                if mine:
+                    f, noise = model()
+                    fast.append((i, f, noise))
+                continue
             if mine:
                 f, noise = model()
                 if pipe is not None and _differentiable(f, noise):
@@ -189,10 +207,22 @@ def _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local):
                 x_ind = torch.cat([x_ind, ind_col], dim=1)
     if pipe is not None:
         pipe.join()
+    if fast:
+        got = _lockstep_total(eng, x0, y, w, fast)
+        if got is None:   # no room for the batch: layer by layer
+            xw = torch.cat([x0, y[:, :len(items) - 1]], dim=1)
+            for j, fj, nj in fast:
+                obs = gpar._obs(xw[:, :int(x0.shape[1]) + j], x_ind, y[:, j:j + 1], w[:, j], fj, nj, complete=True)
+                obs.transient = True
+                pending.append((fj, obs))
+        else:
+            values.extend(got)
     if pending:
         values.extend(_lockstep_values(eng, pending))
     for v in values:
         local = local + v
+    if onecall:
+        x = torch.cat([x0, y[:, :len(items) - 1]], dim=1) if len(items) > 1 else x0
     return local, x, x_ind
 
 

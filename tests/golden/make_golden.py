@@ -76,6 +76,66 @@ WORKLOADS = [
 ]
 
 
+# Micro-cases: ONE recalled detail of the third-party arithmetic each (the items marked "M": recalled, not
+# readable in /root/reference), with values chosen so that the alternative reading changes the number far beyond any tolerance.
+# One run of make_reference_golden.py then settles each of them individually.
+#   per-sincos-scales       m = 1: the two scales of the periodic embedding [sin, cos] differ by 6x (which is sin's?)
+#   per-block-order         m = 2: per/scales = [s1, s2, c1, c2] - sin block then cos block, or interleaved per input?
+#   per-decay-and-period    the locally periodic term: EQ(embedding / per_scale) * EQ(x / decay), period T in 2 pi x / T
+#   rq-small-alpha          RQ = (1 + r^2 / (2 alpha))^-alpha at the reference's initial alpha = 1e-2
+#   input-linear-const      (x / s)(x' / s)^T + c with the unbounded additive constant
+#   weights-noise-over-w    noise / w with weights from 0.1 to 10 (not noise * w, not noise / w^2)
+#   jitter-visible          B.epsilon = 1e-3 next to a noise of 1e-6: where the jitter is added, and that it is added once
+#   markov1-window          markov = 1: layer i sees output i - 1 only
+#   normalise-quirk         normalise_y=True: logpdf applies the UN-normalising map to its argument (gpar/regression.py:483, sic), with
+#                           mean / population standard deviation (ddof = 0) of the non-missing training outputs
+MICRO = [
+    ("micro-per-sincos-scales", dict(n=9, m=1, p=1, config=dict(linear=False, per=True), set={"0/input/per/scales": [0.4, 2.4]})),
+    ("micro-per-block-order", dict(n=10, m=2, p=1, config=dict(linear=False, per=True), set={"0/input/per/scales": [0.3, 0.9, 1.8, 3.6]})),
+    ("micro-per-decay-and-period", dict(n=10, m=1, p=1, config=dict(linear=False, per=True),
+                                        set={"0/input/per/pers": [0.37], "0/input/per/decay": [0.8], "0/input/per/var": 3.0, "0/input/var": 0.05})),
+    ("micro-rq-small-alpha", dict(n=10, m=2, p=2, config=dict(linear=True, nonlinear=True, rq=True),
+                                  set={"0/input/alpha": 1e-2, "1/input/alpha": 1e-2, "1/output/nonlin/alpha": 1e-2})),
+    ("micro-input-linear-const", dict(n=9, m=2, p=1, config=dict(linear=False, input_linear=True),
+                                      set={"0/input/lin/const": 0.35, "0/input/lin/scales": [0.7, 2.0], "0/input/var": 0.1})),
+    ("micro-weights-noise-over-w", dict(n=12, m=1, p=1, config=dict(linear=False), weights=(0.1, 10.0), set={"0/noise": 0.5})),
+    ("micro-jitter-visible", dict(n=10, m=1, p=2, config=dict(linear=True, nonlinear=True), epsilon=1e-3, set={"0/noise": 1e-6, "1/noise": 1e-6})),
+    ("micro-markov1-window", dict(n=10, m=1, p=3, config=dict(linear=True, nonlinear=True, markov=1))),
+    ("micro-normalise-quirk", dict(n=8, m=1, p=2, config=dict(linear=True, nonlinear=True), train=11)),
+]
+
+
+def micro_case(name, c, rng):
+    n, m, p = c["n"], c["m"], c["p"]
+    x = rng.uniform(-1.0, 1.0, (n, m))
+    y = rng.standard_normal((n, p))
+    hypers = hypers_for(m, p, c["config"], rng)
+    for key, value in c.get("set", {}).items():
+        assert key in hypers, key
+        hypers[key] = value
+    w = None
+    if "weights" in c:
+        lo, hi = c["weights"]
+        w = np.exp(rng.uniform(np.log(lo), np.log(hi), (n, p)))
+    eps = c.get("epsilon", 1e-12)
+    out = {"name": name, "config": c["config"], "impute": False, "replace": False, "epsilon": eps, "x_ind": None, "x": x.tolist(),
+           "y": y.tolist(), "w": None if w is None else w.tolist(), "hypers": hypers}
+    y_eval = y
+    if "train" in c:
+        # the regressor is conditioned on (train_x, train_y) with normalise_y=True and then asked for the PRIOR logpdf of (x, y):
+        # the reference maps y through _unnormalise_y first (sic), i.e. evaluates y * std + mean
+        tx = rng.uniform(-1.0, 1.0, (c["train"], m))
+        ty = 3.0 + 2.5 * rng.standard_normal((c["train"], p))
+        ty[2, 1] = np.nan
+        mean = np.array([np.mean(ty[~np.isnan(ty[:, i]), i]) for i in range(p)])
+        std = np.array([np.std(ty[~np.isnan(ty[:, i]), i]) for i in range(p)])   # population standard deviation, as lab's B.std
+        y_eval = y * std + mean
+        out["train_x"] = tx.tolist()
+        out["train_y"] = [[None if np.isnan(v) else v for v in row] for row in ty.tolist()]
+    out["logpdf"] = gpar_ref.gpar_logpdf(x, y_eval, w, hypers, c["config"], impute=False, replace=False, eps=eps)
+    return out
+
+
 def workload_case(name, c, rng):
     n, p = c["n"], c["p"]
     x = np.sort(rng.uniform(0.0, 1.0, n))
@@ -147,6 +207,9 @@ def main():
     wl_rng = np.random.default_rng(20260929)
     for name, c in WORKLOADS:
         out["gpar_logpdf"].append(workload_case(name, c, wl_rng))
+    micro_rng = np.random.default_rng(20260930)   # (a stream of its own: the vectors above keep their values)
+    for name, c in MICRO:
+        out["gpar_logpdf"].append(micro_case(name, c, micro_rng))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpar_cases.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -16,6 +16,10 @@ For every case of gpar_cases.json (same `name`, same x / y / w / hypers / config
     gpar_logpdf[]   GPARRegressor(**config).logpdf(x, y, w)            /root/reference/gpar/regression.py:461-506
     single_gp[]     f(x, noise).logpdf(y); (f | (f(x, noise), y)) mean and covariance at xs    gpar/model.py:226,298-301
     vfe[]           PseudoObs(f(z), f(x, noise), y): elbo, posterior mean / covariance at xs   gpar/model.py:286-287
+The `micro-*` cases among gpar_logpdf[] each isolate ONE detail of the third-party arithmetic that the build recalled rather than
+read (order of the periodic embedding's scales, RQ at alpha = 1e-2, the additive constant of the input-linear term, noise / w,
+where the jitter goes, the Markov window, the un-normalising logpdf quirk with the population standard deviation): a mismatch in
+reference_cases.json names the detail (tests/golden/make_golden.py: MICRO).
 plus, for every gpar_logpdf case, the posterior mean of `predict`-style conditioning is NOT recorded (it is sampled there);
 the deterministic pieces above are what the reference's own tests pin by identities (tests/test_regression.py:92-137).
 """
@@ -71,9 +75,11 @@ def main():
     for case in cases["gpar_logpdf"]:
         B.epsilon = case.get("epsilon", 1e-12)
         x_ind = case.get("x_ind")
-        reg = GPARRegressor(replace=case["replace"], impute=case["impute"], normalise_y=False,
+        reg = GPARRegressor(replace=case["replace"], impute=case["impute"], normalise_y="train_y" in case,
                             x_ind=None if x_ind is None else np.array(x_ind), **case["config"])
         _set_variables(reg, case["hypers"])
+        if "train_y" in case:   # micro-normalise-quirk: conditioned (normalise_y=True) before the PRIOR logpdf is asked for
+            reg.condition(np.array(case["train_x"]), _nan(case["train_y"]))
         w = None if case["w"] is None else np.array(case["w"])
         value = reg.logpdf(np.array(case["x"]), _nan(case["y"]), w)
         out["gpar_logpdf"].append({"name": case["name"], "logpdf": float(value)})
