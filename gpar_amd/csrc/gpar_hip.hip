@@ -505,6 +505,43 @@ int gpar_logpdf_lockstep(const gpar_layer_t* layers, int batch, const double* x,
     hipStream_t st = (hipStream_t)stream;
     for (int b = 0; b < batch; ++b)
         if (!layers[b].fs || !layers[b].ks || layers[b].y_col < 0) return GPAR_ARG_ERROR(2);
+    // Small evaluations: ONE launch per LS_CHUNK layers builds everything (gram.h: lockstep_build_kernel; same bits as the launches
+    // below) - when every feature map fits its compact form and the build is short enough for launch latency to matter.
+    bool fused_build = n > 0 && n <= env_int("GPAR_LOCKSTEP_FUSED_BUILD_ROWS", 2048) && w != nullptr;
+    for (int b = 0; b < batch && fused_build; ++b) {
+        const gpar_fspec_t& fs = *layers[b].fs;
+        if (fs.dz < 0 || fs.dz > LS_MAXDZ) fused_build = false;
+        for (int q = 0; q < fs.dz && fused_build; ++q)
+            if (fs.col[q] < 0 || fs.col[q] > 255) fused_build = false;
+    }
+    if (fused_build) {
+        GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&lockstep_build_kernel), 64 * 1024));
+        const int nt = gpar_ceil_div(n, GRAM_T);
+        for (int b0 = 0; b0 < batch; b0 += LS_CHUNK) {
+            const int cnt = batch - b0 < LS_CHUNK ? batch - b0 : LS_CHUNK;
+            LockstepSpecs sp;
+            memset(&sp, 0, sizeof(sp));
+            int dzmax = 1;
+            for (int b = 0; b < cnt; ++b) {
+                const gpar_layer_t& L = layers[b0 + b];
+                sp.ks[b] = *L.ks;
+                sp.fs[b].dz = L.fs->dz;
+                for (int q = 0; q < L.fs->dz; ++q) {
+                    sp.fs[b].col[q] = (unsigned char)L.fs->col[q];
+                    sp.fs[b].embed[q] = (unsigned char)L.fs->embed[q];
+                    sp.fs[b].inv_scale[q] = L.fs->inv_scale[q];
+                    sp.fs[b].freq[q] = L.fs->freq[q];
+                }
+                sp.noise[b] = L.noise;
+                sp.ycol[b] = L.y_col;
+                if (L.fs->dz > dzmax) dzmax = L.fs->dz;
+            }
+            const size_t lds = ((size_t)2 * dzmax * GRAM_LD + GRAM_TAB_DOUBLES) * sizeof(double);
+            hipLaunchKernelGGL(lockstep_build_kernel, dim3((unsigned)((long long)nt * (nt + 1) / 2), 1, cnt), dim3(256), lds, st, sp, x, n, ldx, y, ldy,
+                               w, ldw, jitter, A + (size_t)b0 * stride_a, lda, stride_a, logdet + b0, info + b0);
+        }
+        GPAR_LAUNCH_CHECK();
+    } else {
     for (int b0 = 0; b0 < batch; b0 += LOCKSTEP_CHUNK) {
         const int cnt = batch - b0 < LOCKSTEP_CHUNK ? batch - b0 : LOCKSTEP_CHUNK;
         LockstepCols lc;
@@ -521,6 +558,7 @@ int gpar_logpdf_lockstep(const gpar_layer_t* layers, int batch, const double* x,
         if (!rc) rc = gram_launch(L.ks, zb, n, ldz, zb, n, ldz, L.fs->dz, A + (size_t)b * stride_a, lda, GPAR_GRAM_LOWER, w ? nd + (size_t)b * n : nullptr,
                                   w ? jitter : L.noise + jitter, nullptr, st);
         if (rc) return rc;
+    }
     }
     if (n > 0) {
         const int rc = potrf_run_batch(A, batch, stride_a, n + 1, n, lda, logdet, info, st, potrf_flags);

@@ -140,6 +140,142 @@ __global__ __launch_bounds__(256) void gram_kernel(gpar_kspec_t ks, const double
     }
 }
 
+// ---- one launch builds the augmented matrices of up to LS_CHUNK layers of a lock-step evaluation (gpar_logpdf_lockstep) ----------
+// Layer b = blockIdx.z: features straight from the design matrix (what featurize_kernel computes, per tile instead of per launch),
+// the lower triangle of k_b + diag(noise_b / w) + jitter I by the SAME term loop as gram_kernel (same helpers, same order: same
+// bits), the observations into row n, corner / log-determinant / info word zeroed.  The specifications travel BY VALUE in the
+// kernel arguments (a compact feature map: at most LS_MAXDZ dims, columns < 256), so nothing is copied to the device and a
+// small evaluation's build is one launch instead of 2 p + 1.
+constexpr int LS_CHUNK = 4;
+constexpr int LS_MAXDZ = 24;
+struct LockstepFeat {
+    int dz, pad_;
+    unsigned char col[LS_MAXDZ];
+    unsigned char embed[LS_MAXDZ];
+    double inv_scale[LS_MAXDZ];
+    double freq[LS_MAXDZ];
+};
+struct LockstepSpecs {
+    gpar_kspec_t ks[LS_CHUNK];
+    LockstepFeat fs[LS_CHUNK];
+    double noise[LS_CHUNK];
+    int ycol[LS_CHUNK];
+};
+static_assert(sizeof(LockstepSpecs) <= 3600, "the specifications of a chunk must fit the kernel-argument segment");
+
+__device__ __forceinline__ double lockstep_feature(const LockstepFeat& fs, int q, const double* __restrict__ xrow) {
+    const double v = xrow[fs.col[q]];
+    double e;
+    if (fs.embed[q] == GPAR_EMBED_SIN) e = sin(v * fs.freq[q]);
+    else if (fs.embed[q] == GPAR_EMBED_COS) e = cos(v * fs.freq[q]);
+    else e = v;
+    return e * fs.inv_scale[q];
+}
+
+__global__ __launch_bounds__(256) void lockstep_build_kernel(LockstepSpecs sp, const double* __restrict__ x, int n, int ldx,
+                                                             const double* __restrict__ y, int ldy, const double* __restrict__ w, int ldw,
+                                                             double jitter, double* __restrict__ A, int lda, long long stride_a,
+                                                             double* __restrict__ logdet, int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(32))) double gsm[];
+    const int b = blockIdx.z;
+    const gpar_kspec_t& ks = sp.ks[b];
+    const LockstepFeat& fs = sp.fs[b];
+    const int dz = fs.dz;
+    double* K = A + (size_t)b * stride_a;
+    const int tile = blockIdx.x;
+    int bm = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+    while ((bm + 1) * (bm + 2) / 2 <= tile) ++bm;
+    while (bm * (bm + 1) / 2 > tile) --bm;
+    const int bn = tile - bm * (bm + 1) / 2;
+    const double* tab = gsm;
+    double* Za = gsm + GRAM_TAB_DOUBLES;
+    double* Zb = Za + (size_t)(dz > 0 ? dz : 1) * GRAM_LD;
+    const int t = threadIdx.x;
+    const int row0 = bm * GRAM_T, col0 = bn * GRAM_T;
+    gram_load_tables(gsm, t);
+    for (int idx = t; idx < GRAM_T * dz; idx += 256) {
+        const int r = idx / dz, d = idx - r * dz;
+        Za[d * GRAM_LD + r] = (row0 + r < n) ? lockstep_feature(fs, d, x + (size_t)(row0 + r) * ldx) : 0.0;
+        Zb[d * GRAM_LD + r] = (col0 + r < n) ? lockstep_feature(fs, d, x + (size_t)(col0 + r) * ldx) : 0.0;
+    }
+    const int ycol = sp.ycol[b];
+    if (bm == bn) {   // the diagonal tiles carry the observations of their columns into row n; the first one the scalars
+        if (t < GRAM_T && col0 + t < n) K[(size_t)n * lda + col0 + t] = y[(size_t)(col0 + t) * ldy + ycol];
+        if (tile == 0 && t == 0) {
+            K[(size_t)n * lda + n] = 0.0;
+            logdet[b] = 0.0;
+            info[b] = 0;
+        }
+    }
+    __syncthreads();
+    const int tx = t & 15, ty = t >> 4;
+    const bool vec = ((lda & 1) == 0) && ((((uintptr_t)K) & 15u) == 0);
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const int cb = 32 * h + 2 * tx;
+        double total[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) total[e] = 0.0;
+        int f = 0;
+        for (int term = 0; term < ks.nterms; ++term) {
+            double expo[8], lin[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { expo[e] = 0.0; lin[e] = ks.coef[term]; }
+            bool any_exp = false;
+            while (f < ks.nfactors && ks.factor[f].term == term) {
+                const int type = ks.factor[f].type, off = ks.factor[f].off, nd = ks.factor[f].nd;
+                double s[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] = 0.0;
+                if (type == GPAR_K_LINEAR) {
+                    gram_accum_dims<true>(Za, Zb, off, nd, ty, cb, s);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) lin[e] *= s[e];
+                } else {
+                    gram_accum_dims<false>(Za, Zb, off, nd, ty, cb, s);
+                    any_exp = true;
+                    if (type == GPAR_K_EQ) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) expo[e] += s[e];
+                    } else {
+                        gram_rqh8(s, ks.factor[f].alpha, expo, tab);
+                    }
+                }
+                ++f;
+            }
+            if (any_exp) {
+                gram_exph8(expo, tab);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) total[e] = fma(lin[e], expo[e], total[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) total[e] += lin[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * ty + i;
+            if (row >= n) continue;
+            const int col = col0 + cb;
+            double v0 = total[2 * i], v1 = total[2 * i + 1];
+            if (col0 == row0) {
+                // noise_b / w: an IEEE division, then + jitter - what the per-layer route adds as diag_add[row] + diag_const
+                const double nd_ = w ? sp.noise[b] / w[(size_t)row * ldw + ycol] : sp.noise[b];
+                const double dadd = nd_ + jitter;
+                if (col == row) v0 += dadd;
+                if (col + 1 == row) v1 += dadd;
+            }
+            double* out = K + (size_t)row * lda + col;
+            if (vec && col + 1 < n) {
+                *reinterpret_cast<g_d2*>(out) = g_d2{v0, v1};
+            } else {
+                if (col < n) out[0] = v0;
+                if (col + 1 < n) out[1] = v1;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gram_diag_kernel(gpar_kspec_t ks, const double* __restrict__ z, int n, int ldz,
                                                         double* __restrict__ out) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;

@@ -34,6 +34,24 @@ def one_call_enabled():
     return os.environ.get("GPAR_ONE_CALL", "1") != "0"
 
 
+_LAST_PATTERN = []   # [tensor, version, host pattern] of the last device-resident y whose NaN pattern was fetched
+
+
+def _device_nan_pattern(y):
+    """NaN pattern of a device tensor as a host array: one small device-to-host copy - a synchronisation - which an evaluation
+    loop over the SAME outputs (an optimiser, a benchmark: `logpdf(x, y)` again and again) would pay every time.  The last
+    tensor is remembered together with its version counter: the same storage, shape and strides at the same version hold the
+    same values (an in-place write moves the counter; the entry keeps the tensor alive, so its memory cannot have been reused)."""
+    if _LAST_PATTERN:
+        ref, version, pattern = _LAST_PATTERN
+        if (ref.data_ptr() == y.data_ptr() and ref.shape == y.shape and ref.stride() == y.stride() and ref.device == y.device
+                and ref._version == version == y._version):
+            return pattern
+    pattern = torch.isnan(y).cpu().numpy()
+    _LAST_PATTERN[:] = [y, y._version, pattern]
+    return pattern
+
+
 def _is_torch(a):
     return isinstance(a, torch.Tensor)
 
@@ -325,7 +343,7 @@ class GPAR:
             w = eng.tensor(w)
             if _is_torch(y) and y.is_cuda and y.dim() == 2 and host_masks():
                 if host_nan is None:
-                    host_nan = torch.isnan(y).cpu().numpy()
+                    host_nan = _device_nan_pattern(y)
                 y._host_nan = host_nan if host_nan.ndim == 2 else None
         return x, y, w
 
@@ -412,7 +430,7 @@ class GPAR:
                 complete = isinstance(mask, slice)
                 x = x[mask]
                 f, noise = model()
-                if pipe is not None and _differentiable(f, noise):
+                if pipe is not None and not onecall and _differentiable(f, noise):   # (the one-call route has checked every layer)
                     pipe.join()
                     pipe = None  # an objective under autograd: keep everything on the caller's stream
                 if pipe is not None and onecall:
@@ -465,7 +483,8 @@ class GPAR:
             if pending:
                 values.extend(_lockstep_values(eng, pending))
             for v in values:
-                total = total + v
+                # (the first term replaces the host-side zero it would be added to: 0 + v is v, and the addition is a launch)
+                total = v if (total.device.type == "cpu" and not total.requires_grad and total.dim() == 0 and float(total) == 0.0 and _is_torch(v)) else total + v
         if return_inputs:
             return x, x_ind
         return total.cpu() if total.is_cuda and not total.requires_grad else total

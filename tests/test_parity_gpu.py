@@ -721,3 +721,25 @@ def test_logpdf_rounding_against_extended_precision(hip, n, noise):
     got = float(f(x, np.full(n, noise)).logpdf(y))
     print(f"   product path: {abs(got - float(exact)) / ulp:.1f} ulp")
     assert abs(got - float(exact)) <= 1e-13 * abs(float(exact)) + 4 * err_lapack, (got, float(exact))
+
+
+def test_nan_pattern_of_device_outputs_is_remembered_until_they_change(hip):
+    """GPAR._prep fetches the NaN pattern of device-resident outputs once per tensor VERSION (model._device_nan_pattern): the same
+    tensor evaluated twice costs one fetch, an in-place write (here: an entry becomes missing) is seen at the next call."""
+    import torch
+
+    from gpar_amd import model
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(300, 1, 3, seed=9)
+    xd, yd = hip.tensor(x), hip.tensor(y)
+    reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False)
+    a = float(reg.logpdf(xd, yd))
+    cached = model._LAST_PATTERN[2]
+    assert float(reg.logpdf(xd, yd)) == a and model._LAST_PATTERN[2] is cached
+    yd[5, 1] = float("nan")
+    b = float(reg.logpdf(xd, yd))
+    assert model._LAST_PATTERN[2] is not cached and np.isfinite(b) and b != a
+    y2 = y.copy()
+    y2[5, 1] = np.nan
+    assert abs(b - float(reg.logpdf(x, y2))) <= 1e-12 * abs(b)
