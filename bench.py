@@ -239,7 +239,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
             "traffic": pmc_traffic(n, m, p),
-            "traffic_source": "profiles/r03_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)",
+            "traffic_source": "profiles/r04_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)",
             "launches": launches.value,
             "flop_per_launch": flops.value / launches.value,
             "avg_launch_ms": ms.value / launches.value,
@@ -360,7 +360,7 @@ def pmc_traffic(n, m, p):
     workload: counters cannot be collected from inside the timed process) - and null if the kernel's source has changed
     since those passes were taken (tools/refresh_profiles.sh stamps them with a hash of csrc/gemm_f64.h), so that a stale
     figure is never reported beside a new kernel."""
-    path = os.path.join(ROOT, "profiles", "r03_bench_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_bench_pmc_traffic.json")
     if (n, m, p) != (16384, 4, 8) or not os.path.exists(path):
         return None
     with open(path) as f:

@@ -44,14 +44,17 @@ CALL_TIME = [
     ("GPAR_POTRF_PREZERO", "0"),
     ("GPAR_POTRF_SMALL_UPDATE", "0"),
     ("GPAR_ONE_CALL", "0"),
+    ("GPAR_LOCKSTEP_FUSED_BUILD_ROWS", "0"),
     ("GPAR_POTRF_BATCH_REST_AFTER_LA", "100000"),
+    ("GPAR_VFE_SPREAD_MAX", "1e3"),
+    ("GPAR_LINEAR_TAIL", "0"),
     ("GPAR_FIT_THREADS", "1"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "0"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "-1"),
     ("GPAR_GRAD_JIT_MIN_ENTRIES", "0"),
     ("GPAR_GRAD_JIT_MIN_ENTRIES", "-1"),
 ]
-CACHED = [("GPAR_GEMM_HALF_TILES", "0"), ("GPAR_GEMM_HALF_TILES", "100000"), ("GPAR_GEMM_MIXED_TAIL", "0"), ("GPAR_GEMM_TILE_BLOCK", "0"),
+CACHED = [("GPAR_AOT", "0"), ("GPAR_AOT_MIN_ENTRIES", "0"), ("GPAR_GEMM_HALF_TILES", "0"), ("GPAR_GEMM_HALF_TILES", "100000"), ("GPAR_GEMM_MIXED_TAIL", "0"), ("GPAR_GEMM_TILE_BLOCK", "0"),
           ("GPAR_GEMM_TILE_BLOCK", "16")]
 
 
