@@ -119,6 +119,11 @@ SIGNATURES = {
         [ctypes.POINTER(FSpec), ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, ctypes.c_long, _ptr, _c_dbl, _ptr, _c_int, _ptr, _c_int,
          _ptr, _ptr, _ptr, _c_int, _ptr],
     ),
+    "gpar_logpdf_dense_grad": (
+        _c_int,
+        [ctypes.POINTER(FSpec), ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, ctypes.c_long, _ptr, _c_dbl, _ptr, _ptr, _c_int, _ptr, _c_int,
+         _ptr, _c_int, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _ptr],
+    ),
     "gpar_logpdf_dense_build": (
         _c_int,
         [ctypes.POINTER(FSpec), ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, ctypes.c_long, _ptr, _c_dbl, _ptr, _c_int, _ptr, _c_int,

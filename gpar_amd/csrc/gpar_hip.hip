@@ -278,6 +278,16 @@ __global__ __launch_bounds__(64) void lockstep_finish_kernel(const double* __res
     }
 }
 
+// row n of the augmented factor -> a contiguous vector (alpha before its backward solve); 1/2 diag(W) -> a vector
+__global__ __launch_bounds__(256) void copy_row_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void half_diag_kernel(const double* __restrict__ W, int ldw, int n, double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = 0.5 * W[(size_t)i * ldw + i];
+}
+
 extern "C" {
 
 int gpar_abi_version(void) { return GPAR_ABI_VERSION; }
@@ -632,6 +642,40 @@ int gpar_gram_grad_cross(const gpar_kspec_t* ks, const double* z1, const double*
                          int nblocks, double* out, void* stream) {
     GPAR_API_GUARD;
     return gram_grad_launch(ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2, dz, W, ldw, mode, workspace, nblocks, out, stream);
+}
+
+int gpar_logpdf_dense_grad(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, const double* y, long incy,
+                           const double* noise_diag, double jitter, double* z, double* zd, int ldz, double* A, int lda, double* X, int ldxw,
+                           double* W, int ldw, double* alpha, double* workspace, int nblocks, double* out, double* half_diag, int* info,
+                           int potrf_flags, void* stream) {
+    GPAR_API_GUARD;
+    if (!fs || !ks || !x || !y || !z || !A || !X || !W || !alpha || !workspace || !out || !half_diag || !info || n <= 0 || nblocks <= 0)
+        return GPAR_ARG_ERROR(1);
+    hipStream_t st = (hipStream_t)stream;
+    // ---- value: what gpar_logpdf_dense does
+    int rc = featurize_launch(fs, x, n, ldx, z, ldz, st);
+    if (!rc && zd && fs->dz > 0) {
+        const long total = (long)n * fs->dz;
+        hipLaunchKernelGGL(featurize_dfreq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *fs, x, n, ldx, zd, ldz);
+    }
+    if (!rc) rc = gram_launch(ks, z, n, ldz, z, n, ldz, fs->dz, A, lda, GPAR_GRAM_LOWER, noise_diag, jitter, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(logpdf_prepare_kernel, dim3(gpar_ceil_div(n + 1, 256)), dim3(256), 0, st, y, incy, n, A, lda, out + 1, info);
+    rc = potrf_run(A, n + 1, n, lda, out + 1, info, st, potrf_flags);
+    if (rc) return rc;
+    hipLaunchKernelGGL(logpdf_value_kernel, dim3(1), dim3(1), 0, st, (const double*)A, lda, n, (double)n * 1.8378770664093453,
+                       (const double*)(out + 1), out);
+    // ---- gradient ingredients: K^-1 from L, alpha^T = (L^-1 y)^T L^-1, W = alpha alpha^T - K^-1, the fused weighted-sum pass
+    rc = chol_inverse_run(A, n, lda, X, ldxw, W, ldw, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(copy_row_kernel, dim3(gpar_ceil_div(n, 256)), dim3(256), 0, st, (const double*)(A + (size_t)n * lda), alpha, n);
+    rc = trsm_rln_run(A, n, lda, alpha, 1, n, st);
+    if (!rc) rc = gemm_launch(1, 0, n, n, 1, 1.0, alpha, n, alpha, n, -1.0, W, ldw, GPAR_GEMM_C_LOWER, st);
+    if (!rc) rc = gram_grad_launch(ks, z, zd, n, ldz, z, zd, n, ldz, fs->dz, W, ldw, GPAR_GRAD_SYM, workspace, nblocks, out + 2, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(half_diag_kernel, dim3(gpar_ceil_div(n, 256)), dim3(256), 0, st, (const double*)W, ldw, n, half_diag);
+    GPAR_LAUNCH_CHECK();
+    return 0;
 }
 
 int gpar_gram_input_grad(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz,

@@ -45,6 +45,14 @@ __all__ = ["Measure", "GP", "FDD", "Obs", "PseudoObs", "PseudoObsVFE", "PseudoOb
 _LOG_2PI = math.log(2.0 * math.pi)
 
 
+def one_call_grad_rows():
+    """Layers with at most this many rows evaluate their training objective and its gradient through ONE library call
+    (gpar_logpdf_dense_grad; GPAR_ONE_CALL_GRAD_ROWS, 0 = never): the same launches, without ~30 host-side steps and two of the
+    three synchronisations around them.  Above, the host's share of an evaluation is negligible and the two-step form lets the
+    factor be reused."""
+    return int(os.environ.get("GPAR_ONE_CALL_GRAD_ROWS", "4096"))
+
+
 def _as_matrix(eng, x):
     """Engine tensor of rank 2 (`B.uprank`: a vector becomes a column)."""
     t = eng.tensor(x)
@@ -590,6 +598,8 @@ class Obs:
             if params or noise is not None or X is not None:
                 self._params = params
                 self._noise_device = None if noise is None else noise.device
+                # value and gradient ingredients in ONE library call when nothing but kernel parameters and noise is differentiated
+                self._fuse_grad = X is None and self._fusable_grad()
                 return _LogMarginal.apply(self, noise, X, None, *[p[3] for p in params])
         if self._value_only():
             # one library call: features, Gram, observations, factorisation, value (the factor is not kept)
@@ -608,11 +618,29 @@ class Obs:
                 and hasattr(eng, "logpdf_dense") and getattr(eng, "_deferred", None) is not None
                 and getattr(eng, "cholesky_retry_factor", 1.0) <= 1.0 and isinstance(self.y, torch.Tensor) and self.y.is_cuda)
 
+    def _fusable_grad(self):
+        """The objective-and-gradient entry point applies: dense observations of a prior process, nothing factored yet, checks
+        deferred (the value stays on the device), no retry ladder, small enough for the caller's side to matter."""
+        eng = self.eng
+        return (self._fac is None and not self.base.is_posterior and 0 < self.fdd.n <= one_call_grad_rows() and hasattr(eng, "logpdf_dense_grad")
+                and getattr(eng, "_deferred", None) is not None and getattr(eng, "cholesky_retry_factor", 1.0) <= 1.0
+                and isinstance(self.y, torch.Tensor) and self.y.is_cuda)
+
     def _value(self):
+        if getattr(self, "_fuse_grad", False) and self._fac is None:
+            eng = self.eng
+            ck = eng.compile(self.base.kernel, self.fdd.x.shape[1])
+            value, info, self._fused_gradients = eng.logpdf_dense_grad(ck, self.fdd.x.detach(), self.y, self.fdd.noise, eng.epsilon)
+            eng.check_info(info)
+            return value.detach()
         return self.factor().logpdf()
 
     def gradients(self):
         """(1/2 diag(W) as a device vector, kernel-parameter gradients) with W = alpha alpha^T - (K + D)^-1."""
+        fused = getattr(self, "_fused_gradients", None)
+        if fused is not None:
+            self._fused_gradients = None
+            return fused()
         eng, fac = self.eng, self.factor()
         W = eng.chol_inverse(fac.L)  # (K + D)^-1, lower triangle
         a = fac.alpha()

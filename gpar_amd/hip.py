@@ -112,6 +112,47 @@ def logpdf_dense(ck, x, y, noise_diag, jitter, lookahead=True, fused=True):
     return words[0], words[1:], info, A
 
 
+def logpdf_dense_grad(ck, x, y, noise_diag, jitter, periodic, lookahead=True, fused=True):
+    """One dense layer's log marginal likelihood AND its gradient ingredients in one library call (gpar_logpdf_dense_grad).
+    Returns (out, half_diag, info, A): out = [value, logdet, GRAD_NACC moment sums] (device), half_diag = 1/2 diag(W) (device, n),
+    info word, the (n + 1) x (n + 1) factor buffer."""
+    lib = _lib.load()
+    _check_mat(x, "x")
+    n, dev = x.shape[0], x.device
+    y = y.reshape(-1)
+    if y.numel() != n or y.dtype != torch.float64 or not y.is_cuda:
+        raise ValueError("y must hold one fp64 device value per row of x")
+    nptr = None
+    if noise_diag is not None:
+        noise_diag = noise_diag.reshape(-1).contiguous()
+        if noise_diag.numel() != n:
+            raise ValueError("noise_diag must hold one value per row of x")
+        nptr = noise_diag.data_ptr()
+    dz = max(ck.dz, 1)
+    z = alloc_matrix(n, dz, dev)
+    zd = alloc_matrix(n, dz, dev, zero=True) if periodic else None
+    A = alloc_matrix(n + 1, n + 1, dev)
+    X = alloc_matrix(n, n, dev)
+    W = alloc_matrix(n, n, dev)
+    nt = (n + 63) // 64
+    nblocks = max(1, min(nt * (nt + 1) // 2, 1024))
+    work = torch.empty(nblocks * _lib.GRAD_NACC + n, dtype=torch.float64, device=dev)   # gradient partials, then alpha
+    out = torch.empty(2 + _lib.GRAD_NACC, dtype=torch.float64, device=dev)
+    half_diag = torch.empty(n, dtype=torch.float64, device=dev)
+    info = torch.empty(1, dtype=torch.int32, device=dev)
+    flags = (0 if lookahead else _lib.POTRF_NO_LOOKAHEAD) | (0 if fused else _lib.POTRF_UNFUSED)
+    _lib.check(
+        lib.gpar_logpdf_dense_grad(
+            ctypes.byref(ck.fspec), ctypes.byref(ck.kspec), x.data_ptr(), n, _ld(x), y.data_ptr(), int(y.stride(0)), nptr, float(jitter),
+            z.data_ptr(), None if zd is None else zd.data_ptr(), _ld(z), A.data_ptr(), _ld(A), X.data_ptr(), _ld(X), W.data_ptr(), _ld(W),
+            work[nblocks * _lib.GRAD_NACC:].data_ptr(), work.data_ptr(), nblocks, out.data_ptr(), half_diag.data_ptr(), info.data_ptr(), flags,
+            stream_ptr(dev),
+        ),
+        "gpar_logpdf_dense_grad",
+    )
+    return out, half_diag, info, A
+
+
 def factor_dense_batch(items, jitter, fused=True):
     """Augmented matrices [[k_b(x_b, x_b) + diag(noise_b) + jitter I, .], [y_b^T, 0]] of layers b that share their number of rows,
     built per layer (gpar_logpdf_dense_build) into one buffer and factored in lock-step (gpar_potrf_batch).

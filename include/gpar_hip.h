@@ -179,6 +179,21 @@ int gpar_featurize_dfreq(const gpar_fspec_t* fs, const double* x, int n, int ldx
 int gpar_grad_nacc(void);
 int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, int n, int ldz, int dz, const double* W,
                    int ldw, double* workspace, int nblocks, double* out, void* stream);
+/* One dense layer's training objective AND the ingredients of its gradient in one call (ABI v5):
+ *   out[0] = log N(y; 0, k(x, x) + diag(noise_diag) + jitter I),  out[1] = log det,  out[2 .. 2 + GPAR_GRAD_NACC) = the moment sums of
+ *   1/2 sum_ab W_ab dK_ab/dtheta (as gpar_gram_grad),  half_diag[a] = 1/2 W_aa (the derivative with respect to noise_diag[a]),
+ * with W = alpha alpha^T - (K + D)^-1.  The same launches the separate entry points make, in the same order (same bits):
+ * gpar_featurize (+ gpar_featurize_dfreq when zd is non-null), gpar_gram, the augmented factorisation, gpar_chol_inverse,
+ * gpar_trsm_rln on the row L^-1 y, the rank-1 update of W, gpar_gram_grad.  Workspaces: z (and zd) n x dz (ldz); A (n + 1) x (n + 1);
+ * X and W n x n; alpha n doubles; workspace nblocks * GPAR_GRAD_NACC doubles.  What it removes is the caller's side: a Python host
+ * spends ~1 ms per evaluation on ~30 launches and three synchronisations around them, which IS the evaluation below n ~ 1000 - the
+ * size the reference's own examples train at.
+ * [objective + gradient of one layer inside varz.minimise_l_bfgs_b, gpar/regression.py:434-459] */
+int gpar_logpdf_dense_grad(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, const double* y, long incy,
+                           const double* noise_diag, double jitter, double* z, double* zd, int ldz, double* A, int lda, double* X, int ldxw,
+                           double* W, int ldw, double* alpha, double* workspace, int nblocks, double* out, double* half_diag, int* info,
+                           int potrf_flags, void* stream);
+
 /* The same moment sums of  sum W dK/dtheta  for the other weight shapes the inducing-point (VFE) bound needs
  * [gradient of the PseudoObs elbo, gpar/model.py:226,286-287 under varz's optimiser]:
  *   GPAR_GRAD_SYM   z2 == z1: W symmetric n1 x n1, lower triangle read, sum over all pairs (what gpar_gram_grad does);

@@ -743,3 +743,40 @@ def test_nan_pattern_of_device_outputs_is_remembered_until_they_change(hip):
     y2 = y.copy()
     y2[5, 1] = np.nan
     assert abs(b - float(reg.logpdf(x, y2))) <= 1e-12 * abs(b)
+
+
+@pytest.mark.parametrize("kw,n", [(dict(linear=True, nonlinear=True), 500), (dict(per=True, rq=True, linear=True, nonlinear=True), 300),
+                                  (dict(linear=True, nonlinear=False, input_linear=True), 1300)])
+def test_one_call_objective_and_gradient_return_the_same_bits(monkeypatch, kw, n):
+    """gpar_logpdf_dense_grad (ABI v5): a layer's training objective and the ingredients of its gradient in one library call -
+    the launches of the separate entry points in their order, so value and gradient are bit for bit those of the two-step route
+    (GPAR_ONE_CALL_GRAD_ROWS=0), with weights, periodic features (frequency derivatives) and a whole fit."""
+    import torch
+
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(n, 2, 3, seed=n)
+    w = np.random.default_rng(3).uniform(0.5, 2.0, y.shape)
+
+    def run():
+        out = {}
+        for mode in ["4096", "0"]:
+            monkeypatch.setenv("GPAR_ONE_CALL_GRAD_ROWS", mode)
+            reg = GPARRegressor(scale=0.5, noise=0.1, normalise_y=False, **kw)
+            reg.logpdf(x, y, w)
+            reg.vs.requires_grad(True)
+            value = reg.logpdf(torch.tensor(x), torch.tensor(y), torch.tensor(w))
+            value.backward()
+            out[mode] = (float(value), {k: v.grad.clone().numpy() for k, v in zip(reg.vs.names, reg.vs.get_vars())})
+            reg2 = GPARRegressor(scale=0.5, noise=0.1, **kw)
+            reg2.fit(x, y, w, iters=3)
+            out[mode + "fit"] = reg2.get_variables()
+        monkeypatch.delenv("GPAR_ONE_CALL_GRAD_ROWS")
+        return out
+
+    got = _on("hip", run)
+    assert got["4096"][0] == got["0"][0]
+    for name, g in got["4096"][1].items():
+        assert np.array_equal(g, got["0"][1][name]), name
+    for name, v in got["4096fit"].items():
+        assert np.array_equal(v, got["0fit"][name]), name
