@@ -120,6 +120,91 @@ __device__ __forceinline__ void p2_chunk(const double* __restrict__ Ls, const do
     }
 }
 
+// ---- the look-ahead update of a latency-bound step ------------------------------------------------------------------------
+// C[kend.., kend .. kend + 64 nc) -= P P^T restricted to the next panel's columns (P = the columns [k0, kend) just factored), one
+// 64 x 64 output tile per workgroup: K / 64 chunks of the panel kernel's own product (p2_chunk), operands double-buffered through
+// registers, the C tile arriving behind the last chunk.  In the tail of a factorisation (and throughout a small one) this update
+// has fewer tiles than the chip has slots, and its duration is ONE tile's: 43-100 us in the 128 x 64 GEMM tile (K = 512 in 32
+// dependent stages at one workgroup per compute unit), ~20 us here - on the critical path of every step.  Diagonal tiles store
+// their lower triangle only (the strict upper triangle holds the next panel's hand-off flags).
+struct LaUpdateArgs {
+    double* A;
+    int N, lda, k0, kend, nc;   // nc: 64-column blocks of the next panel
+    long long batch_a;
+};
+
+__global__ __launch_bounds__(256, 2) void potrf_la_update_kernel(LaUpdateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    double* Cs = psm;
+    double* Xs = psm + PNL_TILE;
+    const int nc = a.nc, tri = nc * (nc + 1) / 2;
+    const int tile = blockIdx.x;
+    int ti, tj;
+    if (tile < tri) {   // the top nc x nc block of tiles: lower triangle
+        ti = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+        while (ti * (ti + 1) / 2 > tile) --ti;
+        tj = tile - ti * (ti + 1) / 2;
+    } else {
+        const int r = tile - tri;
+        ti = nc + r / nc;
+        tj = r - (r / nc) * nc;
+    }
+    double* A = a.A + (size_t)blockIdx.y * a.batch_a;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    const int r0 = a.kend + 64 * ti, c0 = a.kend + 64 * tj;
+    const int nchunks = (a.kend - a.k0) / 64;
+    pan_d4 acc[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) acc[mi] = pan_d4{0.0, 0.0, 0.0, 0.0};
+    pan_d2 xa[8], la[8];
+    p2_gload(A, a.lda, a.N, r0, a.k0, t, xa);
+    p2_gload(A, a.lda, a.N, c0, a.k0, t, la);
+    for (int u = 0; u < nchunks; ++u) {
+        __syncthreads();   // the previous chunk's operand reads are done
+        p2_sstore(Cs, t, la);
+        p2_sstore(Xs, t, xa);
+        __syncthreads();
+        p2_gload(A, a.lda, a.N, c0, a.k0 + 64 * min(u + 1, nchunks - 1), t, la);
+        if (u + 1 < nchunks) p2_gload(A, a.lda, a.N, r0, a.k0 + 64 * (u + 1), t, xa);
+        else p2_gload(A, a.lda, a.N, r0, c0, t, xa);   // behind the last chunk: the output tile itself
+        __builtin_amdgcn_sched_barrier(0);
+        p2_chunk(Cs, Xs, acc, w, l15, lk);
+    }
+    __syncthreads();
+    p2_sstore(Xs, t, xa);
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] -= acc[mi][v];
+    __syncthreads();
+    if (ti != tj) {
+        p2_gstore(A, a.lda, a.N, r0, c0, Xs, t, false);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = t + 256 * q;
+            const int r = c >> 5, cc = (c & 31) * 2;
+            if (r0 + r < a.N && cc <= r) {
+                double* dst = A + (size_t)(r0 + r) * a.lda + c0 + cc;
+                if (cc + 1 <= r) *reinterpret_cast<pan_d2*>(dst) = *reinterpret_cast<const pan_d2*>(Xs + r * PNL_LD + cc);
+                else dst[0] = Xs[r * PNL_LD + cc];
+            }
+        }
+    }
+}
+
+static int potrf_la_update_small(double* A, int N, int lda, int k0, int kend, int ncols, hipStream_t stream, int batch, long long batch_a) {
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_la_update_kernel), P2_LDS_BYTES));
+    const int nc = ncols / 64, tr = (N - kend + 63) / 64;
+    const int tiles = nc * (nc + 1) / 2 + (tr - nc) * nc;
+    LaUpdateArgs a{A, N, lda, k0, kend, nc, batch_a};
+    hipLaunchKernelGGL(potrf_la_update_kernel, dim3(tiles, batch), dim3(256), P2_LDS_BYTES, stream, a);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
 // Position of W_jb (inverse of the jb-th diagonal 16 x 16 block) inside the strictly upper 16 x 16 blocks of the LDS tile.
 __device__ __forceinline__ int p2_wblock(int jb) {
     // jb: 0 -> block (0, 2), 1 -> (0, 3), 2 -> (1, 2), 3 -> (1, 3): columns >= 32, clear of the progress words that the

@@ -391,6 +391,29 @@ static int potrf_gemm_update(const PotrfCtx& c, int k0, int kend, int col_end, h
                        GPAR_GEMM_C_LOWER, stream, role, c.batch, c.batch_a, c.batch_a, c.batch_a);
 }
 
+static int potrf_la_update_small(double* A, int N, int lda, int k0, int kend, int ncols, hipStream_t stream, int batch, long long batch_a);   // panel2.h
+
+// Does the update of the NEXT panel's columns [kend, la_end) take the one-tile-per-workgroup kernel (panel2.h) instead of the GEMM?
+// While it has at most GPAR_POTRF_LA_SMALL_TILES 64 x 64 tiles over the whole batch: then its duration is one tile's, and the
+// small kernel's tile is several times shorter.  The rule looks at the geometry only - never at the look-ahead setting - so that a
+// factorisation returns the same bits with and without look-ahead (potrf_run splits its single update accordingly).
+static bool potrf_la_is_small(const PotrfCtx& c, int k0, int kend, int la_end) {
+    const int cols = la_end - kend, K = kend - k0;
+    if (cols <= 0 || cols % 64 != 0 || K <= 0 || K % 64 != 0 || (c.lda & 1) || !gpar_aligned16(c.A) || (c.batch_a & 1) || (k0 & 1) || c.N - kend <= POTRF_SMALL_ROWS)
+        return false;
+    if (env_int("GPAR_PANEL_V", 2) < 2) return false;
+    const int nc = cols / 64, tr = (c.N - kend + 63) / 64;
+    if (tr < nc) return false;
+    const long long tiles = ((long long)nc * (nc + 1) / 2 + (long long)(tr - nc) * nc) * c.batch;
+    return tiles <= env_int("GPAR_POTRF_LA_SMALL_TILES", 512);
+}
+
+// The update of the next panel's columns by whichever kernel the rule picks.
+static int potrf_la_update(const PotrfCtx& c, int k0, int kend, int la_end, hipStream_t stream) {
+    if (potrf_la_is_small(c, k0, kend, la_end)) return potrf_la_update_small(c.A, c.N, c.lda, k0, kend, la_end - kend, stream, c.batch, c.batch_a);
+    return potrf_gemm_update(c, k0, kend, la_end, stream, 1);
+}
+
 // Factor columns [c0, c1) (already up to date with respect to all columns < c0): on exit rows c0..N of those
 // columns hold L.  Recursive right-looking restricted to the panel: widths nb(level) -> ... -> 64.
 static int potrf_panel(const PotrfCtx& c, int c0, int c1, int nb, hipStream_t stream) {
@@ -442,6 +465,7 @@ static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* 
                               int batch = 1, long long batch_a = 0);
 static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
                              hipStream_t stream);
+static int potrf_la_update_small(double* A, int N, int lda, int k0, int kend, int ncols, hipStream_t stream, int batch, long long batch_a);
 static int env_int(const char* name, int dflt);
 static int trinv_blocks_fused2(const double* L, int n, int ldl, double* X, int ldx, int S, hipStream_t stream);
 static int trsm_block_back_fused2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, hipStream_t stream);
@@ -644,6 +668,20 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         if (!la || kend >= nf) {
             // no further panel to overlap with (or look-ahead off): one update of everything that is left
             if (la && trail_done) { GPAR_HIP_TRY(hipStreamWaitEvent(stream, trail_done, 0)); trail_done = nullptr; }
+            if (kend < nf && next_end < N && potrf_la_is_small(c, k0, kend, next_end)) {
+                // (the same split the look-ahead schedule makes, so that both produce the same bits: the next panel's columns by the
+                // small kernel, everything to their right by the GEMM)
+                rc = potrf_la_update(c, k0, kend, next_end, stream);
+                if (!rc) {
+                    const double* P = A + (size_t)next_end * lda + k0;
+                    prof_begin(stream, pa);
+                    rc = gemm_launch(0, 1, N - next_end, N - next_end, kend - k0, -1.0, P, lda, P, lda, 1.0, A + (size_t)next_end * lda + next_end, lda,
+                                     GPAR_GEMM_C_LOWER, stream, 1, batch, batch_a, batch_a, batch_a);
+                    prof_end(stream, pa, N - next_end, N - next_end, (kend - k0) * batch);
+                }
+                if (rc) return rc;
+                continue;
+            }
             prof_begin(stream, pa);
             rc = potrf_gemm_update(c, k0, kend, N, stream, 1);
             prof_end(stream, pa, N - kend, N - kend, (kend - k0) * batch);
@@ -665,9 +703,13 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         const bool rest_after_la = (N - kend) < env_int(batch == 1 ? "GPAR_POTRF_REST_AFTER_LA" : "GPAR_POTRF_BATCH_REST_AFTER_LA", 0);
         hipEvent_t panel_done = la_event();
         if (!rest_after_la) GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
-        prof_begin(stream, pa);
-        rc = potrf_gemm_update(c, k0, kend, la_end, stream, 1);   // same kernel symbol: it is part of the trailing update
-        prof_end(stream, pa, N - kend, la_end - kend, (kend - k0) * batch);
+        if (potrf_la_is_small(c, k0, kend, la_end)) {
+            rc = potrf_la_update(c, k0, kend, la_end, stream);
+        } else {
+            prof_begin(stream, pa);
+            rc = potrf_gemm_update(c, k0, kend, la_end, stream, 1);   // same kernel symbol: it is part of the trailing update
+            prof_end(stream, pa, N - kend, la_end - kend, (kend - k0) * batch);
+        }
         if (rc) return rc;
         if (rest_after_la) GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
         // (2) everything to the right of the next panel, on the side stream: first the rest of the next group's columns ...

@@ -43,6 +43,8 @@ CALL_TIME = [
     ("GPAR_POTRF_BATCH_LOOKAHEAD", "0"),
     ("GPAR_POTRF_PREZERO", "0"),
     ("GPAR_POTRF_SMALL_UPDATE", "0"),
+    ("GPAR_POTRF_LA_SMALL_TILES", "0"),
+    ("GPAR_POTRF_LA_SMALL_TILES", "100000"),
     ("GPAR_ONE_CALL", "0"),
     ("GPAR_LOCKSTEP_FUSED_BUILD_ROWS", "0"),
     ("GPAR_POTRF_BATCH_REST_AFTER_LA", "100000"),
