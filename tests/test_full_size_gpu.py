@@ -171,7 +171,9 @@ def test_inducing_point_bound_order_is_chosen_on_the_device(hip, monkeypatch, di
         assert auto[0] == solved[0] and np.array_equal(auto[1], solved[1])
     else:
         assert auto[0] != solved[0]   # (the other order did run)
-        assert abs(auto[0] - solved[0]) <= 2e-10 * abs(solved[0]), (auto[0], solved[0])   # what the product-first order costs at this size
+        # what the product-first order costs at this size: ~cond(K_zz) digits (profiles/r04_vfe_routes.txt; the 10th digit also moves
+        # with any change of rounding upstream - the reason it is opt-in)
+        assert abs(auto[0] - solved[0]) <= 1e-9 * abs(solved[0]), (auto[0], solved[0])
         np.testing.assert_allclose(auto[1], solved[1], rtol=1e-6, atol=1e-7)
     # training differentiates the solved cross-Gram whatever the value path chose
     reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False, x_ind=z)

@@ -4,6 +4,8 @@ Tolerances (fp64): GEMM-type results are compared with rtol 1e-12 scaled by the 
 (different summation order than numpy's BLAS); Cholesky factors / solves of well-conditioned matrices with
 rtol 1e-10; Philox uniforms are bit-exact so normals agree to ~1e-14.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.linalg
@@ -921,3 +923,38 @@ def test_many_row_solves_against_an_ill_conditioned_factor_are_backward_stable(n
         scale = (np.abs(Xh) @ np.abs(L).sum(axis=0 if solve is H.trsm_rlt_ else 1)) + np.abs(rhs).max(axis=1)
         assert np.isfinite(Xh).all()
         assert (resid <= 1e-13 * scale).all(), float((resid / scale).max())
+
+
+def test_build_time_archive_serves_mid_size_training_without_a_compilation(env):
+    """A fit at n = 1100 (2^20 weight entries: above the archive's floor of 2^19, far below the run-time compilation thresholds)
+    loads its Gram and gradient kernels from gpar_aot_gfx950.bin: the archive reports entries and loads, hiprtc compiles nothing."""
+    import ctypes
+
+    torch, hip, dev, to_dev = env
+    from gpar_amd import _lib
+    from gpar_amd.engine import HipEngine, set_engine
+    from gpar_amd.regression import GPARRegressor
+
+    lib = _lib.load()
+    before = [ctypes.c_int(), ctypes.c_int(), ctypes.c_int()]
+    lib.gpar_jit_stats(*[ctypes.byref(c) for c in before])
+    loaded0 = ctypes.c_int()
+    lib.gpar_aot_stats(None, ctypes.byref(loaded0))
+    previous = set_engine(HipEngine(device="cuda:0", seed=2))
+    try:
+        rng = np.random.default_rng(5)
+        x = rng.uniform(0, 1, (1100, 2))
+        y = np.stack([np.sin(5 * x[:, 0]), np.cos(4 * x[:, 1]) + x[:, 0]], axis=1) + 0.1 * rng.standard_normal((1100, 2))
+        reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1)
+        reg.fit(x, y, iters=2)
+    finally:
+        set_engine(previous)
+    after = [ctypes.c_int(), ctypes.c_int(), ctypes.c_int()]
+    lib.gpar_jit_stats(*[ctypes.byref(c) for c in after])
+    entries, loaded = ctypes.c_int(), ctypes.c_int()
+    lib.gpar_aot_stats(ctypes.byref(entries), ctypes.byref(loaded))
+    if os.environ.get("GPAR_AOT", "1") == "0" or entries.value == 0:
+        pytest.skip("no kernel archive next to the library")
+    assert entries.value >= 300
+    assert after[0].value == before[0].value, "hiprtc compiled a kernel the archive should hold"
+    assert loaded.value > loaded0.value or after[2].value > 0   # (loaded now, or already cached by an earlier test of this process)
