@@ -517,7 +517,7 @@ int gpar_logpdf_lockstep(const gpar_layer_t* layers, int batch, const double* x,
         if (!layers[b].fs || !layers[b].ks || layers[b].y_col < 0) return GPAR_ARG_ERROR(2);
     // Small evaluations: ONE launch per LS_CHUNK layers builds everything (gram.h: lockstep_build_kernel; same bits as the launches
     // below) - when every feature map fits its compact form and the build is short enough for launch latency to matter.
-    bool fused_build = n > 0 && n <= env_int("GPAR_LOCKSTEP_FUSED_BUILD_ROWS", 2048) && w != nullptr;
+    bool fused_build = n > 0 && n <= env_int("GPAR_LOCKSTEP_FUSED_BUILD_ROWS", 4096) && w != nullptr;
     for (int b = 0; b < batch && fused_build; ++b) {
         const gpar_fspec_t& fs = *layers[b].fs;
         if (fs.dz < 0 || fs.dz > LS_MAXDZ) fused_build = false;
