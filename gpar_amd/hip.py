@@ -6,6 +6,7 @@ stride (`stride(1) == 1`); the leading dimension is `stride(0)`.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -415,6 +416,12 @@ def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, c_lower=False,
     if k != kb:
         raise ValueError(f"inner dimensions differ: {k} vs {kb}")
     if out is None:
+        if (n == 1 and tb and not ta and beta == 0.0 and not (c_lower or a_lower or k_from_row or k_to_col) and B.dim() == 2 and m > 0
+                and os.environ.get("GPAR_GEMV", "1") != "0"):
+            # one column: a matrix-vector product (gpar_gemv: one wave per row) instead of 128-wide tiles with one live column
+            y = torch.empty(m, 1, dtype=torch.float64, device=A.device)
+            _lib.check(lib.gpar_gemv(A.data_ptr(), m, k, _ld(A), B.data_ptr(), 1, float(alpha), y.data_ptr(), 1, stream_ptr(A.device)), "gpar_gemv")
+            return y
         out = alloc_matrix(m, n, A.device)
         if beta != 0.0:
             raise ValueError("beta != 0 needs an `out`")

@@ -367,6 +367,9 @@ int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, 
  * is not read).  [the chol(cov) * z product of Normal.sample for a single draw; a 128-wide GEMM tile for one column is
  * all latency] */
 int gpar_trmv_lower(const double* L, int n, int ldl, const double* x, int incx, double* y, int incy, void* stream);
+/* y[i*incy] = alpha * sum_j A[i][j] * x[j*incx], i < rows: a general row-major matrix times ONE vector (ABI v5; one wave per row).
+ * [posterior means K(x*, X) alpha and K(x*, Z) v: gpar/model.py:298-301 - matrix-vector products that a 128-wide GEMM tile serves badly] */
+int gpar_gemv(const double* A, int rows, int cols, int lda, const double* x, int incx, double alpha, double* y, int incy, void* stream);
 /* The same for `batch` lower-triangular matrices with one vector each, in one launch: y_b = L_b x_b (+ add_b if add is non-null),
  * matrix / vector b at L + b * stride_l, x + b * stride_x, add + b * stride_add, y + b * stride_y (elements).  [the draws of all
  * posterior samples of a layer: mean_s + chol(cov_s) z_s, gpar/regression.py:559-563] */

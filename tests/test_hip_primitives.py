@@ -68,6 +68,21 @@ def test_gemm(env, ta, tb, mnk, pad):
     assert np.all(np.abs(dC2.cpu().numpy() - opA @ opB) <= 1e-13 * scale)
 
 
+@pytest.mark.parametrize("m,k", [(1, 1), (5, 3), (300, 1000), (1024, 1024), (2050, 70), (7, 5000)])
+def test_single_column_product_is_a_matrix_vector_pass(env, m, k, monkeypatch):
+    """gemm(A, v, tb=True) with a one-row v: gpar_gemv (one wave per row); the tile path (GPAR_GEMV=0) agrees to rounding."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(m + k)
+    A, v = rng.standard_normal((m, k)), rng.standard_normal((1, k))
+    got = hip.gemm(to_dev(A), to_dev(v), tb=True, alpha=-1.5).cpu().numpy()
+    want = -1.5 * (A @ v.T)
+    scale = np.abs(A) @ np.abs(v.T) + 1e-300
+    assert got.shape == (m, 1) and np.max(np.abs(got - want) / scale) < 1e-14
+    monkeypatch.setenv("GPAR_GEMV", "0")
+    tiles = hip.gemm(to_dev(A), to_dev(v), tb=True, alpha=-1.5).cpu().numpy()
+    assert np.max(np.abs(tiles - want) / scale) < 1e-14
+
+
 def test_gemm_asymmetric_identity(env):
     # A = I against an asymmetric B catches transposed / permuted output maps
     torch, hip, dev, to_dev = env
