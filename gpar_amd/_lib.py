@@ -141,6 +141,8 @@ SIGNATURES = {
     "gpar_potrf_ex": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr]),
     "gpar_trsm_rlt": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),
     "gpar_trsm_rlt_if": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
+    "gpar_vfe_assemble": (_c_int, [_ptr, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_int, _c_dbl, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr]),
+    "gpar_vfe_value": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
     "gpar_chol_spread": (_c_int, [_ptr, _c_int, _c_int, _c_dbl, _ptr, _ptr, _ptr]),
     "gpar_trsm_rln": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _c_int, _ptr]),
     "gpar_chol_inverse": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr]),

@@ -309,6 +309,55 @@ __global__ __launch_bounds__(256) void half_diag_kernel(const double* __restrict
     if (i < n) out[i] = 0.5 * W[(size_t)i * ldw + i];
 }
 
+// ---- the scalar side of the inducing-point bound (gpar_vfe_assemble / gpar_vfe_value) ------------------------------------------
+// A <- [[G + diag_add I (lower triangle), .], [c^T, 0]], log-determinant and info words zeroed: one launch instead of six tensor operations
+__global__ __launch_bounds__(256) void vfe_assemble_kernel(const double* __restrict__ G, int M, int ldg, const double* __restrict__ c, double diag_add,
+                                                           double* __restrict__ A, int lda, double* __restrict__ logdet, int* __restrict__ info) {
+    const int r = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (r < M) {
+        if (j <= r) A[(size_t)r * lda + j] = G[(size_t)r * ldg + j] + (j == r ? diag_add : 0.0);
+    } else {
+        if (j < M) A[(size_t)M * lda + j] = c[j];
+        if (j == M) {
+            A[(size_t)M * lda + M] = 0.0;
+            logdet[0] = 0.0;
+            info[0] = 0;
+        }
+    }
+}
+// scal[0] = sum ys^2, [1] = sum kdiag / d, [2] = sum log d  (n terms each), [3] = tr G  (M terms): one workgroup, fixed order
+__global__ __launch_bounds__(1024) void vfe_sums_kernel(const double* __restrict__ ys, const double* __restrict__ kdiag, const double* __restrict__ d, int n,
+                                                        const double* __restrict__ G, int M, int ldg, double* __restrict__ scal) {
+    __shared__ double sm[4][1024];
+    const int t = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int i = t; i < n; i += 1024) {
+        const double y = ys[i], di = d[i];
+        a0 = fma(y, y, a0);
+        a1 += kdiag[i] / di;
+        a2 += log(di);
+    }
+    for (int i = t; i < M; i += 1024) a3 += G[(size_t)i * ldg + i];
+    sm[0][t] = a0; sm[1][t] = a1; sm[2][t] = a2; sm[3][t] = a3;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (t < off) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sm[q][t] += sm[q][t + off];
+        }
+        __syncthreads();
+    }
+    if (t < 4) scal[t] = sm[t][0];
+}
+// the bound from its pieces: -1/2 (trace + sum log d + n log 2 pi + log|A| + y^T D^-1 y - |L_A^-1 c|^2)
+__global__ void vfe_value_kernel(const double* __restrict__ scal, const double* __restrict__ logdet, const double* __restrict__ A, int lda, int M,
+                                 double n_log_2pi, int with_trace, double* __restrict__ out) {
+    const double quad = -A[(size_t)M * lda + M];
+    const double trace = with_trace ? scal[1] - scal[3] : 0.0;
+    out[0] = -0.5 * (trace + scal[2] + n_log_2pi + logdet[0] + scal[0] - quad);
+}
+
 extern "C" {
 
 int gpar_abi_version(void) { return GPAR_ABI_VERSION; }
@@ -757,6 +806,26 @@ int gpar_trsm_rlt_if(const double* L, int n, int ldl, double* B, int nrows, int 
     g_pred.flag = nullptr;
     g_pred.sense = 0;
     return rc;
+}
+
+int gpar_vfe_assemble(const double* G, int M, int ldg, const double* c, const double* ys, const double* kdiag, const double* d, int n,
+                      double diag_add, double* A, int lda, double* scal, double* logdet, int* info, void* stream) {
+    GPAR_API_GUARD;
+    if (M <= 0 || n < 0) return 0;
+    if (!G || !c || !A || !scal || !logdet || !info || (n > 0 && (!ys || !kdiag || !d))) return GPAR_ARG_ERROR(1);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(vfe_assemble_kernel, dim3(gpar_ceil_div(M + 1, 256), M + 1), dim3(256), 0, st, G, M, ldg, c, diag_add, A, lda, logdet, info);
+    hipLaunchKernelGGL(vfe_sums_kernel, dim3(1), dim3(1024), 0, st, ys, kdiag, d, n, G, M, ldg, scal);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gpar_vfe_value(const double* scal, const double* logdet, const double* A, int lda, int M, int n, int with_trace, double* out, void* stream) {
+    GPAR_API_GUARD;
+    if (!scal || !logdet || !A || !out) return GPAR_ARG_ERROR(1);
+    hipLaunchKernelGGL(vfe_value_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scal, logdet, A, lda, M, (double)n * 1.8378770664093453, with_trace, out);
+    GPAR_LAUNCH_CHECK();
+    return 0;
 }
 
 int gpar_chol_spread(const double* L, int n, int ldl, double limit, double* spread, int* flag, void* stream) {

@@ -271,6 +271,11 @@ class HipEngine:
     def trsm_rlt_(self, L, B, when=None):
         return hip.trsm_rlt_(L, B, when=when)
 
+    def vfe_factor(self, G, c, ys, kdiag, d, with_trace):
+        """chol of A = I + G with the row c appended and the inducing-point bound, the scalar side in two launches (hip.vfe_factor)."""
+        safe = getattr(self._tls, "safe", False)
+        return hip.vfe_factor(G, c, ys, kdiag, d, 1.0, with_trace, lookahead=not safe and getattr(self._tls, "pipe_depth", 0) < 3, fused=not safe)
+
     def chol_spread(self, L, limit):
         return hip.chol_spread(L, limit)
 

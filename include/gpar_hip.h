@@ -303,6 +303,15 @@ int gpar_trsm_rlt(const double* L, int n, int ldl, double* B, int nrows, int ldb
  *  L_z says that this is harmless - each of the two orders is predicated on the same word, one of them runs.] */
 int gpar_trsm_rlt_if(const double* L, int n, int ldl, double* B, int nrows, int ldb, const int* flag, int run_if, void* stream);
 int gpar_chol_spread(const double* L, int n, int ldl, double limit, double* spread, int* flag, void* stream);
+/* The scalar side of the inducing-point bound in two calls instead of ~25 tensor operations per layer (ABI v5):
+ *   gpar_vfe_assemble  A <- [[G + diag_add I, .], [c^T, 0]] ((M + 1) x (M + 1): what gpar_potrf factors next; lower triangle of G read),
+ *                      logdet / info zeroed, scal[0..3] <- sum ys^2, sum kdiag / d, sum log d (n terms, fixed order), tr G;
+ *   gpar_vfe_value     out[0] <- -1/2 (with_trace (scal[1] - scal[3]) + scal[2] + n log 2 pi + logdet + scal[0] + A[M][M]) once A is factored
+ *                      (its corner then holds -|L_A^-1 c|^2).
+ * [the elbo of stheno's PseudoObs, gpar/model.py:226 with :286-287: trace term, log-determinants and quadratic form] */
+int gpar_vfe_assemble(const double* G, int M, int ldg, const double* c, const double* ys, const double* kdiag, const double* d, int n,
+                      double diag_add, double* A, int lda, double* scal, double* logdet, int* info, void* stream);
+int gpar_vfe_value(const double* scal, const double* logdet, const double* A, int lda, int M, int n, int with_trace, double* out, void* stream);
 /* B <- B L^-1  (right side, lower, not transposed: backward substitution on the rows of B). */
 int gpar_trsm_rln(const double* L, int n, int ldl, double* B, int nrows, int ldb, void* stream);
 

@@ -51,6 +51,7 @@ CALL_TIME = [
     ("GPAR_VFE_SPREAD_MAX", "1e3"),
     ("GPAR_LINEAR_TAIL", "0"),
     ("GPAR_GEMV", "0"),
+    ("GPAR_VFE_FUSED_SCALARS", "0"),
     ("GPAR_ONE_CALL_GRAD_ROWS", "0"),
     ("GPAR_FIT_THREADS", "1"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "0"),
