@@ -326,36 +326,43 @@ __global__ __launch_bounds__(256) void vfe_assemble_kernel(const double* __restr
         }
     }
 }
-// scal[0] = sum ys^2, [1] = sum kdiag / d, [2] = sum log d  (n terms each), [3] = tr G  (M terms): one workgroup, fixed order
-__global__ __launch_bounds__(1024) void vfe_sums_kernel(const double* __restrict__ ys, const double* __restrict__ kdiag, const double* __restrict__ d, int n,
-                                                        const double* __restrict__ G, int M, int ldg, double* __restrict__ scal) {
-    __shared__ double sm[4][1024];
-    const int t = threadIdx.x;
+// Partial sums of  ys^2, kdiag / d, log d  (n terms each) and of the diagonal of G (M terms): VFE_PARTS workgroups, block b writes
+// scal[4 b .. 4 b + 3]; vfe_value_kernel adds the parts in order (a fixed summation order; one workgroup over 65536 terms with a
+// logarithm and a division each took 67 us)
+constexpr int VFE_PARTS = 64;
+__global__ __launch_bounds__(256) void vfe_sums_kernel(const double* __restrict__ ys, const double* __restrict__ kdiag, const double* __restrict__ d, int n,
+                                                       const double* __restrict__ G, int M, int ldg, double* __restrict__ scal) {
+    __shared__ double sm[4][256];
+    const int t = threadIdx.x, b = blockIdx.x;
+    const int per_n = (n + VFE_PARTS - 1) / VFE_PARTS, per_m = (M + VFE_PARTS - 1) / VFE_PARTS;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int i = t; i < n; i += 1024) {
+    for (int i = b * per_n + t; i < min(n, (b + 1) * per_n); i += 256) {
         const double y = ys[i], di = d[i];
         a0 = fma(y, y, a0);
         a1 += kdiag[i] / di;
         a2 += log(di);
     }
-    for (int i = t; i < M; i += 1024) a3 += G[(size_t)i * ldg + i];
+    for (int i = b * per_m + t; i < min(M, (b + 1) * per_m); i += 256) a3 += G[(size_t)i * ldg + i];
     sm[0][t] = a0; sm[1][t] = a1; sm[2][t] = a2; sm[3][t] = a3;
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
+    for (int off = 128; off > 0; off >>= 1) {
         if (t < off) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) sm[q][t] += sm[q][t + off];
         }
         __syncthreads();
     }
-    if (t < 4) scal[t] = sm[t][0];
+    if (t < 4) scal[4 * b + t] = sm[t][0];
 }
 // the bound from its pieces: -1/2 (trace + sum log d + n log 2 pi + log|A| + y^T D^-1 y - |L_A^-1 c|^2)
 __global__ void vfe_value_kernel(const double* __restrict__ scal, const double* __restrict__ logdet, const double* __restrict__ A, int lda, int M,
                                  double n_log_2pi, int with_trace, double* __restrict__ out) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < VFE_PARTS; ++b)
+        for (int q = 0; q < 4; ++q) s[q] += scal[4 * b + q];
     const double quad = -A[(size_t)M * lda + M];
-    const double trace = with_trace ? scal[1] - scal[3] : 0.0;
-    out[0] = -0.5 * (trace + scal[2] + n_log_2pi + logdet[0] + scal[0] - quad);
+    const double trace = with_trace ? s[1] - s[3] : 0.0;
+    out[0] = -0.5 * (trace + s[2] + n_log_2pi + logdet[0] + s[0] - quad);
 }
 
 extern "C" {
@@ -815,7 +822,7 @@ int gpar_vfe_assemble(const double* G, int M, int ldg, const double* c, const do
     if (!G || !c || !A || !scal || !logdet || !info || (n > 0 && (!ys || !kdiag || !d))) return GPAR_ARG_ERROR(1);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(vfe_assemble_kernel, dim3(gpar_ceil_div(M + 1, 256), M + 1), dim3(256), 0, st, G, M, ldg, c, diag_add, A, lda, logdet, info);
-    hipLaunchKernelGGL(vfe_sums_kernel, dim3(1), dim3(1024), 0, st, ys, kdiag, d, n, G, M, ldg, scal);
+    hipLaunchKernelGGL(vfe_sums_kernel, dim3(VFE_PARTS), dim3(256), 0, st, ys, kdiag, d, n, G, M, ldg, scal);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

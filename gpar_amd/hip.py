@@ -389,16 +389,16 @@ def vfe_factor(G, c, ys, kdiag, d, diag_add, with_trace, lookahead=True, fused=T
     M, n, dev = G.shape[0], ys.numel(), G.device
     c, ys, kdiag, d = (t.reshape(-1).contiguous() for t in (c, ys, kdiag, d))
     A = alloc_matrix(M + 1, M + 1, dev)
-    words = torch.empty(6, dtype=torch.float64, device=dev)   # 4 sums, logdet, bound
+    words = torch.empty(258, dtype=torch.float64, device=dev)   # logdet, bound, then 64 x 4 partial sums
     info = torch.empty(1, dtype=torch.int32, device=dev)
     st = stream_ptr(dev)
     _lib.check(lib.gpar_vfe_assemble(G.data_ptr(), M, _ld(G), c.data_ptr(), ys.data_ptr(), kdiag.data_ptr(), d.data_ptr(), n, float(diag_add),
-                                     A.data_ptr(), _ld(A), words.data_ptr(), words[4:].data_ptr(), info.data_ptr(), st), "gpar_vfe_assemble")
+                                     A.data_ptr(), _ld(A), words[2:].data_ptr(), words.data_ptr(), info.data_ptr(), st), "gpar_vfe_assemble")
     flags = (0 if lookahead else _lib.POTRF_NO_LOOKAHEAD) | (0 if fused else _lib.POTRF_UNFUSED)
-    _lib.check(lib.gpar_potrf_ex(A.data_ptr(), M + 1, M, _ld(A), words[4:].data_ptr(), info.data_ptr(), flags, st), "gpar_potrf_ex")
-    _lib.check(lib.gpar_vfe_value(words.data_ptr(), words[4:].data_ptr(), A.data_ptr(), _ld(A), M, n, int(bool(with_trace)), words[5:].data_ptr(), st),
+    _lib.check(lib.gpar_potrf_ex(A.data_ptr(), M + 1, M, _ld(A), words.data_ptr(), info.data_ptr(), flags, st), "gpar_potrf_ex")
+    _lib.check(lib.gpar_vfe_value(words[2:].data_ptr(), words.data_ptr(), A.data_ptr(), _ld(A), M, n, int(bool(with_trace)), words[1:].data_ptr(), st),
                "gpar_vfe_value")
-    return A, words[4:5], info, words[5]
+    return A, words[0:1], info, words[1]
 
 
 def chol_spread(L, limit):

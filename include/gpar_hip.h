@@ -305,9 +305,9 @@ int gpar_trsm_rlt_if(const double* L, int n, int ldl, double* B, int nrows, int 
 int gpar_chol_spread(const double* L, int n, int ldl, double limit, double* spread, int* flag, void* stream);
 /* The scalar side of the inducing-point bound in two calls instead of ~25 tensor operations per layer (ABI v5):
  *   gpar_vfe_assemble  A <- [[G + diag_add I, .], [c^T, 0]] ((M + 1) x (M + 1): what gpar_potrf factors next; lower triangle of G read),
- *                      logdet / info zeroed, scal[0..3] <- sum ys^2, sum kdiag / d, sum log d (n terms, fixed order), tr G;
- *   gpar_vfe_value     out[0] <- -1/2 (with_trace (scal[1] - scal[3]) + scal[2] + n log 2 pi + logdet + scal[0] + A[M][M]) once A is factored
- *                      (its corner then holds -|L_A^-1 c|^2).
+ *                      logdet / info zeroed, scal (256 doubles: 64 partial sums of each) <- sum ys^2, sum kdiag / d, sum log d (n terms), tr G;
+ *   gpar_vfe_value     out[0] <- -1/2 (with_trace (S1 - S3) + S2 + n log 2 pi + logdet + S0 + A[M][M]) once A is factored (its corner then
+ *                      holds -|L_A^-1 c|^2), S_q the sums of the parts in order.
  * [the elbo of stheno's PseudoObs, gpar/model.py:226 with :286-287: trace term, log-determinants and quadratic form] */
 int gpar_vfe_assemble(const double* G, int M, int ldg, const double* c, const double* ys, const double* kdiag, const double* d, int n,
                       double diag_add, double* A, int lda, double* scal, double* logdet, int* info, void* stream);
