@@ -358,13 +358,13 @@ struct PotrfCtx {
 // likelihood, whose corner becomes -|L^-1 y|^2 - one wave per stored element (i, j), j <= i: lanes stride K, butterfly sum.
 // A 64 x 64 tile of the GEMM kernel for ONE element is all latency (42 us per evaluation at every size; this: ~4 us).
 constexpr int POTRF_SMALL_ROWS = 16;
-__global__ __launch_bounds__(64) void potrf_small_update_kernel(double* __restrict__ A, int lda, int kend, int k0, int rows, int cols, long long batch_a) {
+// (org: first row / column of the updated block; the K columns [k0, k0 + K) of its rows are the operand)
+__global__ __launch_bounds__(64) void potrf_small_update_kernel(double* __restrict__ A, int lda, int org, int k0, int K, int rows, int cols, long long batch_a) {
     const int i = blockIdx.x / cols, j = blockIdx.x - i * cols;
     if (j > i) return;
     A += (size_t)blockIdx.y * batch_a;
-    const double* Pi = A + (size_t)(kend + i) * lda + k0;
-    const double* Pj = A + (size_t)(kend + j) * lda + k0;
-    const int K = kend - k0;
+    const double* Pi = A + (size_t)(org + i) * lda + k0;
+    const double* Pj = A + (size_t)(org + j) * lda + k0;
     double a0 = 0.0, a1 = 0.0;
     int k = threadIdx.x;
     for (; k + 64 < K; k += 128) {
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64) void potrf_small_update_kernel(double* __restri
     double s = a0 + a1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (threadIdx.x == 0) A[(size_t)(kend + i) * lda + kend + j] -= s;
+    if (threadIdx.x == 0) A[(size_t)(org + i) * lda + org + j] -= s;
 }
 
 static int potrf_gemm_update(const PotrfCtx& c, int k0, int kend, int col_end, hipStream_t stream, int role = 0) {
@@ -383,7 +383,7 @@ static int potrf_gemm_update(const PotrfCtx& c, int k0, int kend, int col_end, h
     const int rows = c.N - kend, cols = col_end - kend;
     if (rows <= 0 || cols <= 0) return 0;
     if (rows <= POTRF_SMALL_ROWS && env_int("GPAR_POTRF_SMALL_UPDATE", 1)) {
-        hipLaunchKernelGGL(potrf_small_update_kernel, dim3(rows * cols, c.batch), dim3(64), 0, stream, c.A, c.lda, kend, k0, rows, cols, c.batch_a);
+        hipLaunchKernelGGL(potrf_small_update_kernel, dim3(rows * cols, c.batch), dim3(64), 0, stream, c.A, c.lda, kend, k0, kend - k0, rows, cols, c.batch_a);
         return 0;
     }
     const double* P = c.A + (size_t)kend * c.lda + k0;
@@ -412,6 +412,20 @@ static bool potrf_la_is_small(const PotrfCtx& c, int k0, int kend, int la_end) {
 static int potrf_la_update(const PotrfCtx& c, int k0, int kend, int la_end, hipStream_t stream) {
     if (potrf_la_is_small(c, k0, kend, la_end)) return potrf_la_update_small(c.A, c.N, c.lda, k0, kend, la_end - kend, stream, c.batch, c.batch_a);
     return potrf_gemm_update(c, k0, kend, la_end, stream, 1);
+}
+
+// Everything to the right of the next step's columns: A[from:N, from:N] -= P P^T (lower), P = A[from:N, k0:kend).  A handful of rows
+// (the augmented row once the last panel is next) by the one-wave kernel, else the batched GEMM.
+static int potrf_rest_update(const PotrfCtx& c, int k0, int kend, int from, hipStream_t stream) {
+    const int rows = c.N - from;
+    if (rows <= 0) return 0;
+    if (rows <= POTRF_SMALL_ROWS && env_int("GPAR_POTRF_SMALL_UPDATE", 1)) {
+        hipLaunchKernelGGL(potrf_small_update_kernel, dim3(rows * rows, c.batch), dim3(64), 0, stream, c.A, c.lda, from, k0, kend - k0, rows, rows, c.batch_a);
+        return 0;
+    }
+    const double* P = c.A + (size_t)from * c.lda + k0;
+    return gemm_launch(0, 1, rows, rows, kend - k0, -1.0, P, c.lda, P, c.lda, 1.0, c.A + (size_t)from * c.lda + from, c.lda, GPAR_GEMM_C_LOWER, stream, 1,
+                       c.batch, c.batch_a, c.batch_a, c.batch_a);
 }
 
 // Factor columns [c0, c1) (already up to date with respect to all columns < c0): on exit rows c0..N of those
@@ -668,15 +682,13 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         if (!la || kend >= nf) {
             // no further panel to overlap with (or look-ahead off): one update of everything that is left
             if (la && trail_done) { GPAR_HIP_TRY(hipStreamWaitEvent(stream, trail_done, 0)); trail_done = nullptr; }
-            if (kend < nf && next_end < N && potrf_la_is_small(c, k0, kend, next_end)) {
+            if (kend < nf && next_end <= N && potrf_la_is_small(c, k0, kend, next_end)) {
                 // (the same split the look-ahead schedule makes, so that both produce the same bits: the next panel's columns by the
                 // small kernel, everything to their right by the GEMM)
                 rc = potrf_la_update(c, k0, kend, next_end, stream);
                 if (!rc) {
-                    const double* P = A + (size_t)next_end * lda + k0;
                     prof_begin(stream, pa);
-                    rc = gemm_launch(0, 1, N - next_end, N - next_end, kend - k0, -1.0, P, lda, P, lda, 1.0, A + (size_t)next_end * lda + next_end, lda,
-                                     GPAR_GEMM_C_LOWER, stream, 1, batch, batch_a, batch_a, batch_a);
+                    rc = potrf_rest_update(c, k0, kend, next_end, stream);
                     prof_end(stream, pa, N - next_end, N - next_end, (kend - k0) * batch);
                 }
                 if (rc) return rc;
@@ -730,10 +742,8 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         {
             const int rows = N - next_end, cols = N - next_end;
             if (rows > 0) {
-                const double* P = A + (size_t)next_end * lda + k0;
                 prof_begin(side, pa);
-                rc = gemm_launch(0, 1, rows, cols, kend - k0, -1.0, P, lda, P, lda, 1.0, A + (size_t)next_end * lda + next_end,
-                                 lda, GPAR_GEMM_C_LOWER, side, 1, batch, batch_a, batch_a, batch_a);
+                rc = potrf_rest_update(c, k0, kend, next_end, side);
                 prof_end(side, pa, rows, cols, (kend - k0) * batch);
                 if (rc) return rc;
             }
