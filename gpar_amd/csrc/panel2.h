@@ -222,7 +222,10 @@ __device__ __forceinline__ int p2_wblock(int jb) {
 // x1 = x0 + W (t - L_bb x0), eight more matrix-core products for that block - backward stable while eps * cond << 1, and paid
 // only where it is needed.  The four flags of a tile sit in row 1, columns 16 .. 19 of the tile (strictly upper: scratch by the
 // ABI's convention, clear of the progress words in row 0 and of the inverses from column 32 on).
-constexpr double P2_REFINE_RATIO = 32.0;
+#ifndef GPAR_P2_REFINE_RATIO
+#define GPAR_P2_REFINE_RATIO 32.0
+#endif
+constexpr double P2_REFINE_RATIO = GPAR_P2_REFINE_RATIO;
 __device__ __forceinline__ int p2_flag_slot(int jb) { return PNL_LD + 16 + jb; }
 
 // Wave w inverts the w-th diagonal 16 x 16 block  [La 0; Lba Lb]  of the lower-triangular tile Cs into the 16 x 16 block

@@ -9,6 +9,8 @@ library.  Layer i models output i given the inputs and the previous outputs: its
 
 Tensors are torch float64 on the engine's device; numpy inputs are accepted and converted.
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -111,31 +113,60 @@ def last(xs, select=None):
         yield True, current
 
 
-def _retry_unfused(evaluate, layers=(), inputs=(), rewind=False):
-    """evaluate(); should a hand-off inside a persistent panel kernel have timed out (device-side info < 0: results
-    invalid), once more with the engine in safe mode - separate leaf kernels, no look-ahead, no layer pipelining.  Whether
-    the retry is allowed is read off the actual graph, not off the global grad mode (which is on by default on every
-    inference path): an evaluation none of whose layers carries trainable tensors and none of whose inputs requires grad is
-    not part of an objective and is simply repeated; an objective under autograd is not retried here - the optimiser treats
-    the error as a failed evaluation."""
-    from .engine import HandOffTimeoutError
+_RETRYING = threading.local()
 
+
+def notpd_retry_enabled():
+    """GPAR_NOTPD_RETRY (default 1): a factorisation that reports a non-positive pivot on the fused panel path is given a second
+    opinion on the unfused one before the error reaches the caller."""
+    import os
+
+    return os.environ.get("GPAR_NOTPD_RETRY", "1") != "0"
+
+
+def _retry_unfused(evaluate, layers=(), inputs=(), rewind=False):
+    """evaluate(); once more with the engine in safe mode - separate leaf kernels, no look-ahead, no layer pipelining - should
+
+    * a hand-off inside a persistent panel kernel have timed out (device-side info < 0: results invalid).  Whether this retry is
+      allowed is read off the actual graph, not off the global grad mode (which is on by default on every inference path): an
+      evaluation none of whose layers carries trainable tensors and none of whose inputs requires grad is not part of an
+      objective and is simply repeated; an objective under autograd is not retried here - the optimiser treats the error as a
+      failed evaluation;
+    * a factorisation have reported a non-positive pivot.  K_zz + 1e-12 of many inducing inputs on one axis sits at the edge of
+      numerical definiteness: its smallest eigenvalue (~1e-12) is of the size of ANY Cholesky's backward error (2e-15 |K|), and
+      which of two backward-stable factorisations gets through is a matter of rounding - LAPACK itself fails on a tenth of such
+      matrices (tools/r04_marginal_potrf.py: 6 of 60).  The fused panel kernel solves its strips through explicit inverses of
+      16 x 16 blocks with one refinement step (backward error 2.8e-15 where substitution, the unfused path and LAPACK, leave
+      1.9e-15) and so fails on a few more: two of forty sparse fuzz cases where numpy's Cholesky does not.  The unfused path
+      is the arithmetic of LAPACK's; an error it repeats is reported (for `fit`: a failed evaluation, as in varz).  The
+      evaluation builds its graph afresh, so this retry is taken under autograd too."""
+    from .engine import HandOffTimeoutError, NotPositiveDefiniteError
+
+    if getattr(_RETRYING, "active", False):
+        return evaluate()  # already inside the second attempt of an enclosing evaluation
     calls = getattr(get_engine(), "_calls", None) if rewind else None
     try:
         return evaluate()
-    except HandOffTimeoutError:
+    except (HandOffTimeoutError, NotPositiveDefiniteError) as e:
         eng = get_engine()
         if not hasattr(eng, "safe_mode"):
             raise
-        if calls is not None:
-            eng._calls = calls  # `rewind`: the repetition draws the same random numbers as the failed attempt
-        if torch.is_grad_enabled():
+        if isinstance(e, NotPositiveDefiniteError):
+            if not notpd_retry_enabled():
+                raise
+        elif torch.is_grad_enabled():
             if any(_is_torch(t) and t.requires_grad for t in inputs):
                 raise
             if any(_differentiable(*model()) for model in layers):
                 raise
-        with eng.safe_mode():
-            return evaluate()
+        if calls is not None:
+            eng._calls = calls  # `rewind`: the repetition draws the same random numbers as the failed attempt
+        _RETRYING.active = True
+        try:
+            with eng.safe_mode():
+                return evaluate()
+        finally:
+            _RETRYING.active = False
 
 
 def _differentiable(f, noise):

@@ -119,6 +119,51 @@ def test_hand_off_timeout_inside_a_training_objective_is_not_retried():
         set_engine(previous)
 
 
+def test_non_positive_pivot_gets_a_second_opinion_on_the_unfused_path(monkeypatch):
+    """A matrix at the edge of numerical definiteness (K_zz + 1e-12 of many inducing inputs on one axis): the fused panel path and
+    LAPACK's arithmetic do not fail on the same ones, so a non-positive pivot is confirmed on the unfused path before it is
+    reported - under autograd too (the evaluation builds its graph afresh) - and reported if that path repeats it."""
+    from gpar_amd.engine import NotPositiveDefiniteError, set_engine
+    from gpar_amd.regression import GPARRegressor
+
+    from oracle.engine import OracleEngine
+
+    class Marginal(type(_FlakyEngine(0))):
+        always = False
+
+        def potrf_(self, A, nf=None):
+            if self.always or (self.fail > 0 and not self.in_safe):
+                self.fail -= 1
+                raise NotPositiveDefiniteError(148)
+            return OracleEngine.potrf_(self, A, nf=nf)
+
+    x, y = _tiny()
+    eng = Marginal()
+    previous = set_engine(eng)
+    try:
+        reg = GPARRegressor(noise=0.1)
+        want = float(reg.logpdf(x, y))
+        eng.fail = 1
+        assert float(reg.logpdf(x, y)) == want and eng.safe_entries == 1
+        reg.vs.requires_grad(True)
+        eng.fail = 1
+        value = reg.logpdf(torch.tensor(x), torch.tensor(y))
+        value.backward()
+        assert float(value.detach()) == want and eng.safe_entries == 2
+        reg.vs.requires_grad(False)
+        eng.always = True  # the unfused path agrees: the error is the caller's
+        with pytest.raises(NotPositiveDefiniteError):
+            reg.logpdf(x, y)
+        assert eng.safe_entries == 3
+        eng.always, eng.fail = False, 1
+        monkeypatch.setenv("GPAR_NOTPD_RETRY", "0")
+        with pytest.raises(NotPositiveDefiniteError):
+            reg.logpdf(x, y)
+        assert eng.safe_entries == 3
+    finally:
+        set_engine(previous)
+
+
 def test_sparse_method_is_validated_at_construction():
     from gpar_amd.regression import GPARRegressor
 

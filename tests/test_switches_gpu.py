@@ -54,6 +54,7 @@ CALL_TIME = [
     ("GPAR_VFE_FUSED_SCALARS", "0"),
     ("GPAR_ONE_CALL_GRAD_ROWS", "0"),
     ("GPAR_FIT_THREADS", "1"),
+    ("GPAR_NOTPD_RETRY", "0"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "0"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "-1"),
     ("GPAR_GRAD_JIT_MIN_ENTRIES", "0"),

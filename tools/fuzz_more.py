@@ -30,30 +30,31 @@ def case(seed):
     xs = rng.uniform(0, 1, (int(rng.integers(5, 300)), m))
     return kw, x, y, w, xs
 
-bad = 0
-for seed in range(int(sys.argv[1]), int(sys.argv[2])):
-    kw, x, y, w, xs = case(seed)
-    desc = {k: (v.shape if hasattr(v, "shape") else v) for k, v in kw.items()}
-    t0 = time.time()
-    try:
-        sparse = "x_ind" in kw
-        hv, hg = _grads("hip", kw, x, y, w)
+if __name__ == "__main__":
+    bad = 0
+    for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+        kw, x, y, w, xs = case(seed)
+        desc = {k: (v.shape if hasattr(v, "shape") else v) for k, v in kw.items()}
+        t0 = time.time()
         try:
-            ov, og = _grads("oracle", kw, x, y, w)
+            sparse = "x_ind" in kw
+            hv, hg = _grads("hip", kw, x, y, w)
+            try:
+                ov, og = _grads("oracle", kw, x, y, w)
+            except Exception as e:
+                print(seed, "ORACLE FAILED but hip ok", type(e).__name__, x.shape, desc); continue
+            tol = 1e-5 if sparse else 1e-9
+            dv = abs(hv - ov) / max(abs(ov), 1.0)
+            big = max(np.max(np.abs(og)), 1e-3)
+            dg = np.max(np.abs(hg - og)) / big
+            hp, hpost, hs, _, _ = _run("hip", kw, x, y, w, xs)
+            op, opost, os_, _, _ = _run("oracle", kw, x, y, w, xs)
+            dpost = abs(hpost - opost) / max(abs(opost), 1.0)
+            ds = np.max(np.abs(hs - os_)) / max(1.0, np.abs(os_).max())
+            flag = "" if (dv <= tol and dg <= (1e-3 if sparse else 1e-6) and dpost <= tol * 10 and ds <= (1e-3 if sparse else 1e-6)) else "  <<<<<< MISMATCH"
+            bad += bool(flag)
+            print(seed, x.shape, y.shape[1], "sparse" if sparse else "dense", "dv %.1e dg %.1e dpost %.1e dsample %.1e  %.1fs%s" % (dv, dg, dpost, ds, time.time() - t0, flag), desc if flag else "", flush=True)
         except Exception as e:
-            print(seed, "ORACLE FAILED but hip ok", type(e).__name__, x.shape, desc); continue
-        tol = 1e-5 if sparse else 1e-9
-        dv = abs(hv - ov) / max(abs(ov), 1.0)
-        big = max(np.max(np.abs(og)), 1e-3)
-        dg = np.max(np.abs(hg - og)) / big
-        hp, hpost, hs, _, _ = _run("hip", kw, x, y, w, xs)
-        op, opost, os_, _, _ = _run("oracle", kw, x, y, w, xs)
-        dpost = abs(hpost - opost) / max(abs(opost), 1.0)
-        ds = np.max(np.abs(hs - os_)) / max(1.0, np.abs(os_).max())
-        flag = "" if (dv <= tol and dg <= (1e-3 if sparse else 1e-6) and dpost <= tol * 10 and ds <= (1e-3 if sparse else 1e-6)) else "  <<<<<< MISMATCH"
-        bad += bool(flag)
-        print(seed, x.shape, y.shape[1], "sparse" if sparse else "dense", "dv %.1e dg %.1e dpost %.1e dsample %.1e  %.1fs%s" % (dv, dg, dpost, ds, time.time() - t0, flag), desc if flag else "", flush=True)
-    except Exception as e:
-        bad += 1
-        print(seed, "HIP FAILED", type(e).__name__, str(e)[:150], x.shape, desc, flush=True)
-print("bad:", bad)
+            bad += 1
+            print(seed, "HIP FAILED", type(e).__name__, str(e)[:150], x.shape, desc, flush=True)
+    print("bad:", bad)
