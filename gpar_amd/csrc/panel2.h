@@ -964,14 +964,21 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
 // block's tiles X[rb][u], u < c, are staged once per pair and used against L[c][u] and L[c + 1][u] in turn, and the product
 // (c + 1, c) takes X[rb][c] from the LDS tile the strip of column c has just written - 56 tile movements per 512-column block
 // instead of 72 (the bulk work of this task is bound by operand bytes: lesson 31).  Same sums in the same order: same bits.
+// (two panels in one launch, potrf_group2_kernel below)  cstart > ufirst: the column blocks [ufirst, cstart) of this row block are
+// SOLVED already - the previous panel's columns - and only enter the sums; column block c is column block c - cstart of the panel
+// whose team the progress words belong to.  pub != nullptr: after every column block the row block's own progress word receives
+// pub_base + (number of column blocks solved), behind write-through stores of the tile.
 template <bool FLAGS>
 __device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const double* __restrict__ L, int ldl, int lrows, int lr0, int lc0,
                                                    double* __restrict__ B, int ldb, int brows, int r0, int bc0, int ncol, double* __restrict__ psm,
-                                                   int ufirst = 0) {   // (ufirst: column blocks before it are zero and stay zero - an upper-triangular right-hand side)
+                                                   int ufirst = 0,   // (ufirst: column blocks before it are zero and stay zero - an upper-triangular right-hand side)
+                                                   int cstart = -1, unsigned long long* pub = nullptr, unsigned long long pub_base = 0ull) {
     double* Cs = psm;
     double* Xs = psm + PNL_TILE;
     unsigned long long* seen = reinterpret_cast<unsigned long long*>(psm + 2 * PNL_TILE);   // 16 words (FLAGS: progress cache)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    if (cstart < 0) cstart = ufirst;
+    const int fo = FLAGS ? cstart : 0;   // progress words count the column blocks of the panel that starts at column block cstart
     if (FLAGS) {
         if (t < 16) seen[t] = 0ull;
         __syncthreads();
@@ -983,7 +990,7 @@ __device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const dou
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int v = 0; v < 4; ++v) T[mi][v] = Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] - acc[mi][v];
-        if (FLAGS) p2_wait(p, seen, c, (unsigned long long)c + 1);   // the triangle (with its inverse blocks and flags) is out
+        if (FLAGS) p2_wait(p, seen, c - fo, (unsigned long long)(c - fo) + 1);   // the triangle (with its inverse blocks and flags) is out
         else __syncthreads();
         {
             pan_d2 lt[8];
@@ -1001,9 +1008,14 @@ __device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const dou
 #pragma unroll
             for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] = T[mi][v];
         __syncthreads();
-        p2_gstore(B, ldb, brows, r0, bc0 + 64 * c, Xs, t, false);
+        p2_gstore(B, ldb, brows, r0, bc0 + 64 * c, Xs, t, pub != nullptr);
+        if (pub) {   // (wave-uniform) the tile is out before the word says so
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(pub, pub_base + (unsigned long long)(c - cstart) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
-    for (int c = ufirst; c < ncol; c += 2) {
+    for (int c = cstart; c < ncol; c += 2) {
         const bool pair = c + 1 < ncol;
         pan_d4 acc0[4], acc1[4];
 #pragma unroll
@@ -1012,8 +1024,8 @@ __device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const dou
         p2_gload(B, ldb, brows, r0, bc0 + 64 * ufirst, t, xa);   // X[rb][ufirst] - or, for c = ufirst, the tile to be solved itself
         if (c > ufirst) {
             if (FLAGS) {   // every L[c][u] and L[c + 1][u], u < c, is out
-                p2_wait(p, seen, c, (unsigned long long)c);
-                if (pair) p2_wait(p, seen, c + 1, (unsigned long long)c);
+                p2_wait(p, seen, c - fo, (unsigned long long)(c - fo));
+                if (pair) p2_wait(p, seen, c + 1 - fo, (unsigned long long)(c - fo));
             }
             pan_d2 la0[8], la1[8];
             p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * ufirst, t, la0);
@@ -1044,7 +1056,7 @@ __device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const dou
         solve_column(c, acc0);
         if (pair) {
             // the product (c + 1, c): X[rb][c] is in Xs (the strip has just left it there), L[c + 1][c] and the next tile to solve arrive now
-            if (FLAGS) p2_wait(p, seen, c + 1, (unsigned long long)c + 1);   // team row c + 1 has solved (and published) its strip of column c
+            if (FLAGS) p2_wait(p, seen, c + 1 - fo, (unsigned long long)(c - fo) + 1);   // team row c + 1 has solved (and published) its strip of column c
             pan_d2 lc[8];
             p2_gload(L, ldl, lrows, lr0 + 64 * (c + 1), lc0 + 64 * c, t, lc);
             p2_gload(B, ldb, brows, r0, bc0 + 64 * (c + 1), t, xa);
@@ -1105,6 +1117,209 @@ static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* 
             GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)b * batch_a + (size_t)k0 * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream));
     const int R = (N - k0 + 63) / 64;
     hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R, batch), dim3(256), P2_LDS_BYTES, stream, p);
+    GPAR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TWO consecutive panels in one launch (the latency-bound tail of a factorisation, and all of a small one).
+//
+// Between two panel kernels the schedule of potrf_run has a launch boundary, the update of the next panel's columns (a launch of
+// its own, 20-100 us even when it is a single round of tiles) and another boundary: a 64-column step of the chain costs 12.9 us
+// inside a panel and ~26 us averaged over a latency-bound step.  Here the second panel's chain starts ~one tile product after the
+// first one's ends.  Workgroups in dispatch order (every wait is on a lower index, as in potrf_panel2_kernel):
+//   (0) the row blocks of panel 0 [k0, k1): as above, except that bulk row blocks publish a progress word per column block;
+//   (1) the 36 tiles of panel 1's diagonal block, C -= X_i X_j^T over panel 0's eight column blocks: one workgroup per tile,
+//       chunk u as soon as rows i and j have column block u, the C tile in registers from the start - behind the last column
+//       block of panel 0 there is one tile product and one store left; each tile then counts itself into its row's word;
+//   (2) panel 1's team rows: each waits for its row's tiles of (1), then as above;
+//   (3) the tiles of panel 1's columns BELOW its diagonal block, like (1) (folded into the bulk row blocks' left-looking sums -
+//       64 more tile products in one workgroup, ~150 us - they outlast panel 1's chain: n = 1024 0.33 -> 0.43 ms);
+//   (4) panel 1's bulk row blocks: each waits for its eight tiles of (3).
+// Words (all in the strict upper triangle of diagonal tiles - scratch by the ABI's convention - and zeroed by potrf_zero_flags):
+// row block b keeps its progress word in row 2, its tile count in row 3, column 8 of the diagonal tile of row block b - 1
+// (its own diagonal tile may have a single row: the augmented row).  Progress counts column blocks of the whole matrix, the
+// tile count accumulates over the fused launches of a factorisation (8 per launch for every row below the launch's panels): no
+// word is ever reset.
+struct GroupArgs {
+    PanelArgs p;                  // panel 0
+    unsigned long long la_base;   // tiles every row block below k0 has counted in earlier fused launches of this factorisation
+};
+
+__device__ __forceinline__ unsigned long long* grp_word(double* A, int lda, int arb, int which) {
+    return reinterpret_cast<unsigned long long*>(A + (size_t)(64 * (arb - 1) + 2 + which) * lda + 64 * (arb - 1) + 8);
+}
+
+// all threads; returns once *word >= need (bounded like p2_wait) with this compute unit's stale lines dropped
+__device__ __forceinline__ void grp_wait(unsigned long long* word, unsigned long long need, int* info) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > PNL_SPIN_LIMIT) {
+                if (info) atomicCAS(info, 0, -77);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// one 64 x 64 tile (ti, tj) of panel 1's columns: C -= X_i X_j^T over panel 0's S column blocks, then count it into row ti's word
+__device__ __forceinline__ void grp_la_tile(const PanelArgs& p, int k1, int kb0, int ti, int tj, double* __restrict__ psm) {
+    const int S = p.S, t = threadIdx.x;
+    double* Cs = psm;
+    double* Xs = psm + PNL_TILE;
+    const int lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    const int r0 = k1 + 64 * ti, c0 = k1 + 64 * tj;
+    unsigned long long* wi = grp_word(p.A, p.lda, kb0 + S + ti, 0);
+    unsigned long long* wj = grp_word(p.A, p.lda, kb0 + S + tj, 0);
+    pan_d4 acc[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) acc[mi] = pan_d4{0.0, 0.0, 0.0, 0.0};
+    pan_d2 ct[8];   // the output tile: last written by an earlier launch on the stream
+    p2_gload(p.A, p.lda, p.N, r0, c0, t, ct);
+    for (int u = 0; u < S; ++u) {
+        grp_wait(wi, (unsigned long long)(kb0 + u + 1), p.info);
+        if (ti != tj) grp_wait(wj, (unsigned long long)(kb0 + u + 1), p.info);
+        pan_d2 xa[8], la[8];
+        p2_gload(p.A, p.lda, p.N, r0, p.k0 + 64 * u, t, xa);
+        p2_gload(p.A, p.lda, p.N, c0, p.k0 + 64 * u, t, la);
+        p2_sstore(Cs, t, la);
+        p2_sstore(Xs, t, xa);
+        __syncthreads();
+        p2_chunk(Cs, Xs, acc, w, l15, lk);
+        __syncthreads();   // the operand reads are done before the next chunk's tiles (or the output tile) land
+    }
+    p2_sstore(Xs, t, ct);
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] -= acc[mi][v];
+    __syncthreads();
+    if (ti != tj) {
+        p2_gstore(p.A, p.lda, p.N, r0, c0, Xs, t, true);
+    } else {   // lower triangle only: the strict upper triangle holds panel 1's words
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = t + 256 * q;
+            const int r = c >> 5, cc = (c & 31) * 2;
+            if (r0 + r < p.N && cc <= r) {
+                double* dst = p.A + (size_t)(r0 + r) * p.lda + c0 + cc;
+                if (cc + 1 <= r) {
+                    const pan_d2 v = *reinterpret_cast<const pan_d2*>(Xs + r * PNL_LD + cc);
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+                } else {
+                    const double v = Xs[r * PNL_LD + cc];
+                    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_fetch_add(grp_word(p.A, p.lda, kb0 + S + ti, 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256, 2) void potrf_group2_kernel(GroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double psm[];
+    PanelArgs p = g.p;
+    const int batch = gridDim.y;
+    const int S = p.S;                         // 8
+    const int R0 = (p.N - p.k0 + 63) / 64;     // row blocks from k0
+    const int R1 = R0 - S;                     // row blocks from k1
+    const int TD = S * (S + 1) / 2;            // tiles of panel 1's diagonal block
+    const int TB = (R1 - S) * S;               // tiles of panel 1's columns below it
+    const int k1 = p.k0 + 64 * S;
+    const int kb0 = p.k0 / 64;
+    int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    int rb, b;
+    if (lin < R0 * batch) {
+        // ---- (0) panel 0: teams of all matrices first, as in potrf_panel2_kernel ----
+        if (lin < S * batch) {
+            rb = lin / batch;
+            b = lin - rb * batch;
+        } else {
+            const int idx = lin - S * batch;
+            rb = S + idx / batch;
+            b = idx % batch;
+        }
+        p.A += (size_t)b * p.batch_a;
+        if (p.logdet) p.logdet += b;
+        if (p.info) p.info += b;
+        const int r0 = p.k0 + 64 * rb;
+        if (rb < S) {
+            __builtin_amdgcn_s_setprio(3);
+            p2_row_block<true, true>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, rb, 0, rb, psm);
+        } else {
+            p2_row_block_pairs<true>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, S, psm, 0, 0, grp_word(p.A, p.lda, kb0 + rb, 0),
+                                     (unsigned long long)kb0);
+        }
+        return;
+    }
+    lin -= R0 * batch;
+    if (lin < TD * batch) {
+        // ---- (1) one tile of panel 1's diagonal block ----
+        const int tile = lin / batch;
+        b = lin - tile * batch;
+        p.A += (size_t)b * p.batch_a;
+        if (p.info) p.info += b;
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+        __builtin_amdgcn_s_setprio(2);
+        grp_la_tile(p, k1, kb0, ti, tile - ti * (ti + 1) / 2, psm);
+        return;
+    }
+    lin -= TD * batch;
+    if (lin < S * batch) {
+        // ---- (2) panel 1's team ----
+        rb = lin / batch;
+        b = lin - rb * batch;
+        p.A += (size_t)b * p.batch_a;
+        if (p.logdet) p.logdet += b;
+        if (p.info) p.info += b;
+        __builtin_amdgcn_s_setprio(3);
+        grp_wait(grp_word(p.A, p.lda, kb0 + S + rb, 1), g.la_base + (unsigned long long)rb + 1ull, p.info);
+        p.k0 = k1;
+        p2_row_block<true, true>(p, p.A, p.lda, p.N, k1, k1, p.A, p.lda, p.N, k1 + 64 * rb, k1, rb, 0, rb, psm);
+        return;
+    }
+    lin -= S * batch;
+    if (lin < TB * batch) {
+        // ---- (3) one tile of panel 1's columns below the diagonal block ----
+        const int tile = lin / batch;
+        b = lin - tile * batch;
+        p.A += (size_t)b * p.batch_a;
+        if (p.info) p.info += b;
+        const int ti = S + tile / S;
+        grp_la_tile(p, k1, kb0, ti, tile - (ti - S) * S, psm);
+        return;
+    }
+    lin -= TB * batch;
+    // ---- (4) panel 1's bulk row blocks ----
+    rb = S + lin / batch;
+    b = lin % batch;
+    p.A += (size_t)b * p.batch_a;
+    if (p.info) p.info += b;
+    grp_wait(grp_word(p.A, p.lda, kb0 + S + rb, 1), g.la_base + (unsigned long long)S, p.info);
+    p.k0 = k1;
+    p2_row_block_pairs<true>(p, p.A, p.lda, p.N, k1, k1, p.A, p.lda, p.N, k1 + 64 * rb, k1, S, psm);
+}
+
+static int potrf_group2_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, int batch,
+                              long long batch_a, unsigned long long la_base) {
+    GroupArgs g;
+    g.p = PanelArgs{A, N, lda, k0, W / 64, logdet, info, nullptr};
+    g.p.batch_a = batch_a;
+    g.p.pairs = 1;
+    g.la_base = la_base;
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_group2_kernel), P2_LDS_BYTES));
+    const int S = W / 64;
+    const int R0 = (N - k0 + 63) / 64, R1 = R0 - S;
+    const int per = R0 + S * (S + 1) / 2 + S + (R1 - S) * S + (R1 - S);
+    hipLaunchKernelGGL(potrf_group2_kernel, dim3(per, batch), dim3(256), P2_LDS_BYTES, stream, g);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

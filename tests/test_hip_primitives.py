@@ -521,6 +521,50 @@ def test_lockstep_batch_factorisation_equals_one_at_a_time(env, N, nf, batch):
     assert np.allclose(np.tril(got[:N])[:, :nf], L0[:, :nf], rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("N,nf,batch", [(1025, 1024, 1), (1026, 1024, 4), (2049, 2048, 1), (2100, 2048, 3), (3137, 3136, 1), (2600, 1100, 2), (5200, 5200, 1),
+                                        (4161, 4160, 2)])
+def test_two_panels_per_launch_leave_the_factor_of_one_panel_per_launch(env, monkeypatch, N, nf, batch):
+    """potrf_group2_kernel (two 512-column panels per launch, the second panel's chain starting one tile product behind the first
+    one's; GPAR_POTRF_FUSE2_ROWS / GPAR_POTRF_FUSE2_BATCH_ROWS) against the one-panel-per-launch schedule: same factor, Schur
+    complement and logdet to rounding, with EVERY eligible step fused and with the default rule; single augmented rows (N = 64 k + 1),
+    ragged last row blocks, partial factorisations with many rows below, lock-step batches, look-ahead on (N = 5200); repeated
+    runs return the same bits (the hand-off words are never reset inside a factorisation)."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(N + batch)
+    pts = rng.uniform(0, 1, (N, 3))
+    mats = []
+    for b in range(batch):
+        d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+        mats.append(np.exp(-0.5 * d2 / (0.2 + 0.05 * b)) + (0.05 + 0.02 * b) * np.eye(N))
+    host = to_dev(np.concatenate(mats, axis=0))
+    A = hip.alloc_matrix(batch * N, N, dev)
+
+    def run():
+        A.copy_(host)
+        if batch == 1:
+            logdet, info = hip.potrf_(A, nf)
+        else:
+            logdet, info = hip.potrf_batch_(A, batch, nf)
+        assert info.cpu().tolist() == [0] * batch
+        return np.tril(A.cpu().numpy().reshape(batch, N, -1)[:, :, :N]), logdet.cpu().numpy().copy()
+
+    monkeypatch.setenv("GPAR_POTRF_FUSE2_ROWS", "0")
+    monkeypatch.setenv("GPAR_POTRF_FUSE2_BATCH_ROWS", "0")
+    ref, ref_logdet = run()
+    for rows in ("1000000", None):
+        for name in ("GPAR_POTRF_FUSE2_ROWS", "GPAR_POTRF_FUSE2_BATCH_ROWS"):
+            if rows is None:
+                monkeypatch.delenv(name)
+            else:
+                monkeypatch.setenv(name, rows)
+        got, logdet = run()
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 2e-13 * scale, (rows, np.abs(got - ref).max() / scale)
+        assert np.allclose(logdet, ref_logdet, rtol=1e-13, atol=0)
+        again, logdet2 = run()
+        assert np.array_equal(again, got) and np.array_equal(logdet2, logdet)
+
+
 @pytest.mark.parametrize("ns,n,batch", [(200, 333, 5), (512, 1024, 3), (65, 10, 2)])
 def test_batched_downdate_and_draws(env, ns, n, batch):
     """gpar_gemm_batch (C_b -= V_b V_b^T, lower) and gpar_trmv_lower_batch (y_b = L_b z_b + m_b): the per-sample steps of

@@ -45,6 +45,11 @@ CALL_TIME = [
     ("GPAR_POTRF_SMALL_UPDATE", "0"),
     ("GPAR_POTRF_LA_SMALL_TILES", "0"),
     ("GPAR_POTRF_LA_SMALL_TILES", "100000"),
+    ("GPAR_POTRF_FUSE2_ROWS", "0"),
+    ("GPAR_POTRF_FUSE2_ROWS", "100000"),
+    ("GPAR_POTRF_FUSE2_BATCH_ROWS", "0"),
+    ("GPAR_POTRF_FUSE2_BATCH_ROWS", "100000"),
+    ("GPAR_POTRF_LA_SMALL_TILES2", "0"),
     ("GPAR_ONE_CALL", "0"),
     ("GPAR_LOCKSTEP_FUSED_BUILD_ROWS", "0"),
     ("GPAR_POTRF_BATCH_REST_AFTER_LA", "100000"),
