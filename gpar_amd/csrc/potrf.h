@@ -328,7 +328,9 @@ static PotrfPolicy potrf_policy(int N) {
     // trailing updates are long enough to hide it (measured with half-tile workgroups for the small launches: n = 5120
     // 3.12 -> 2.97 ms, 6144 4.06 -> 3.81, 8192 6.75 -> 5.98; a wash at 4096, a loss at 3072).  The unfused fallback keeps
     // it off (its small kernels starve behind the SYRK).
-    p.lookahead = (p.fused && N >= 4608) ? 1 : 0;
+    // (round 4, with the small look-ahead update kernel and two panels per launch: n = 3072 1.152 -> 1.097 ms, 4096 1.767 -> 1.631, 4600
+    // 2.248 -> 1.96, a wash at 2048: profiles/r04_exp_potrf_fuse2.txt)
+    p.lookahead = (p.fused && N >= 2560) ? 1 : 0;
     p.nbo = env_int("GPAR_POTRF_NBO", p.nbo);
     p.nbm = env_int("GPAR_POTRF_NBM", p.nbm);
     p.lookahead = env_int("GPAR_POTRF_LOOKAHEAD", p.lookahead);
@@ -647,11 +649,12 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // GPAR_POTRF_FUSE2_ROWS rows from the step's first column on (a lock-step batch: GPAR_POTRF_FUSE2_BATCH_ROWS over the batch - it
     // fills the chip sooner).  Measured (tools/exp_potrf_fuse2.py, profiles/r04_exp_potrf_fuse2.txt): lone n = 1024 / 2048 / 3072 /
     // 4096 0.333 -> 0.310 / 0.753 -> 0.651 / 1.246 -> 1.146 / 1.869 -> 1.765 ms with every step fused; where a trailing update runs
-    // beside the panels on the side stream (look-ahead, N >= 4608) the waiting tile workgroups cost it compute-unit slots, and only the
-    // last 3072 rows gain (n = 8192 5.115 -> 5.047 ms, 5.30 fused from 5120 rows on; n = 16384 inside the noise); a lock-step batch of
+    // beside the panels on the side stream (look-ahead, N >= 2560) the waiting tile workgroups cost it compute-unit slots, and only the
+    // last ~2500 rows gain (n = 8192 5.04 -> 4.92 ms, 5.30 fused from 5120 rows on; n = 4096 1.640 -> 1.579, 3072 1.130 -> 1.079, 2560
+    // 0.924 -> 0.866; n = 4600 1.94 / 1.95 / 2.00 / 2.18 ms fused never / from 2560 / 4200 / 5120 rows; n = 16384 inside the noise); a lock-step batch of
     // four gains 1 % on its last pair of panels and loses when more are fused (4 x 4096: 2.74 -> 2.71 / 2.84 ms).  Geometry only, like
     // every other rule here: the same bits with and without look-ahead.
-    const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", N >= 4608 ? 3072 : 5120) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 6144) / batch;
+    const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", 2560) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 6144) / batch;
     const bool fuse2_on = pol.fused && prezero && !(flags & GPAR_POTRF_UNFUSED) && nbo == 512 && env_int("GPAR_PANEL_V", 2) >= 2 &&
                           env_int("GPAR_PANEL_PAIRS", 1) && (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && fuse2_rows > 0 && tail == 0;
     int fuse2_launches = 0;   // every row block below a fused launch's panels counts 8 tiles per launch (panel2.h)

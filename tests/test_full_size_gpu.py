@@ -384,7 +384,7 @@ def test_factorisation_can_be_captured_into_a_graph_after_gpar_init(hip):
     from gpar_amd import hip as H
 
     dev = hip.device
-    n = 5200   # look-ahead active (n >= 4608), a ragged last panel
+    n = 5200   # look-ahead active (n >= 2560), a ragged last panel
     g = torch.Generator().manual_seed(3)
     x = torch.rand(n, 3, generator=g, dtype=torch.float64).to(dev)
     K = torch.exp(-0.5 * torch.cdist(x, x) ** 2 / 0.25)

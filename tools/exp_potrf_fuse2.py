@@ -21,7 +21,10 @@ for spec in os.environ.get("FUSE2_SWEEP", "default").split(","):
         if len(parts) > 2:
             env["GPAR_POTRF_LA_SMALL_TILES2"] = parts[2]
         VARIANTS.append((f"fuse2 {spec}", env))
-KEYS = ["GPAR_POTRF_FUSE2_ROWS", "GPAR_POTRF_FUSE2_BATCH_ROWS", "GPAR_POTRF_LA_SMALL_TILES2"]
+# FUSE2_ENVS="A=1;B=2,C=3": further variants given as environment assignments
+for spec in filter(None, os.environ.get("FUSE2_ENVS", "").split(",")):
+    VARIANTS.append((spec, dict(kv.split("=") for kv in spec.split(";"))))
+KEYS = sorted({k for _, v in VARIANTS for k in v} | {"GPAR_POTRF_FUSE2_ROWS", "GPAR_POTRF_FUSE2_BATCH_ROWS", "GPAR_POTRF_LA_SMALL_TILES2"})
 REPS = int(os.environ.get("FUSE2_REPS", "6"))
 
 for case in cases:
