@@ -964,7 +964,7 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
 // block's tiles X[rb][u], u < c, are staged once per pair and used against L[c][u] and L[c + 1][u] in turn, and the product
 // (c + 1, c) takes X[rb][c] from the LDS tile the strip of column c has just written - 56 tile movements per 512-column block
 // instead of 72 (the bulk work of this task is bound by operand bytes: lesson 31).  Same sums in the same order: same bits.
-// (two panels in one launch, potrf_group2_kernel below)  cstart > ufirst: the column blocks [ufirst, cstart) of this row block are
+// (two panels in one launch, potrf_group_kernel below)  cstart > ufirst: the column blocks [ufirst, cstart) of this row block are
 // SOLVED already - the previous panel's columns - and only enter the sums; column block c is column block c - cstart of the panel
 // whose team the progress words belong to.  pub != nullptr: after every column block the row block's own progress word receives
 // pub_base + (number of column blocks solved), behind write-through stores of the tile.
@@ -1122,27 +1122,30 @@ static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// TWO consecutive panels in one launch (the latency-bound tail of a factorisation, and all of a small one).
+// SEVERAL consecutive panels in one launch (the latency-bound tail of a factorisation, and all of a small one).
 //
 // Between two panel kernels the schedule of potrf_run has a launch boundary, the update of the next panel's columns (a launch of
 // its own, 20-100 us even when it is a single round of tiles) and another boundary: a 64-column step of the chain costs 12.9 us
-// inside a panel and ~26 us averaged over a latency-bound step.  Here the second panel's chain starts ~one tile product after the
-// first one's ends.  Workgroups in dispatch order (every wait is on a lower index, as in potrf_panel2_kernel):
+// inside a panel and ~26 us averaged over a latency-bound step.  Here panel q + 1's chain starts ~one tile product after panel
+// q's ends.  Workgroups in dispatch order (every wait is on a lower index, as in potrf_panel2_kernel):
 //   (0) the row blocks of panel 0 [k0, k1): as above, except that bulk row blocks publish a progress word per column block;
-//   (1) the 36 tiles of panel 1's diagonal block, C -= X_i X_j^T over panel 0's eight column blocks: one workgroup per tile,
-//       chunk u as soon as rows i and j have column block u, the C tile in registers from the start - behind the last column
-//       block of panel 0 there is one tile product and one store left; each tile then counts itself into its row's word;
-//   (2) panel 1's team rows: each waits for its row's tiles of (1), then as above;
-//   (3) the tiles of panel 1's columns BELOW its diagonal block, like (1) (folded into the bulk row blocks' left-looking sums -
-//       64 more tile products in one workgroup, ~150 us - they outlast panel 1's chain: n = 1024 0.33 -> 0.43 ms);
-//   (4) panel 1's bulk row blocks: each waits for its eight tiles of (3).
+//   then for every further panel q = 1 .. G - 1 of the launch, [kq, kq + 512):
+//   (a) the 36 tiles of its diagonal block, C -= X_i X_j^T over the 8 q column blocks of the launch's earlier panels: one
+//       workgroup per tile, column block u as soon as rows i and j have it, the C tile in registers from the start - behind the
+//       last column block of panel q - 1 there is one tile product and one store left; each tile then counts itself into its
+//       row's word;
+//   (b) its team rows: each waits for its row's tiles of (a), then as above;
+//   (c) the tiles of its columns BELOW the diagonal block, like (a) (folded into the bulk row blocks' left-looking sums - 64 more
+//       tile products in one workgroup, ~150 us - they outlast the panel's chain: n = 1024 0.33 -> 0.43 ms);
+//   (d) its bulk row blocks: each waits for its eight tiles of (c), and publishes like (0) unless the panel is the last.
 // Words (all in the strict upper triangle of diagonal tiles - scratch by the ABI's convention - and zeroed by potrf_zero_flags):
 // row block b keeps its progress word in row 2, its tile count in row 3, column 8 of the diagonal tile of row block b - 1
 // (its own diagonal tile may have a single row: the augmented row).  Progress counts column blocks of the whole matrix, the
-// tile count accumulates over the fused launches of a factorisation (8 per launch for every row below the launch's panels): no
-// word is ever reset.
+// tile count accumulates over the fused launches of a factorisation (8 per panel after a launch's first for every row below
+// them): no word is ever reset.
 struct GroupArgs {
     PanelArgs p;                  // panel 0
+    int G;                        // panels in this launch
     unsigned long long la_base;   // tiles every row block below k0 has counted in earlier fused launches of this factorisation
 };
 
@@ -1166,21 +1169,23 @@ __device__ __forceinline__ void grp_wait(unsigned long long* word, unsigned long
     __syncthreads();
 }
 
-// one 64 x 64 tile (ti, tj) of panel 1's columns: C -= X_i X_j^T over panel 0's S column blocks, then count it into row ti's word
-__device__ __forceinline__ void grp_la_tile(const PanelArgs& p, int k1, int kb0, int ti, int tj, double* __restrict__ psm) {
-    const int S = p.S, t = threadIdx.x;
+// one 64 x 64 tile (ti, tj) of panel q's columns (kq = its first column, q >= 1): C -= X_i X_j^T over the 8 q column blocks of the
+// launch's earlier panels [k0, kq) - column block u as soon as rows i and j have it -, then the tile counts itself into row ti's word
+__device__ __forceinline__ void grp_la_tile(const PanelArgs& p, int kq, int ti, int tj, double* __restrict__ psm) {
+    const int t = threadIdx.x;
     double* Cs = psm;
     double* Xs = psm + PNL_TILE;
     const int lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
-    const int r0 = k1 + 64 * ti, c0 = k1 + 64 * tj;
-    unsigned long long* wi = grp_word(p.A, p.lda, kb0 + S + ti, 0);
-    unsigned long long* wj = grp_word(p.A, p.lda, kb0 + S + tj, 0);
+    const int r0 = kq + 64 * ti, c0 = kq + 64 * tj;
+    const int kb0 = p.k0 / 64, nchunks = (kq - p.k0) / 64;
+    unsigned long long* wi = grp_word(p.A, p.lda, kq / 64 + ti, 0);
+    unsigned long long* wj = grp_word(p.A, p.lda, kq / 64 + tj, 0);
     pan_d4 acc[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) acc[mi] = pan_d4{0.0, 0.0, 0.0, 0.0};
     pan_d2 ct[8];   // the output tile: last written by an earlier launch on the stream
     p2_gload(p.A, p.lda, p.N, r0, c0, t, ct);
-    for (int u = 0; u < S; ++u) {
+    for (int u = 0; u < nchunks; ++u) {
         grp_wait(wi, (unsigned long long)(kb0 + u + 1), p.info);
         if (ti != tj) grp_wait(wj, (unsigned long long)(kb0 + u + 1), p.info);
         pan_d2 xa[8], la[8];
@@ -1201,7 +1206,7 @@ __device__ __forceinline__ void grp_la_tile(const PanelArgs& p, int k1, int kb0,
     __syncthreads();
     if (ti != tj) {
         p2_gstore(p.A, p.lda, p.N, r0, c0, Xs, t, true);
-    } else {   // lower triangle only: the strict upper triangle holds panel 1's words
+    } else {   // lower triangle only: the strict upper triangle holds the panel's words
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int c = t + 256 * q;
@@ -1220,24 +1225,37 @@ __device__ __forceinline__ void grp_la_tile(const PanelArgs& p, int k1, int kb0,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) __hip_atomic_fetch_add(grp_word(p.A, p.lda, kb0 + S + ti, 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) __hip_atomic_fetch_add(grp_word(p.A, p.lda, kq / 64 + ti, 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256, 2) void potrf_group2_kernel(GroupArgs g) {
+__global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     extern __shared__ __attribute__((aligned(16))) double psm[];
     PanelArgs p = g.p;
     const int batch = gridDim.y;
     const int S = p.S;                         // 8
     const int R0 = (p.N - p.k0 + 63) / 64;     // row blocks from k0
-    const int R1 = R0 - S;                     // row blocks from k1
-    const int TD = S * (S + 1) / 2;            // tiles of panel 1's diagonal block
-    const int TB = (R1 - S) * S;               // tiles of panel 1's columns below it
-    const int k1 = p.k0 + 64 * S;
+    const int TD = S * (S + 1) / 2;            // tiles of a panel's diagonal block
     const int kb0 = p.k0 / 64;
     int lin = blockIdx.x + gridDim.x * blockIdx.y;
     int rb, b;
-    if (lin < R0 * batch) {
-        // ---- (0) panel 0: teams of all matrices first, as in potrf_panel2_kernel ----
+    // ---- which segment: panel 0's rows, then per panel q >= 1 (a) diagonal-block tiles, (b) team rows, (c) tiles below, (d) bulk rows
+    int q = 0, seg = 0;
+    if (lin >= R0 * batch) {
+        lin -= R0 * batch;
+        for (q = 1; q < g.G; ++q) {
+            const int Rq = R0 - S * q;
+            const int sizes[4] = {TD * batch, S * batch, (Rq - S) * S * batch, (Rq - S) * batch};
+            for (seg = 1; seg <= 4; ++seg) {
+                if (lin < sizes[seg - 1]) break;
+                lin -= sizes[seg - 1];
+            }
+            if (seg <= 4) break;
+        }
+    }
+    const int kq = p.k0 + 64 * S * q;
+    const bool last = q == g.G - 1;
+    if (seg == 0) {
+        // teams of all matrices first, as in potrf_panel2_kernel
         if (lin < S * batch) {
             rb = lin / batch;
             b = lin - rb * batch;
@@ -1246,80 +1264,68 @@ __global__ __launch_bounds__(256, 2) void potrf_group2_kernel(GroupArgs g) {
             rb = S + idx / batch;
             b = idx % batch;
         }
-        p.A += (size_t)b * p.batch_a;
-        if (p.logdet) p.logdet += b;
-        if (p.info) p.info += b;
-        const int r0 = p.k0 + 64 * rb;
-        if (rb < S) {
-            __builtin_amdgcn_s_setprio(3);
-            p2_row_block<true, true>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, rb, 0, rb, psm);
-        } else {
-            p2_row_block_pairs<true>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, S, psm, 0, 0, grp_word(p.A, p.lda, kb0 + rb, 0),
-                                     (unsigned long long)kb0);
-        }
-        return;
-    }
-    lin -= R0 * batch;
-    if (lin < TD * batch) {
-        // ---- (1) one tile of panel 1's diagonal block ----
-        const int tile = lin / batch;
-        b = lin - tile * batch;
-        p.A += (size_t)b * p.batch_a;
-        if (p.info) p.info += b;
-        int ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-        __builtin_amdgcn_s_setprio(2);
-        grp_la_tile(p, k1, kb0, ti, tile - ti * (ti + 1) / 2, psm);
-        return;
-    }
-    lin -= TD * batch;
-    if (lin < S * batch) {
-        // ---- (2) panel 1's team ----
+    } else if (seg == 1 || seg == 3) {
+        rb = lin / batch;   // tile index
+        b = lin - rb * batch;
+    } else if (seg == 2) {
         rb = lin / batch;
         b = lin - rb * batch;
-        p.A += (size_t)b * p.batch_a;
-        if (p.logdet) p.logdet += b;
-        if (p.info) p.info += b;
-        __builtin_amdgcn_s_setprio(3);
-        grp_wait(grp_word(p.A, p.lda, kb0 + S + rb, 1), g.la_base + (unsigned long long)rb + 1ull, p.info);
-        p.k0 = k1;
-        p2_row_block<true, true>(p, p.A, p.lda, p.N, k1, k1, p.A, p.lda, p.N, k1 + 64 * rb, k1, rb, 0, rb, psm);
-        return;
+    } else {
+        rb = S + lin / batch;
+        b = lin % batch;
     }
-    lin -= S * batch;
-    if (lin < TB * batch) {
-        // ---- (3) one tile of panel 1's columns below the diagonal block ----
-        const int tile = lin / batch;
-        b = lin - tile * batch;
-        p.A += (size_t)b * p.batch_a;
-        if (p.info) p.info += b;
-        const int ti = S + tile / S;
-        grp_la_tile(p, k1, kb0, ti, tile - (ti - S) * S, psm);
-        return;
-    }
-    lin -= TB * batch;
-    // ---- (4) panel 1's bulk row blocks ----
-    rb = S + lin / batch;
-    b = lin % batch;
     p.A += (size_t)b * p.batch_a;
+    if (p.logdet) p.logdet += b;
     if (p.info) p.info += b;
-    grp_wait(grp_word(p.A, p.lda, kb0 + S + rb, 1), g.la_base + (unsigned long long)S, p.info);
-    p.k0 = k1;
-    p2_row_block_pairs<true>(p, p.A, p.lda, p.N, k1, k1, p.A, p.lda, p.N, k1 + 64 * rb, k1, S, psm);
+    if (seg == 1) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= rb) ++ti;
+        __builtin_amdgcn_s_setprio(2);
+        grp_la_tile(p, kq, ti, rb - ti * (ti + 1) / 2, psm);
+        return;
+    }
+    if (seg == 3) {
+        const int ti = S + rb / S;
+        grp_la_tile(p, kq, ti, rb - (ti - S) * S, psm);
+        return;
+    }
+    // ---- a row block of panel q
+    const int r0 = kq + 64 * rb;
+    const unsigned long long counted = g.la_base + (unsigned long long)(S * (q - 1));   // tiles this row has counted before panel q's
+    if (rb < S) {
+        __builtin_amdgcn_s_setprio(3);
+        if (q > 0) grp_wait(grp_word(p.A, p.lda, kq / 64 + rb, 1), counted + (unsigned long long)rb + 1ull, p.info);
+        p.k0 = kq;
+        p2_row_block<true, true>(p, p.A, p.lda, p.N, kq, kq, p.A, p.lda, p.N, r0, kq, rb, 0, rb, psm);
+    } else {
+        if (q > 0) grp_wait(grp_word(p.A, p.lda, kq / 64 + rb, 1), counted + (unsigned long long)S, p.info);
+        p.k0 = kq;
+        // (every panel but the last: the row block publishes its column blocks for the tiles of the panels to come)
+        p2_row_block_pairs<true>(p, p.A, p.lda, p.N, kq, kq, p.A, p.lda, p.N, r0, kq, S, psm, 0, 0,
+                                 last ? nullptr : grp_word(p.A, p.lda, kq / 64 + rb, 0), (unsigned long long)(kq / 64));
+    }
 }
 
-static int potrf_group2_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, int batch,
-                              long long batch_a, unsigned long long la_base) {
+static long long potrf_group_workgroups(int N, int k0, int S, int G) {
+    const int R0 = (N - k0 + 63) / 64;
+    long long per = R0;
+    for (int q = 1; q < G; ++q) {
+        const int Rq = R0 - S * q;
+        per += S * (S + 1) / 2 + S + (long long)(Rq - S) * S + (Rq - S);
+    }
+    return per;
+}
+
+static int potrf_group_fused(double* A, int N, int lda, int k0, int W, int G, double* logdet, int* info, hipStream_t stream, int batch,
+                             long long batch_a, unsigned long long la_base) {
     GroupArgs g;
     g.p = PanelArgs{A, N, lda, k0, W / 64, logdet, info, nullptr};
     g.p.batch_a = batch_a;
     g.p.pairs = 1;
+    g.G = G;
     g.la_base = la_base;
-    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_group2_kernel), P2_LDS_BYTES));
-    const int S = W / 64;
-    const int R0 = (N - k0 + 63) / 64, R1 = R0 - S;
-    const int per = R0 + S * (S + 1) / 2 + S + (R1 - S) * S + (R1 - S);
-    hipLaunchKernelGGL(potrf_group2_kernel, dim3(per, batch), dim3(256), P2_LDS_BYTES, stream, g);
+    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_group_kernel), P2_LDS_BYTES));
+    hipLaunchKernelGGL(potrf_group_kernel, dim3((unsigned)potrf_group_workgroups(N, k0, W / 64, G), batch), dim3(256), P2_LDS_BYTES, stream, g);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

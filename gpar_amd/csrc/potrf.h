@@ -407,7 +407,7 @@ static bool potrf_la_is_small(const PotrfCtx& c, int k0, int kend, int la_end) {
     const int nc = cols / 64, tr = (c.N - kend + 63) / 64;
     if (tr < nc) return false;
     const long long tiles = ((long long)nc * (nc + 1) / 2 + (long long)(tr - nc) * nc) * c.batch;
-    // behind a fused pair of panels (K = 1024, potrf_group2_kernel) a tile is 16 chunks and the alternative a K = 1024 GEMM tile of
+    // behind a fused pair of panels (K >= 1024, potrf_group_kernel) a tile is 16 chunks and the alternative a K = 1024 GEMM tile of
     // ~200 us: several rounds of small tiles still win
     if (K >= 1024) return tiles <= env_int("GPAR_POTRF_LA_SMALL_TILES2", 2048);
     return tiles <= env_int("GPAR_POTRF_LA_SMALL_TILES", 512);
@@ -485,8 +485,8 @@ static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* 
 static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
                              hipStream_t stream);
 static int potrf_la_update_small(double* A, int N, int lda, int k0, int kend, int ncols, hipStream_t stream, int batch, long long batch_a);
-static int potrf_group2_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, int batch,
-                              long long batch_a, unsigned long long la_base);
+static int potrf_group_fused(double* A, int N, int lda, int k0, int W, int G, double* logdet, int* info, hipStream_t stream, int batch,
+                             long long batch_a, unsigned long long la_base);
 static int env_int(const char* name, int dflt);
 static int trinv_blocks_fused2(const double* L, int n, int ldl, double* X, int ldx, int S, hipStream_t stream);
 static int trsm_block_back_fused2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, hipStream_t stream);
@@ -645,7 +645,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // 18.1 -> 19.7 ms: a team row's products for column block c (c chunks of 0.55 us) run while row c factors its
     // diagonal tile (5 us), and from c ~ 10 on they outlast it and join the chain.
     const int tail = pol.fused ? env_int("GPAR_POTRF_TAIL", 0) : 0;
-    // Two panels in ONE launch (potrf_group2_kernel, panel2.h) once the rows that are left make a step latency-bound: at most
+    // Two or more panels in ONE launch (potrf_group_kernel, panel2.h; at most GPAR_POTRF_FUSE_MAX) once the rows that are left make a step latency-bound: at most
     // GPAR_POTRF_FUSE2_ROWS rows from the step's first column on (a lock-step batch: GPAR_POTRF_FUSE2_BATCH_ROWS over the batch - it
     // fills the chip sooner).  Measured (tools/exp_potrf_fuse2.py, profiles/r04_exp_potrf_fuse2.txt): lone n = 1024 / 2048 / 3072 /
     // 4096 0.333 -> 0.310 / 0.753 -> 0.651 / 1.246 -> 1.146 / 1.869 -> 1.765 ms with every step fused; where a trailing update runs
@@ -657,9 +657,20 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", 2560) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 6144) / batch;
     const bool fuse2_on = pol.fused && prezero && !(flags & GPAR_POTRF_UNFUSED) && nbo == 512 && env_int("GPAR_PANEL_V", 2) >= 2 &&
                           env_int("GPAR_PANEL_PAIRS", 1) && (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && fuse2_rows > 0 && tail == 0;
-    int fuse2_launches = 0;   // every row block below a fused launch's panels counts 8 tiles per launch (panel2.h)
-    auto fusable2 = [&](int k) { return fuse2_on && !groupable(k) && k % 64 == 0 && k + 2 * nbo <= nf && N - k <= fuse2_rows; };
-    auto panel_end = [&](int k) { return fusable2(k) ? k + 2 * nbo : ((nf - k <= tail || k + nbo >= nf) ? nf : k + nbo); };
+    unsigned long long fuse_counted = 0;   // tiles every row block below the fused launches so far has counted (panel2.h)
+    // (more than two panels per launch add little - between panels inside a launch the next team waits ~45 us for the last column
+    // blocks of its own rows, which the bulk row blocks of the panel before finish behind the chain - : n = 1536 0.497 -> 0.452 ms with
+    // three, n = 2048 0.647 -> 0.637 with four, nothing beyond; 4 measured equal or better than 2 / 3 / 8 at every size)
+    const int fuse_max = env_int("GPAR_POTRF_FUSE_MAX", 4);
+    // panels the step at column k takes in one launch (0: the step is not fused)
+    auto fuse_panels = [&](int k) {
+        if (!fuse2_on || groupable(k) || k % 64 != 0 || N - k > fuse2_rows) return 0;
+        int G = (nf - k) / nbo;
+        if (G > fuse_max) G = fuse_max;
+        return G >= 2 ? G : 0;
+    };
+    auto fusable2 = [&](int k) { return fuse_panels(k) > 0; };
+    auto panel_end = [&](int k) { return fusable2(k) ? k + fuse_panels(k) * nbo : ((nf - k <= tail || k + nbo >= nf) ? nf : k + nbo); };
     for (int k0 = 0, knext = 0; k0 < nf; k0 = knext) {
         int kend = panel_end(k0);
         // a ragged tail (nf not a multiple of 64) becomes its own narrow panel so the wide part stays fusable
@@ -682,9 +693,10 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         } else {
             const int w = kend - k0;
             const bool fused_ok = pol.fused && w % 64 == 0 && w <= 1024 && N - k0 >= 64 && (k0 % 2 == 0) && (lda % 2 == 0) && gpar_aligned16(A);
-            if (fusable2(k0) && w == 2 * nbo) {
-                rc = potrf_group2_fused(A, N, lda, k0, nbo, logdet, info, stream, batch, batch_a, 8ull * (unsigned long long)fuse2_launches);
-                ++fuse2_launches;
+            if (fusable2(k0) && w == fuse_panels(k0) * nbo) {
+                const int G = fuse_panels(k0);
+                rc = potrf_group_fused(A, N, lda, k0, nbo, G, logdet, info, stream, batch, batch_a, fuse_counted);
+                fuse_counted += 8ull * (unsigned long long)(G - 1);
             } else if (fused_ok) {
                 rc = potrf_panel_any(A, N, lda, k0, w, logdet, info, stream, prezero, batch, batch_a);
             } else {
@@ -710,6 +722,21 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
                 // (the same split the look-ahead schedule makes, so that both produce the same bits: the next panel's columns by the
                 // small kernel, everything to their right by the GEMM)
                 rc = potrf_la_update(c, k0, kend, next_end, stream);
+                if (!rc) {
+                    prof_begin(stream, pa);
+                    rc = potrf_rest_update(c, k0, kend, next_end, stream);
+                    prof_end(stream, pa, N - next_end, N - next_end, (kend - k0) * batch);
+                }
+                if (rc) return rc;
+                continue;
+            }
+            if (kend < nf && next_end < N) {
+                // (the same two launches as the look-ahead schedule below - the next step's columns, then everything to their right:
+                // the update kernel picks its tile shape by the size of the launch, and a tile that preloads C rounds differently
+                // from one that adds it at the end, so ONE launch over everything would not return the look-ahead schedule's bits)
+                prof_begin(stream, pa);
+                rc = potrf_gemm_update(c, k0, kend, next_end, stream, 1);
+                prof_end(stream, pa, N - kend, next_end - kend, (kend - k0) * batch);
                 if (!rc) {
                     prof_begin(stream, pa);
                     rc = potrf_rest_update(c, k0, kend, next_end, stream);

@@ -523,10 +523,10 @@ def test_lockstep_batch_factorisation_equals_one_at_a_time(env, N, nf, batch):
 
 @pytest.mark.parametrize("N,nf,batch", [(1025, 1024, 1), (1026, 1024, 4), (2049, 2048, 1), (2100, 2048, 3), (3137, 3136, 1), (2600, 1100, 2), (5200, 5200, 1),
                                         (4161, 4160, 2)])
-def test_two_panels_per_launch_leave_the_factor_of_one_panel_per_launch(env, monkeypatch, N, nf, batch):
-    """potrf_group2_kernel (two 512-column panels per launch, the second panel's chain starting one tile product behind the first
-    one's; GPAR_POTRF_FUSE2_ROWS / GPAR_POTRF_FUSE2_BATCH_ROWS) against the one-panel-per-launch schedule: same factor, Schur
-    complement and logdet to rounding, with EVERY eligible step fused and with the default rule; single augmented rows (N = 64 k + 1),
+def test_several_panels_per_launch_leave_the_factor_of_one_panel_per_launch(env, monkeypatch, N, nf, batch):
+    """potrf_group_kernel (two to GPAR_POTRF_FUSE_MAX 512-column panels per launch, each panel's chain starting one tile product
+    behind the one before; GPAR_POTRF_FUSE2_ROWS / GPAR_POTRF_FUSE2_BATCH_ROWS) against the one-panel-per-launch schedule: same
+    factor, Schur complement and logdet to rounding, with EVERY eligible step fused in twos, threes and eights and with the default rule; single augmented rows (N = 64 k + 1),
     ragged last row blocks, partial factorisations with many rows below, lock-step batches, look-ahead on (N = 5200); repeated
     runs return the same bits (the hand-off words are never reset inside a factorisation)."""
     torch, hip, dev, to_dev = env
@@ -551,18 +551,40 @@ def test_two_panels_per_launch_leave_the_factor_of_one_panel_per_launch(env, mon
     monkeypatch.setenv("GPAR_POTRF_FUSE2_ROWS", "0")
     monkeypatch.setenv("GPAR_POTRF_FUSE2_BATCH_ROWS", "0")
     ref, ref_logdet = run()
-    for rows in ("1000000", None):
-        for name in ("GPAR_POTRF_FUSE2_ROWS", "GPAR_POTRF_FUSE2_BATCH_ROWS"):
-            if rows is None:
-                monkeypatch.delenv(name)
+    for rows, most in (("1000000", "2"), ("1000000", "3"), ("1000000", "8"), (None, None)):
+        for name, value in (("GPAR_POTRF_FUSE2_ROWS", rows), ("GPAR_POTRF_FUSE2_BATCH_ROWS", rows), ("GPAR_POTRF_FUSE_MAX", most)):
+            if value is None:
+                monkeypatch.delenv(name, raising=False)
             else:
-                monkeypatch.setenv(name, rows)
+                monkeypatch.setenv(name, value)
         got, logdet = run()
         scale = np.abs(ref).max()
         assert np.abs(got - ref).max() <= 2e-13 * scale, (rows, np.abs(got - ref).max() / scale)
         assert np.allclose(logdet, ref_logdet, rtol=1e-13, atol=0)
         again, logdet2 = run()
         assert np.array_equal(again, got) and np.array_equal(logdet2, logdet)
+
+
+@pytest.mark.parametrize("N,nf", [(2601, 2600), (3137, 3136), (4097, 4096), (5001, 5000), (5200, 5200), (6300, 6200), (4700, 3000)])
+def test_look_ahead_does_not_change_a_single_bit_of_the_factor(env, N, nf):
+    """The schedule of a factorisation is a function of its shape only: with the trailing update on the side stream (look-ahead) or
+    on the caller's, the same launches with the same tile shapes touch every element in the same order - sizes at which single
+    panels, fused launches of several panels, ragged last panels and the small update kernels all occur."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(N)
+    pts = to_dev(rng.uniform(0, 1, (N, 3)))
+    K = hip.alloc_matrix(N, N, dev)
+    K.copy_(torch.exp(-0.5 * torch.cdist(pts, pts) ** 2 / 0.2))
+    K.diagonal().add_(0.05)
+    A = hip.alloc_matrix(N, N, dev)
+    out = []
+    for la in (True, False, True):
+        A.copy_(K)
+        logdet, info = hip.potrf_(A, nf, lookahead=la)
+        assert int(info.item()) == 0
+        out.append((torch.tril(A).clone(), float(logdet)))
+    assert torch.equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert torch.equal(out[0][0], out[2][0]) and out[0][1] == out[2][1]
 
 
 @pytest.mark.parametrize("ns,n,batch", [(200, 333, 5), (512, 1024, 3), (65, 10, 2)])

@@ -50,6 +50,8 @@ CALL_TIME = [
     ("GPAR_POTRF_FUSE2_BATCH_ROWS", "0"),
     ("GPAR_POTRF_FUSE2_BATCH_ROWS", "100000"),
     ("GPAR_POTRF_LA_SMALL_TILES2", "0"),
+    ("GPAR_POTRF_FUSE_MAX", "2"),
+    ("GPAR_POTRF_FUSE_MAX", "8"),
     ("GPAR_ONE_CALL", "0"),
     ("GPAR_LOCKSTEP_FUSED_BUILD_ROWS", "0"),
     ("GPAR_POTRF_BATCH_REST_AFTER_LA", "100000"),
