@@ -18,7 +18,9 @@
  *   - All matrices are ROW-MAJOR IEEE fp64 in device (HBM) memory with an explicit leading dimension
  *     (elements between consecutive rows).  For symmetric matrices the LOWER triangle is authoritative;
  *     the strict upper triangle is never read; it may hold anything on entry and is SCRATCH: gpar_potrf keeps the
- *     hand-off flags of its persistent panel kernel there (two rows of 56 words per 512-column panel).
+ *     hand-off words of its persistent panel kernels there (rows 0 .. 4, columns 8 .. 63 of every 64 x 64 diagonal tile:
+ *     progress words of a panel's team, inverses of 16 x 16 diagonal blocks, and - where several panels share a launch -
+ *     per-row-block progress words and tile counters), zeroed by one launch at the start of a factorisation.
  *   - Plain pointers and sizes only.  The caller owns every buffer, including workspace
  *     (gpar_workspace_doubles gives the sizes); the library never allocates or frees device MEMORY.  Every compute call
  *     only enqueues work on `stream` (a hipStream_t passed as void*) and returns; nothing synchronises the host except
