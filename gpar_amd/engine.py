@@ -492,11 +492,16 @@ class HipEngine:
             side = _SIDE[str(self.device)] = torch.cuda.Stream(device=self.device)
         return None if side == torch.cuda.current_stream(self.device) else side
 
-    def worker_streams(self, depth=None):
+    def worker_streams(self, depth=None, rows=None):
         """The same streams, for callers that drive them from separate host threads (GPARRegressor.fit trains
-        independent layers concurrently).  Empty when disabled (GPAR_FIT_THREADS=0/1)."""
+        independent layers concurrently).  Empty when disabled (GPAR_FIT_THREADS=0/1).  Default: two threads; four where one
+        layer's evaluation is a latency-bound chain long enough to matter and short enough to leave the chip idle - 2048 to 5120
+        rows (fit(iters=20), four layers, 2 -> 4 threads: n = 2048 139 -> 120 ms, 3072 200 -> 135, 4096 274 -> 196, eight
+        layers at 4096 590 -> 414; below, the threads contend for the interpreter: n = 400 89 -> 122; above, two evaluations
+        fill the chip: n = 6144 625 -> 692, 8192 1063 -> 1149, C3 13.4 -> 13.3 s; profiles/r04_fit_threads.txt)."""
         if depth is None:
-            depth = int(os.environ.get("GPAR_FIT_THREADS", "2"))
+            env = os.environ.get("GPAR_FIT_THREADS")
+            depth = int(env) if env is not None else (4 if rows is not None and 2048 <= int(rows) <= 5120 else 2)
         if depth < 2:
             return []
         return _device_streams(self.device, depth)

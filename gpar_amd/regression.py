@@ -305,7 +305,7 @@ class GPARRegressor:
 
         from .parallel import layers_train_independently
 
-        streams = eng.worker_streams() if hasattr(eng, "worker_streams") else []
+        streams = eng.worker_streams(rows=self.n) if hasattr(eng, "worker_streams") else []
         if fix and self.p > 1 and len(streams) > 1 and layers_train_independently(self, y_dev):
             # Layers whose inputs are data and whose hyper-parameters are their own train independently of one another:
             # two host threads, each on its own stream, keep two L-BFGS-B drivers in flight so that one layer's

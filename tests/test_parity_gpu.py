@@ -419,6 +419,34 @@ def test_concurrent_layer_training_equals_serial_training(monkeypatch):
     assert got["tied_independent"] is False
 
 
+def test_default_thread_count_of_fit_follows_the_problem_size(monkeypatch):
+    """HipEngine.worker_streams: four training threads from 2048 to 5120 rows, two otherwise (profiles/r04_fit_threads.txt);
+    at a size where the default is four, the trained hyper-parameters are those of the serial loop, bit for bit."""
+    from gpar_amd.regression import GPARRegressor
+
+    x, y = _problem(2100, 2, 4, seed=13)
+
+    def run():
+        from gpar_amd.engine import get_engine
+
+        eng = get_engine()
+        monkeypatch.delenv("GPAR_FIT_THREADS", raising=False)
+        counts = {rows: len(eng.worker_streams(rows=rows)) for rows in (400, 2047, 2048, 5120, 5121, 16384)}
+        out = {"counts": counts}
+        for threads in [None, "1"]:
+            if threads is not None:
+                monkeypatch.setenv("GPAR_FIT_THREADS", threads)
+            reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1)
+            reg.fit(x, y, iters=3)
+            out[threads] = {k: np.array(v) for k, v in reg.get_variables().items()}
+        return out
+
+    got = _on("hip", run)
+    assert got["counts"] == {400: 2, 2047: 2, 2048: 4, 5120: 4, 5121: 2, 16384: 2}
+    for name in got["1"]:
+        assert np.array_equal(got[None][name], got["1"][name]), name
+
+
 def test_predict_reduction_on_device_matches_numpy_reduction():
     """predict = device-side mean / percentiles of the same samples `sample` returns (row a10 of SURVEY section 8):
     same seed -> the HIP reduction equals numpy's on the HIP samples bit for bit, and the oracle's to sample parity."""

@@ -19,13 +19,18 @@ set_engine(eng)
 cases = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(400, 3), (2048, 4)]
 for n, p in cases:
     x, y = synthetic(n, 2, p)
-    for rep in range(2):
+    best = 1e9
+    for rep in range(int(os.environ.get("FIT_REPS", "2"))):   # (the first fit of a process pays one-time costs: the last / best one counts)
         reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         reg.fit(x, y, iters=20)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if rep > 0:
+            best = min(best, dt)
+    if os.environ.get("FIT_REPS"):
+        dt = best
     evals = getattr(optimise, "LAST_EVALUATIONS", None)
     print(f"n={n} p={p}: fit(iters=20) {1e3 * dt:.1f} ms  evaluations {evals}")
     if os.environ.get("PROFILE"):
