@@ -498,6 +498,17 @@ def config_grid_leg(eng, evals=5, warmup=2):
             rec["predict_100_samples_ms"] = 1e3 * (time.perf_counter() - t0)
             rec["predict_n_star"] = 2048
             rec["predict_finite"] = bool(np.isfinite(mean).all())
+            # training at this size: layer by layer, L-BFGS-B, analytic gradient (second fit of the process: the first one pays the
+            # allocator's first big blocks)
+            for rep in range(2):
+                trainee = GPARRegressor(**kw)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                trainee.fit(x_np, y_np, iters=20)
+                torch.cuda.synchronize()
+                rec["fit_20_iters_ms"] = 1e3 * (time.perf_counter() - t0)
+            rec["fit_finite"] = bool(all(np.all(np.isfinite(v)) for v in trainee.get_variables().values()))
+            del trainee
         if name == "C5":
             reg.condition(x_np, y_np)
             xs = np.random.default_rng(2).uniform(0, 1, (2048, m))
@@ -511,7 +522,41 @@ def config_grid_leg(eng, evals=5, warmup=2):
         grid[name] = rec
         del x, y, reg
         torch.cuda.empty_cache()
+    grid["lone_factorisation_ms"] = lone_factorisation_leg(eng)
     return grid
+
+
+def lone_factorisation_leg(eng, sizes=(1024, 2048, 4096, 8192)):
+    """gpar_potrf alone - what every layer of a `fit` and every rank of a layer-parallel evaluation runs - on the augmented
+    (n + 1) x (n + 1) matrix of a log marginal likelihood: best of 5, milliseconds per size."""
+    import torch
+
+    from gpar_amd import hip
+
+    out = {}
+    for n in sizes:
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(n)
+        pts = torch.rand(n, 4, generator=gen, dtype=torch.float64).to(eng.device)
+        K0 = hip.alloc_matrix(n + 1, n + 1, eng.device, zero=True)
+        K0[:n, :n] = torch.exp(-0.5 * torch.cdist(pts, pts) ** 2 / 0.25)
+        K0[:n, :n].diagonal().add_(0.1)
+        K0[n, :n] = torch.sin(5 * pts[:, 0])
+        A = hip.alloc_matrix(n + 1, n + 1, eng.device)
+        best = float("inf")
+        for _ in range(5):
+            A.copy_(K0)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _, info = hip.potrf_(A, nf=n)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        out[str(n)] = best if int(info.item()) == 0 else None
+        del K0, A, pts
+        torch.cuda.empty_cache()
+    return out
 
 
 def _leaf_spec(spec):
