@@ -24,7 +24,7 @@ POTRF_UNFUSED = 2
 WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE, WS_INPUT_GRAD = 1, 2, 3, 4, 5
 GRAD_NACC = GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 LIB_NAME = "libgpar_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -87,6 +87,7 @@ SIGNATURES = {
     "gpar_jit_compile": (ctypes.c_longlong, [_c_int, ctypes.POINTER(KSpec), _c_int, ctypes.c_char_p, _ptr, ctypes.c_longlong, ctypes.c_char_p, _c_int,
                                              ctypes.c_char_p, _c_int]),
     "gpar_aot_stats": (_c_int, [ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    "gpar_aot_fingerprint": (ctypes.c_ulonglong, []),
     "gpar_jit_stats": (_c_int, [ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "gpar_featurize": (_c_int, [ctypes.POINTER(FSpec), _ptr, _c_int, _c_int, _ptr, _c_int, _ptr]),
     "gpar_gram": (

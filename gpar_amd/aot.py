@@ -16,6 +16,7 @@ import time
 
 ARCH = "gfx950"
 ARCHIVE = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"gpar_aot_{ARCH}.bin")
+MAGIC = b"GPARAOT2"   # + u32 ABI version + u64 generator fingerprint (csrc/jit.h): the library ignores an archive that is not its own
 
 # keyword families (everything else at its default); the BASELINE configurations are members: C2 = "linear" at m = 2, C3 = "nonlinear"
 # with markov = 2 at m = 4, C4 = "nonlinear" at m = 8 (+ the sparse kinds), C5 = "per_rq" at m = 3
@@ -113,9 +114,13 @@ def build(jobs_n=None, quiet=False):
                 entries[got[0]] = got[1]
     if errors:
         raise RuntimeError(f"{len(errors)} kernels failed to compile, e.g. {errors[0]}")
+    from . import _lib
+
+    lib = _lib.load()
     tmp = ARCHIVE + ".tmp"
     with open(tmp, "wb") as f:
-        f.write(b"GPARAOT1")
+        f.write(MAGIC)
+        f.write(struct.pack("<IQ", lib.gpar_abi_version(), lib.gpar_aot_fingerprint()))
         f.write(struct.pack("<I", len(ARCH)) + ARCH.encode())
         f.write(struct.pack("<I", len(entries)))
         for key in sorted(entries):
@@ -127,12 +132,32 @@ def build(jobs_n=None, quiet=False):
     return len(entries)
 
 
+def read_header(path=ARCHIVE):
+    """(ABI version, generator fingerprint) an archive was built for, or None if there is no readable archive of this format."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(20)
+    except OSError:
+        return None
+    if len(head) < 20 or head[:8] != MAGIC:
+        return None
+    return struct.unpack_from("<IQ", head, 8)
+
+
+def is_current(path=ARCHIVE):
+    """Does the archive belong to the library next to it?  (The library applies the same test before it uses one.)"""
+    from . import _lib
+
+    lib = _lib.load()
+    return read_header(path) == (lib.gpar_abi_version(), lib.gpar_aot_fingerprint())
+
+
 def read_keys(path=ARCHIVE):
     """Keys of an archive (for tests)."""
     with open(path, "rb") as f:
         blob = f.read()
-    assert blob[:8] == b"GPARAOT1"
-    at = 8
+    assert blob[:8] == MAGIC
+    at = 8 + 12
     (alen,) = struct.unpack_from("<I", blob, at)
     at += 4
     arch = blob[at:at + alen].decode()

@@ -443,6 +443,38 @@ long long gpar_jit_compile(int kind, const gpar_kspec_t* ks, int dz, const char*
     return (long long)code.size();
 }
 
+// Fingerprint of the kernel generators: FNV-1a over the sources of every kernel kind for one probe structure that uses every factor
+// type (EQ x RQ product, a linear term, a constant term; six feature dims), + the ABI version.  Pure host code, needs no GPU.
+unsigned long long gpar::aot_fingerprint() {
+    static unsigned long long cached = 0ull;
+    if (cached) return cached;
+    gpar_kspec_t ks;
+    memset(&ks, 0, sizeof ks);
+    ks.nterms = 3;
+    ks.nfactors = 3;
+    ks.coef[0] = 1.0; ks.coef[1] = 1.0; ks.coef[2] = 1.0;
+    ks.factor[0] = gpar_factor_t{GPAR_K_EQ, 0, 0, 2, 0.0};
+    ks.factor[1] = gpar_factor_t{GPAR_K_RQ, 0, 2, 2, 0.5};
+    ks.factor[2] = gpar_factor_t{GPAR_K_LINEAR, 1, 4, 2, 0.0};
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const std::string& text) {
+        for (unsigned char ch : text) h = (h ^ ch) * 1099511628211ull;
+        h = (h ^ 0xffu) * 1099511628211ull;
+    };
+    const int kinds[] = {JIT_GRAM, JIT_GRAD, JIT_GRAD + 10, JIT_GRAD + 20, JIT_GRAD + 30, JIT_INPUT_GRAD, JIT_INPUT_GRAD + 10};
+    for (int kind : kinds) {
+        std::string source, entry;
+        int jkind = 0, extra = 0;
+        if (jit_request(kind, ks, 6, jkind, extra, entry, source, true)) mix(entry + "\n" + source);
+        else mix("-");
+    }
+    mix("abi " + std::to_string(GPAR_ABI_VERSION));
+    cached = h ? h : 1ull;
+    return cached;
+}
+
+unsigned long long gpar_aot_fingerprint(void) { return gpar::aot_fingerprint(); }
+
 int gpar_aot_stats(int* entries, int* loaded) {
     GPAR_API_GUARD_NOSTREAM;
     if (entries) *entries = (int)g_aot.entries.size();

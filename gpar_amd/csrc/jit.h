@@ -89,14 +89,19 @@ static bool jit_compile(const std::string& source, const char* name, const std::
 // produce, and kept as an archive of code objects next to the library (gpar_aot_<arch>.bin).  A structure found there costs a
 // hipModuleLoadData (~1 ms) instead of 0.3-0.6 s of hiprtc at first use - so it is used at EVERY problem size, not only where a
 // training run repays a compilation: below n = 4096 the interpreting gradient kernels run at 397 / 380 registers with spills.
-// Archive: "GPARAOT1", u32 arch length + arch, u32 count, then per entry u32 key length + key ("<kind>#<signature>"), u64 code
-// size + code object.  Anything unreadable is ignored (hiprtc then serves, as before).
+// Archive: "GPARAOT2", u32 ABI version, u64 generator fingerprint, u32 arch length + arch, u32 count, then per entry u32 key length +
+// key ("<kind>#<signature>"), u64 code size + code object.  The fingerprint (aot_fingerprint() in gpar_hip.hip) hashes the sources
+// this library GENERATES for a probe structure that exercises every factor type and kernel kind: an archive written by a library
+// whose generators (gram_jit.h, grad_jit.h, gram_math.inc) or ABI differ is ignored, whatever the file dates say - its code
+// objects could have another argument layout or other arithmetic.  Anything unreadable is ignored too (hiprtc then serves).
+static unsigned long long aot_fingerprint();   // gpar_hip.hip (needs the source generators)
 struct AotState {
     bool tried = false;
     std::string arch;
     std::vector<char> blob;
     std::map<std::string, std::pair<size_t, size_t>> entries;   // key -> (offset, size) into blob
     int loaded = 0;
+    bool stale = false;   // an archive was found and rejected: other ABI version or generator fingerprint
 };
 static AotState g_aot;
 
@@ -122,10 +127,16 @@ static void aot_init(const std::string& arch) {
     std::vector<char> blob(size > 0 ? (size_t)size : 0);
     const bool read_ok = size > 0 && fread(blob.data(), 1, (size_t)size, f) == (size_t)size;
     fclose(f);
-    if (!read_ok || blob.size() < 16 || memcmp(blob.data(), "GPARAOT1", 8) != 0) return;
+    if (!read_ok || blob.size() < 32 || memcmp(blob.data(), "GPARAOT2", 8) != 0) return;
     size_t at = 8;
     auto u32 = [&](uint32_t& v) { if (at + 4 > blob.size()) return false; memcpy(&v, &blob[at], 4); at += 4; return true; };
     auto u64 = [&](uint64_t& v) { if (at + 8 > blob.size()) return false; memcpy(&v, &blob[at], 8); at += 8; return true; };
+    uint32_t abi = 0;
+    uint64_t fingerprint = 0;
+    if (!u32(abi) || !u64(fingerprint) || abi != (uint32_t)GPAR_ABI_VERSION || fingerprint != (uint64_t)aot_fingerprint()) {
+        g_aot.stale = true;
+        return;
+    }
     uint32_t alen = 0, count = 0;
     if (!u32(alen) || at + alen > blob.size()) return;
     const std::string built_for(&blob[at], alen);

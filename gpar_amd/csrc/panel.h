@@ -45,6 +45,7 @@ struct PanelArgs {
     long long batch_a = 0;   // batched launch (panel2.h, gridDim.y matrices of the same shape): matrix y starts at A + y * batch_a,
                              // its logdet / info words are logdet[y], info[y]
     int pairs = 0;           // panel2.h: bulk row blocks take their column blocks in pairs (p2_row_block_pairs)
+    int progressive = 0;     // panel2.h: a diagonal tile is handed to the next team row in four block columns while it is being factored (P3Publish)
 };
 
 __device__ __forceinline__ unsigned long long* pnl_flag(const PanelArgs& p, int f) {

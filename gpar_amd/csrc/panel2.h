@@ -79,8 +79,11 @@ __device__ __forceinline__ void p2_gstore(double* __restrict__ M, int ld, int nr
             const pan_d2 v = *reinterpret_cast<const pan_d2*>(src + r * PNL_LD + cc);
             double* dst = M + (size_t)(r0 + r) * ld + c0 + cc;
             if (through) {
-                // one 16-byte write-through store (an 8-byte sc1 store costs a fabric write of its own: 2.7x per byte)
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+                // one 16-byte write-through store (an 8-byte sc1 store costs a fabric write of its own: 2.7x per byte).  Every asm
+                // store of more than 8 bytes in this file ends with `s_nop 1`: the data registers are read over several cycles and
+                // the compiler, which does not look inside asm, may otherwise overwrite them with its next instruction (seen in
+                // round 5: the low word of one double in ~1e5 stores zeroed - 1e-7 relative -, only in some launches).
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(dst), "v"(v) : "memory");
             } else {
                 *reinterpret_cast<pan_d2*>(dst) = v;
             }
@@ -236,8 +239,9 @@ __device__ __forceinline__ int p2_flag_slot(int jb) { return PNL_LD + 16 + jb; }
 //       result going from the accumulators of the first product straight into the B operand of the second.
 // A 16-step substitution on the vector ALUs needs 120 wave-uniform LDS reads per wave (every one a full LDS instruction):
 // 2 us with four waves at it, on the critical chain of every 64 columns; this form takes a quarter of that.
-__device__ __forceinline__ void p2_inverse_blocks(double* __restrict__ Cs, int w, int lane) {
-    const int l15 = lane & 15, lk = lane >> 4;
+// (the two phases are separate functions because the panel's diagonal-tile owner runs them in different rounds of p3_diag)
+__device__ __forceinline__ void p2_inverse_sub(double* __restrict__ Cs, int w, int lane) {
+    const int l15 = lane & 15;
     const int base = 16 * w;
     double* W = Cs + p2_wblock(w);
     {
@@ -255,15 +259,20 @@ __device__ __forceinline__ void p2_inverse_blocks(double* __restrict__ Cs, int w
             mx = fmax(mx, __shfl_xor(mx, 8, 64));
             if (lane == 0) Cs[p2_flag_slot(w)] = (mx > P2_REFINE_RATIO * mn) ? 1.0 : 0.0;
         }
-        double x[8];
+        double x[8], rp[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = (i == j) ? 1.0 : 0.0;
+        // the eight reciprocal pivots ahead of the substitution (independent of it: eight pipelined v_rcp_f64 + Newton steps instead
+        // of one dependent chain per step; same operations, same bits)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rp[k] = __builtin_amdgcn_rcp(c[k][k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rp[k] = fma(fma(-c[k][k], rp[k], 1.0), rp[k], rp[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rp[k] = fma(fma(-c[k][k], rp[k], 1.0), rp[k], rp[k]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const double d = c[k][k];
-            double r = __builtin_amdgcn_rcp(d);
-            r = fma(fma(-d, r, 1.0), r, r);
-            r = fma(fma(-d, r, 1.0), r, r);
+            const double r = rp[k];
             const double xk = x[k] * r;
             x[k] = xk;
 #pragma unroll
@@ -275,9 +284,12 @@ __device__ __forceinline__ void p2_inverse_blocks(double* __restrict__ Cs, int w
 #pragma unroll
         for (int i = 0; i < 8; ++i) W[i * PNL_LD + 8 + (l15 & 7)] = 0.0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void p2_inverse_couple(double* __restrict__ Cs, int w, int lane) {
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int base = 16 * w;
+    double* W = Cs + p2_wblock(w);
     // P = Lba Wa: rows 8 .. 15 (registers 2, 3 of the D layout), columns 0 .. 7
     pan_d4 P = pan_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -299,36 +311,52 @@ __device__ __forceinline__ void p2_inverse_blocks(double* __restrict__ Cs, int w
     }
 }
 
+__device__ __forceinline__ void p2_inverse_blocks(double* __restrict__ Cs, int w, int lane) {
+    p2_inverse_sub(Cs, w, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    p2_inverse_couple(Cs, w, lane);
+}
+
 // T (this wave's 16 rows x 64 columns, T layout) <- X^T with X L^T = T, L the lower-triangular tile in Cs whose diagonal
 // 16 x 16 blocks have their inverses at p2_wblock().
-__device__ __forceinline__ void p2_strip(const double* __restrict__ Cs, pan_d4 (&T)[4], int l15, int lk) {
+// (one 16-column block of the strip, JB = 0 .. 3 in this order; a team row that follows the diagonal tile's owner block by block -
+// p2_row_block, progressive hand-off - calls the steps one at a time)
+template <int JB>
+__device__ __forceinline__ void p2_strip_step(const double* __restrict__ Cs, pan_d4 (&T)[4], int l15, int lk) {
+    constexpr int jb = JB;
+    const double* W = Cs + p2_wblock(jb);
+    pan_d4 x = pan_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-        const double* W = Cs + p2_wblock(jb);
-        pan_d4 x = pan_d4{0.0, 0.0, 0.0, 0.0};
+    for (int k4 = 0; k4 < 4; ++k4)
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(W[l15 * PNL_LD + 4 * k4 + lk], T[jb][k4], x, 0, 0, 0);
+    if (Cs[p2_flag_slot(jb)] != 0.0) {   // (wave-uniform) an ill-conditioned block: x += W (t - L_bb x)
+        pan_d4 r = T[jb];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int k = 4 * k4 + lk;
+            const double l = Cs[(16 * jb + l15) * PNL_LD + 16 * jb + k];   // L_bb[m = l15][k]; above its diagonal the tile holds scratch
+            r = __builtin_amdgcn_mfma_f64_16x16x4f64(k <= l15 ? -l : 0.0, x[k4], r, 0, 0, 0);
+        }
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4)
-            x = __builtin_amdgcn_mfma_f64_16x16x4f64(W[l15 * PNL_LD + 4 * k4 + lk], T[jb][k4], x, 0, 0, 0);
-        if (Cs[p2_flag_slot(jb)] != 0.0) {   // (wave-uniform) an ill-conditioned block: x += W (t - L_bb x)
-            pan_d4 r = T[jb];
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const int k = 4 * k4 + lk;
-                const double l = Cs[(16 * jb + l15) * PNL_LD + 16 * jb + k];   // L_bb[m = l15][k]; above its diagonal the tile holds scratch
-                r = __builtin_amdgcn_mfma_f64_16x16x4f64(k <= l15 ? -l : 0.0, x[k4], r, 0, 0, 0);
-            }
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4)
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(W[l15 * PNL_LD + 4 * k4 + lk], r[k4], x, 0, 0, 0);
-        }
-        T[jb] = x;
-#pragma unroll
-        for (int j2 = jb + 1; j2 < 4; ++j2) {
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4)
-                T[j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Cs[(16 * j2 + l15) * PNL_LD + 16 * jb + 4 * k4 + lk], x[k4], T[j2], 0, 0, 0);
-        }
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(W[l15 * PNL_LD + 4 * k4 + lk], r[k4], x, 0, 0, 0);
     }
+    T[jb] = x;
+#pragma unroll
+    for (int j2 = jb + 1; j2 < 4; ++j2) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+            T[j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Cs[(16 * j2 + l15) * PNL_LD + 16 * jb + 4 * k4 + lk], x[k4], T[j2], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void p2_strip(const double* __restrict__ Cs, pan_d4 (&T)[4], int l15, int lk) {
+    p2_strip_step<0>(Cs, T, l15, lk);
+    p2_strip_step<1>(Cs, T, l15, lk);
+    p2_strip_step<2>(Cs, T, l15, lk);
+    p2_strip_step<3>(Cs, T, l15, lk);
 }
 
 // ---- the diagonal-tile factorisation: wave-uniform coefficients through DPP ------------------------------------------
@@ -654,10 +682,98 @@ __device__ __forceinline__ void p3_diag_block(double (&acc)[8], const double (&p
     }
 }
 
+// ---- inverse blocks for free, and the progressive hand-off of the diagonal tile (panel kernels) --------------------------------
+// (1) The strips need the inverses W_b of the four diagonal 16 x 16 blocks of the tile (p2_strip).  They used to be computed after
+// the factorisation (p2_inverse_blocks: 8 x 8 substitutions + a coupling product, ~1 us on the chain of every 64 columns).  Now
+// they fall out of the factorisation itself: a row e_i appended to the tile is turned by the very column operations of the
+// factorisation into  e_i L^-T = column i of L^-1,  and wave 0 has idle lanes to carry such rows - lanes 8-15 of its DPP row R hold
+// tile rows 8 R .. 8 R + 7, which are dead (above the block, or the replicated rows themselves) from round R on.  Block b (rounds
+// 2 b and 2 b + 1) uses DPP rows 2 (b & 1) ("A": e_0 .. e_7, carried through both rounds) and 2 (b & 1) + 1 ("B": e_8 .. e_15,
+// second round only); at the end of round 2 b + 1 they write W_b.  Same instruction stream, no extra instructions on the chain.
+// (2) The team row that factors NEXT needs this tile for the last strip of its row block, and that strip consumes the tile in four
+// 16-column blocks (p2_strip_step).  Block column b - rows 16 b .. 63 of columns 16 b .. 16 b + 15 with W_b and its refinement flag -
+// is complete in LDS at the end of round 2 b + 1: wave 3 stores it (write-through) in round 2 b + 2 and announces it in round
+// 2 b + 3, while the later columns are still being factored; the follower's strip, its share of X X^T and the hand-off latency run
+// beside the factorisation instead of behind it.  The progress word counts QUARTERS of a column block for that reason.
+// (The replicated rows of a round reach the tile in LDS one round late - see below; wave 0 also leaves them in the 8 x 8 scratch
+// block S right away, which is where wave 3 takes the last diagonal 8 x 8 block of a block column from.)
+struct P3Publish {
+    double* dst = nullptr;             // the tile in global memory (row r0, column of the diagonal block); nullptr: nothing is published here
+    int ld = 0, rows = 0;              // leading dimension; valid rows from r0
+    unsigned long long* word = nullptr;
+    unsigned long long base = 0ull;    // word value that means "every strip of this row block is out" (4 * trow)
+};
+
+// refinement flag of diagonal block b (see P2_REFINE_RATIO): one wave; S != nullptr: its last eight pivots are still on their way
+// to the tile and are read from the scratch block
+__device__ __forceinline__ void p3_block_flag(double* __restrict__ T, const double* __restrict__ S, int b, int lane) {
+    const int l = lane & 15;
+    double d = (S && l >= 8) ? S[(l - 8) * 8 + (l - 8)] : T[(16 * b + l) * PNL_LD + 16 * b + l];
+    double mn = d, mx = d;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, off, 64));
+        mx = fmax(mx, __shfl_xor(mx, off, 64));
+    }
+    if (lane == 0) T[p2_flag_slot(b)] = (mx > P2_REFINE_RATIO * mn) ? 1.0 : 0.0;
+}
+
+// wave-wide (64 lanes): block column b of the lower-triangular tile T, the inverse block W_b and its refinement flag, write-through
+__device__ __forceinline__ void p3_store_column(const double* __restrict__ T, const double* __restrict__ S, int b, int lane, const P3Publish& pub) {
+    const int r8 = lane >> 3, c2 = (lane & 7) * 2;
+    pan_d2 v[8], wv[2];
+    const int cc = 16 * b + c2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = min(16 * b + 8 * i + r8, 63);
+        v[i] = *reinterpret_cast<const pan_d2*>(T + r * PNL_LD + cc);
+    }
+    if (S && c2 >= 8) v[1] = *reinterpret_cast<const pan_d2*>(S + r8 * 8 + (c2 - 8));   // rows 16 b + 8 .., columns 16 b + 8 ..: the late block
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wv[q] = *reinterpret_cast<const pan_d2*>(T + (16 * (b >> 1) + 8 * q + r8) * PNL_LD + 32 + 16 * (b & 1) + c2);
+    const double fl = T[p2_flag_slot(b)];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = 16 * b + 8 * i + r8;
+        if (r < 64 && cc <= r && r < pub.rows) {
+            double* dst = pub.dst + (size_t)r * pub.ld + cc;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(dst), "v"(v[i]) : "memory");
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = 16 * (b >> 1) + 8 * q + r8;
+        if (r < pub.rows) {
+            double* dst = pub.dst + (size_t)r * pub.ld + 32 + 16 * (b & 1) + c2;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(dst), "v"(wv[q]) : "memory");
+        }
+    }
+    if (lane == 0 && 1 < pub.rows) {
+        double* dst = pub.dst + (size_t)pub.ld + 16 + b;
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(fl) : "memory");
+    }
+}
+
+// blocks (mi, ni), mi >= ni >= n0, in the order ni-major: the idx-th one
+__device__ __forceinline__ void p3_update_block(int n0, int idx, int& mi, int& ni) {
+    ni = n0;
+    int left = idx;
+    while (left >= 4 - ni) { left -= 4 - ni; ++ni; }
+    mi = ni + left;
+}
+
 template <bool STAMP = false>
-__device__ __forceinline__ void p3_diag(double* __restrict__ T, int col0, const PanelArgs& p, int t, long long* __restrict__ st = nullptr) {
+__device__ __forceinline__ void p3_diag(double* __restrict__ T, int col0, const PanelArgs& p, int t, long long* __restrict__ st = nullptr,
+                                        double* __restrict__ S = nullptr, const P3Publish pub = P3Publish()) {
     const int lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
-    double held[8];   // threads 0-7: the replicated rows' results of the previous round, not yet in LDS (see below)
+    const bool progressive = pub.dst != nullptr && S != nullptr;
+    // dev aid (tools/time_panel2.hip): column 9 = the publishing wave's phases, column 10 = end of every round
+#define P3_STAMP(col, k)                                                                                             \
+    do {                                                                                                              \
+        if (p.stamps && blockIdx.x < 16) p.stamps[((size_t)blockIdx.x * 17 + (col)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    double held[8];   // the lane's results of the previous round (threads 0-7: the replicated rows, not yet in the tile; wave 0's
+                      // identity lanes: the first half of their row of the inverse)
 #pragma unroll
     for (int q = 0; q < 8; ++q) held[q] = 0.0;
     for (int jb = 0; jb < 8; ++jb) {
@@ -669,6 +785,10 @@ __device__ __forceinline__ void p3_diag(double* __restrict__ T, int col0, const 
             const pan_d2* src = reinterpret_cast<const pan_d2*>(&T[row * PNL_LD + 8 * jb]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
+            // identity rows (see (1) above): block bq = jb / 2, its first (half = 0) or second round
+            const int bq = jb >> 1, half = jb & 1, ga = 2 * (bq & 1), ii = l15 - 8;
+            const bool idl = w == 0 && l15 >= 8;
+            const bool idA = idl && lk == ga, idB = idl && lk == ga + 1;
             if (jb > 0) {
                 const pan_d2* ps = reinterpret_cast<const pan_d2*>(&T[row * PNL_LD + 8 * (jb - 1)]);
 #pragma unroll
@@ -682,8 +802,25 @@ __device__ __forceinline__ void p3_diag(double* __restrict__ T, int col0, const 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) hd[q] = pan_d2{held[2 * q], held[2 * q + 1]};
                 }
+                if (idA) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        prev[q] = half ? held[q] : 0.0;
+                        acc[q] = (!half && q == ii) ? 1.0 : 0.0;
+                    }
+                } else if (idB && half) {   // (in the block's first round these lanes still hold live rows of the tile)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        prev[q] = 0.0;
+                        acc[q] = (q == ii) ? 1.0 : 0.0;
+                    }
+                }
                 p3_diag_block<true>(acc, prev);
             } else {
+                if (idA) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = (q == ii) ? 1.0 : 0.0;
+                }
                 p3_diag_block<false>(acc, prev);
             }
             // rows below the block: written by their only holder (rows above it carry the strict upper triangle's scratch
@@ -694,29 +831,92 @@ __device__ __forceinline__ void p3_diag(double* __restrict__ T, int col0, const 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
             }
+            if (t < 8 && S && half) {   // (the publishing wave reads the block's last diagonal 8 x 8 block from here in the NEXT round;
+                                        // written in odd rounds only, so that it is not overwritten while being read)
+                pan_d2* sd = reinterpret_cast<pan_d2*>(&S[t * 8]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sd[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
+            }
+            if (half && (idA || idB)) {   // W_bq = (L_bq)^-1: lane i of A holds column i (rows 0-7 from the first round), lane i of B column 8 + i
+                double* Wb = T + p2_wblock(bq);
+                if (idA) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { Wb[j * PNL_LD + ii] = prev[j]; Wb[(8 + j) * PNL_LD + ii] = acc[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { Wb[j * PNL_LD + 8 + ii] = 0.0; Wb[(8 + j) * PNL_LD + 8 + ii] = acc[j]; }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) held[q] = acc[q];
             if (STAMP && t == 0) st[3 * jb + 2] = (long long)__builtin_readcyclecounter();
-        } else if (w >= 2 && jb > 0) {
-            // T[mi][ni] -= L[mi][jb - 1] L[ni][jb - 1]^T  (K = 8) for the 16 x 16 blocks that reach columns >= 8 jb + 8
-            const int c0 = 8 * jb + 8, kb = 8 * (jb - 1) + lk;
-            int idx = 0;
-            for (int ni = c0 >> 4; ni < 4; ++ni)
-                for (int mi = ni; mi < 4; ++mi, ++idx) {
-                    if ((idx & 1) != (w & 1)) continue;
-                    double* C = &T[(16 * mi + lk) * PNL_LD + 16 * ni + l15];
-                    pan_d4 c = pan_d4{C[0], C[4 * PNL_LD], C[8 * PNL_LD], C[12 * PNL_LD]};
-                    const double* a = &T[(16 * mi + l15) * PNL_LD + kb];
-                    const double* b = &T[(16 * ni + l15) * PNL_LD + kb];
-                    const double a0 = -a[0], a1 = -a[4], b0 = b[0], b1 = b[4];
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
-                    if (16 * ni + l15 >= c0) { C[0] = c[0]; C[4 * PNL_LD] = c[1]; C[8 * PNL_LD] = c[2]; C[12 * PNL_LD] = c[3]; }
+        } else if (w >= 2) {
+            if (progressive && w == 3 && jb >= 2) {   // the publishing wave: block column (jb - 2) / 2 out, then announced
+                if (lane == 0) P3_STAMP(9, jb - 2);
+                if ((jb & 1) == 0) {
+                    const int b = (jb - 2) >> 1;
+                    p3_block_flag(T, S, b, lane);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    p3_store_column(T, S, b, lane, pub);
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(pub.word, pub.base + (unsigned long long)((jb - 1) >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            }
+            if (jb > 0) {
+                // T[mi][ni] -= L[mi][jb - 1] L[ni][jb - 1]^T  (K = 8) for the 16 x 16 blocks that reach columns >= 8 jb + 8: 6, 6, 3, 3, 1, 1, 0
+                // of them, dealt alternately over waves 2 and 3; a wave's (at most three) blocks are loaded together, multiplied,
+                // stored - one LDS round trip per round instead of one per block.
+                const int c0 = 8 * jb + 8, kb = 8 * (jb - 1) + lk, n0 = c0 >> 4;
+                const int nblk = (4 - n0) * (5 - n0) / 2;
+                pan_d4 c[3];
+                double a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl) {
+                    const int idx = 2 * sl + (w & 1);
+                    if (idx < nblk) {
+                        int mi, ni;
+                        p3_update_block(n0, idx, mi, ni);
+                        const double* C = &T[(16 * mi + lk) * PNL_LD + 16 * ni + l15];
+                        c[sl] = pan_d4{C[0], C[4 * PNL_LD], C[8 * PNL_LD], C[12 * PNL_LD]};
+                        const double* a = &T[(16 * mi + l15) * PNL_LD + kb];
+                        const double* b = &T[(16 * ni + l15) * PNL_LD + kb];
+                        a0[sl] = -a[0]; a1[sl] = -a[4]; b0[sl] = b[0]; b1[sl] = b[4];
+                    }
+                }
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl) {
+                    const int idx = 2 * sl + (w & 1);
+                    if (idx < nblk) {
+                        c[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[sl], b0[sl], c[sl], 0, 0, 0);
+                        c[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[sl], b1[sl], c[sl], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl) {
+                    const int idx = 2 * sl + (w & 1);
+                    if (idx < nblk) {
+                        int mi, ni;
+                        p3_update_block(n0, idx, mi, ni);
+                        double* C = &T[(16 * mi + lk) * PNL_LD + 16 * ni + l15];
+                        if (16 * ni + l15 >= c0) { C[0] = c[sl][0]; C[4 * PNL_LD] = c[sl][1]; C[8 * PNL_LD] = c[sl][2]; C[12 * PNL_LD] = c[sl][3]; }
+                    }
+                }
+            }
         }
         __syncthreads();
+        if (t == 0) P3_STAMP(10, jb);
     }
+#undef P3_STAMP
+}
+
+// log-determinant share and LAPACK-style info of a factored diagonal tile (wave 0; off the hand-off chain: called after the tile
+// has been published)
+__device__ __forceinline__ void p3_diag_logdet(const double* __restrict__ T, int col0, const PanelArgs& p, int t) {
     if (t < 64) {
+        const int lane = t;
         const double mydiag = T[lane * PNL_LD + lane];
         const unsigned long long badmask = __ballot(!(mydiag > 0.0));
         double ld = 2.0 * log(mydiag);
@@ -730,12 +930,16 @@ __device__ __forceinline__ void p3_diag(double* __restrict__ T, int col0, const 
 }
 
 // Tiles (mi, ni), mi >= ni, of a 64 x 64 lower triangle dealt over the four waves: slot q of wave w.
-//   w0: (0,0) (1,0) (2,0)    w1: (1,1) (2,1) (3,0)    w2: (2,2) (3,1)    w3: (3,3) (3,2)
+//   w0: (0,0) (1,0) (2,0)    w1: (1,1) (2,1) (3,1)    w2: (2,2) (3,2)    w3: (3,3) (3,0)
+// Every tile belongs to a wave that holds one of its two row groups (wave w owns rows 16 w .. 16 w + 15 of the row block): in the
+// progressive last strip that operand comes straight from the strip's registers (the T layout IS an MFMA operand), the diagonal
+// tile (w, w) needs no LDS read at all.  Waves 0 - 2 hold the N side (ni = w), wave 3's second tile the M side (mi = 3).
 __device__ __forceinline__ int p2_dtile_m(int w, int q) { return q == 0 ? w : (w == 0 ? q : (w == 1 ? q + 1 : 3)); }
-__device__ __forceinline__ int p2_dtile_n(int w, int q) { return q == 0 ? w : (w == 0 ? 0 : (w == 1 ? (q == 1 ? 1 : 0) : (w == 2 ? 1 : 2))); }
+__device__ __forceinline__ int p2_dtile_n(int w, int q) { return q == 0 ? w : (w == 3 ? 0 : w); }
 
-// ---- progress words: prog[t] = number of column blocks team row t has completed and published (u strips, then the
-// diagonal block: t + 1 means L[t][t] is out).  They live where the first generation kept its flags (pnl_flag).
+// ---- progress words: prog[t] = 4 x the number of column blocks team row t has completed and published (u strips, then the
+// diagonal block: 4 (t + 1) means L[t][t] is out; 4 t + b, b = 1 .. 3: the first b block columns of the diagonal tile with their
+// inverse blocks are out - the progressive hand-off of p3_diag).  They live where the first generation kept its flags (pnl_flag).
 __device__ __forceinline__ void p2_publish(const PanelArgs& p, int trow, unsigned long long value) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -794,6 +998,8 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
         if (FLAGS && p.stamps && t == 0 && blockIdx.x < 16)                                                           \
             p.stamps[((size_t)blockIdx.x * 17 + (col)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime();      \
     } while (0)
+    const bool progressive = FLAGS && TEAM && p.progressive;
+    bool parked = false;   // TEAM: the row block's diagonal tile is in Cs and the last X is on its way out (progressive last strip)
     for (int c = ufirst; c < ncol; ++c) {
         P2_STAMP(c, 0);
         pan_d4 acc[4];
@@ -802,7 +1008,7 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
         pan_d2 xa[8];   // the row block's own tile of column block u (operand of chunk u), finally of column block c itself
         p2_gload(B, ldb, brows, r0, bc0 + 64 * ufirst, t, xa);
         if (c > ufirst) {
-            if (FLAGS) p2_wait(p, seen, c, (unsigned long long)c);   // every L[c][u], u < c, is out
+            if (FLAGS) p2_wait(p, seen, c, 4ull * (unsigned long long)c);   // every L[c][u], u < c, is out
             pan_d2 la[8];
             p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * ufirst, t, la);
             for (int u = ufirst; u < c; ++u) {
@@ -827,8 +1033,92 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int v = 0; v < 4; ++v) T[mi][v] = Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] - acc[mi][v];
+        const bool last = TEAM && c == ncol - 1;
+        if (last && progressive) {
+            // ---- the strip that the NEXT diagonal tile waits for, block column by block column behind the owner of L[c][c] (see
+            // P3Publish): per 16-column block  wait -> its rows of the triangle + its inverse block into Cs -> strip step -> the
+            // block's columns of X into Xs and out -> its K = 16 share of D = X X^T, operands from the strip's registers.
+            // Same products in the same order as the one-piece path below: the same bits.
+            pan_d2 dt[8];   // the row block's own diagonal tile: requested ahead of everything, rides in 32 registers
+            p2_gload(B, ldb, brows, r0, bc0 + 64 * trow, t, dt);
+            const double* Lt = L + (size_t)(lr0 + 64 * c) * ldl + lc0 + 64 * c;
+            const int lvalid = lrows - (lr0 + 64 * c);   // valid rows of that tile (a team row's diagonal tile: 64)
+            auto fetch = [&](int jb) {
+                // rows 16 jb .. 63 of columns 16 jb .. 16 jb + 15 (512 pairs at most), W_jb (128 pairs), the refinement flag
+                pan_d2 v0, v1, v2;
+                const int e0 = t, e1 = t + 256;
+                const int ra = 16 * jb + (e0 >> 3), rb_ = 16 * jb + (e1 >> 3), cc = 16 * jb + (e0 & 7) * 2;
+                v0 = *reinterpret_cast<const pan_d2*>(Lt + (size_t)min(ra, lvalid - 1) * ldl + cc);
+                v1 = *reinterpret_cast<const pan_d2*>(Lt + (size_t)min(min(rb_, 63), lvalid - 1) * ldl + cc);
+                const int wr = 16 * (jb >> 1) + ((t & 127) >> 3), wc = 32 + 16 * (jb & 1) + (t & 7) * 2;
+                v2 = *reinterpret_cast<const pan_d2*>(Lt + (size_t)min(wr, lvalid - 1) * ldl + wc);
+                double fl = 0.0;
+                if (t == 255) fl = Lt[(size_t)min(1, lvalid - 1) * ldl + 16 + jb];
+                if (ra < 64) *reinterpret_cast<pan_d2*>(Cs + ra * PNL_LD + cc) = v0;
+                if (rb_ < 64) *reinterpret_cast<pan_d2*>(Cs + rb_ * PNL_LD + cc) = v1;
+                if (t < 128) *reinterpret_cast<pan_d2*>(Cs + wr * PNL_LD + wc) = v2;
+                if (t == 255) Cs[p2_flag_slot(jb)] = fl;
+            };
+            auto xout = [&](int jb) {   // columns 16 jb .. + 15 of X: own rows -> Xs (all rows -> global after the next barrier)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * jb + lk + 4 * v] = T[jb][v];
+            };
+            auto xstore = [&](int jb) {   // 64 rows x 16 columns, write-through: 512 pairs
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = t + 256 * q, r = e >> 3, cc = 16 * jb + (e & 7) * 2;
+                    if (r0 + r < brows) {
+                        const pan_d2 v = *reinterpret_cast<const pan_d2*>(Xs + r * PNL_LD + cc);
+                        double* dst = B + (size_t)(r0 + r) * ldb + bc0 + 64 * c + cc;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(dst), "v"(v) : "memory");
+                    }
+                }
+            };
+            auto dself = [&](int jb) {   // the wave's diagonal tile (w, w): both operands are the strip's own registers
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) dacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(T[jb][k4], T[jb][k4], dacc[0], 0, 0, 0);
+            };
+            auto dcross = [&](int jb) {   // the other tiles: one operand from registers, the other wave's rows from Xs
+#pragma unroll
+                for (int q = 1; q < 3; ++q) {
+                    if (q == 2 && w >= 2) continue;
+                    const int other = (w == 3) ? p2_dtile_n(w, q) : p2_dtile_m(w, q);
+                    const double* xo = Xs + (16 * other + l15) * PNL_LD + 16 * jb + lk;
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const double o = xo[4 * k4];
+                        dacc[q] = (w == 3) ? __builtin_amdgcn_mfma_f64_16x16x4f64(T[jb][k4], o, dacc[q], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f64_16x16x4f64(o, T[jb][k4], dacc[q], 0, 0, 0);
+                    }
+                }
+            };
+#define P2_PROGRESSIVE_STEP(JB)                                                                                  \
+            p2_wait(p, seen, c, 4ull * (unsigned long long)c + (unsigned long long)(JB) + 1ull);                 \
+            if ((JB) == 0) P2_STAMP(c, 2);                                                                       \
+            if ((JB) == 3) P2_STAMP(c, 3);                                                                       \
+            fetch(JB);                                                                                           \
+            __syncthreads();                                                                                     \
+            p2_strip_step<JB>(Cs, T, l15, lk);                                                                   \
+            xout(JB);                                                                                            \
+            dself(JB);                                                                                           \
+            __syncthreads();                                                                                     \
+            if ((JB) == 3) P2_STAMP(c, 4);                                                                       \
+            xstore(JB);                                                                                          \
+            dcross(JB);
+            P2_PROGRESSIVE_STEP(0)
+            P2_PROGRESSIVE_STEP(1)
+            P2_PROGRESSIVE_STEP(2)
+            P2_PROGRESSIVE_STEP(3)
+#undef P2_PROGRESSIVE_STEP
+            P2_STAMP(c, 5);   // diagonal-tile accumulation done
+            __syncthreads();  // every wave is done with the triangle in Cs
+            p2_sstore(Cs, t, dt);
+            parked = true;
+            P2_STAMP(c, 6);
+            continue;
+        }
         // the triangle to solve against
-        if (FLAGS) p2_wait(p, seen, c, (unsigned long long)c + 1);
+        if (FLAGS) p2_wait(p, seen, c, 4ull * (unsigned long long)c + 4ull);
         else __syncthreads();
         P2_STAMP(c, 2);   // triangle available
         {
@@ -852,7 +1142,6 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
         // A team row block's last strip: its diagonal tile is requested BEFORE the write-through stores of X (memory
         // operations return in order: requested behind them it would arrive with their acknowledgement) and rides out the
         // accumulation below in 32 registers.
-        const bool last = TEAM && c == ncol - 1;
         pan_d2 dt[8];
         if (last) p2_gload(B, ldb, brows, r0, bc0 + 64 * trow, t, dt);
         p2_gstore(B, ldb, brows, r0, bc0 + 64 * c, Xs, t, TEAM);
@@ -883,7 +1172,7 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
             }
             P2_STAMP(c, 5);   // diagonal-tile accumulation done
             if (!last) {
-                p2_publish(p, trow, (unsigned long long)c + 1);
+                p2_publish(p, trow, 4ull * (unsigned long long)c + 4ull);
             } else {
                 // the tile is parked in Cs (the triangle is dead: every wave is past the barrier that ended the strip); X is
                 // published after the barrier that the assembly below needs anyway
@@ -900,9 +1189,13 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
             p2_gload(B, ldb, brows, r0, bc0 + 64 * trow, t, dt);
             p2_sstore(Cs, t, dt);
         }
-        __syncthreads();
-        if (ncol > 0 && t == 0)   // every wave has drained its write-through stores of the last X
-            __hip_atomic_store(pnl_flag(p, trow), (unsigned long long)ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!parked) {
+            __syncthreads();
+            if (ncol > 0 && t == 0)   // every wave has drained its write-through stores of the last X
+                __hip_atomic_store(pnl_flag(p, trow), 4ull * (unsigned long long)ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __syncthreads();
+        }
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             if (q < 2 || w < 2) {
@@ -910,51 +1203,77 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Cs[(16 * mi + lk + 4 * v) * PNL_LD + 16 * ni + l15] -= dacc[q][v];
             }
+        if (parked) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last block's stores of X rode out the assembly
         __syncthreads();
+        if (parked && t == 0)
+            __hip_atomic_store(pnl_flag(p, trow), 4ull * (unsigned long long)ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         P2_STAMP(trow, 1);   // diagonal tile assembled
+        P3Publish pub;
+        pub.dst = B + (size_t)r0 * ldb + bc0 + 64 * trow;
+        pub.ld = ldb;
+        pub.rows = brows - r0;
+        pub.word = pnl_flag(p, trow);
+        pub.base = 4ull * (unsigned long long)trow;
+        double* Sd = psm + 2 * PNL_TILE + 16;   // 8 x 8 scratch block behind the progress cache
 #ifdef GPAR_EXPERIMENT_OLD_DIAG
         pnl_diag(Cs, r0, p, t);
+        __syncthreads();
+        p2_inverse_blocks(Cs, w, lane);
+        __syncthreads();
 #else
-        p3_diag(Cs, r0, p, t);
+        p3_diag(Cs, r0, p, t, nullptr, progressive ? Sd : nullptr, pub);
+        // (every round ends with a barrier: the tile, W_0 .. W_3 included, is complete in LDS here)
 #endif
-        __syncthreads();
         P2_STAMP(trow, 2);   // factored
-        p2_inverse_blocks(Cs, w, lane);   // into four strictly upper 16 x 16 blocks of the tile (scratch by the ABI's convention)
-        __syncthreads();
-        {   // the lower triangle in 16-byte write-through stores (the pair that holds the diagonal element of an even row also
-            // writes its right-hand neighbour: scratch - the progress words sit in row 0 from column 8 on, the inverses from
-            // column 32 on in rows 0 .. 31).  (Issued before the inverses are computed they only delayed the inverses' own
-            // stores: 1.56 -> 1.88 us for this stretch.)
+        if (!progressive) {
+            p3_block_flag(Cs, nullptr, w, lane);
+            __syncthreads();
+            {   // the lower triangle in 16-byte write-through stores (the pair that holds the diagonal element of an even row also
+                // writes its right-hand neighbour: scratch - the progress words sit in row 0 from column 8 on, the inverses from
+                // column 32 on in rows 0 .. 31).
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = t + 256 * q;
-                const int r = e >> 5, cc = (e & 31) * 2;
-                if (cc <= r && r0 + r < brows) {
-                    const pan_d2 v = *reinterpret_cast<const pan_d2*>(Cs + r * PNL_LD + cc);
-                    double* dst = B + (size_t)(r0 + r) * ldb + bc0 + 64 * trow + cc;
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+                for (int q = 0; q < 8; ++q) {
+                    const int e = t + 256 * q;
+                    const int r = e >> 5, cc = (e & 31) * 2;
+                    if (cc <= r && r0 + r < brows) {
+                        const pan_d2 v = *reinterpret_cast<const pan_d2*>(Cs + r * PNL_LD + cc);
+                        double* dst = B + (size_t)(r0 + r) * ldb + bc0 + 64 * trow + cc;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(dst), "v"(v) : "memory");
+                    }
                 }
             }
-        }
-        {   // the four inverse blocks: 1024 doubles, two 16-byte write-through stores per thread
+            {   // the four inverse blocks: 1024 doubles, two 16-byte write-through stores per thread
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int e = t + 256 * q;                  // 512 pairs
-                const int jb = e >> 7, i = (e >> 3) & 15, jj = (e & 7) * 2;
-                const int off = p2_wblock(jb) + i * PNL_LD + jj;
-                const pan_d2 v = *reinterpret_cast<const pan_d2*>(Cs + off);
-                double* dst = B + (size_t)(r0 + (off / PNL_LD)) * ldb + bc0 + 64 * trow + (off % PNL_LD);
-                if (r0 + (off / PNL_LD) < brows) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+                for (int q = 0; q < 2; ++q) {
+                    const int e = t + 256 * q;                  // 512 pairs
+                    const int jb = e >> 7, i = (e >> 3) & 15, jj = (e & 7) * 2;
+                    const int off = p2_wblock(jb) + i * PNL_LD + jj;
+                    const pan_d2 v = *reinterpret_cast<const pan_d2*>(Cs + off);
+                    double* dst = B + (size_t)(r0 + (off / PNL_LD)) * ldb + bc0 + 64 * trow + (off % PNL_LD);
+                    if (r0 + (off / PNL_LD) < brows) asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(dst), "v"(v) : "memory");
+                }
+            }
+            if (t < 2 && r0 + 1 < brows) {   // the four refinement flags: row 1, columns 16 .. 19
+                const pan_d2 v = *reinterpret_cast<const pan_d2*>(Cs + p2_flag_slot(2 * t));
+                double* dst = B + (size_t)(r0 + 1) * ldb + bc0 + 64 * trow + 16 + 2 * t;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(dst), "v"(v) : "memory");
+            }
+        } else {
+            // block columns 0 .. 2 went out during the factorisation; the last one now (wave 3: a handful of stores)
+            if (w == 3) {
+                p3_block_flag(Cs, nullptr, 3, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                p3_store_column(Cs, nullptr, 3, lane, pub);
             }
         }
-        if (t < 2 && r0 + 1 < brows) {   // the four refinement flags: row 1, columns 16 .. 19
-            const pan_d2 v = *reinterpret_cast<const pan_d2*>(Cs + p2_flag_slot(2 * t));
-            double* dst = B + (size_t)(r0 + 1) * ldb + bc0 + 64 * trow + 16 + 2 * t;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-        }
-        P2_STAMP(trow, 3);   // inverses + stores issued
-        p2_publish(p, trow, (unsigned long long)trow + 1);
+        P2_STAMP(trow, 3);   // stores issued
+        p2_publish(p, trow, 4ull * (unsigned long long)trow + 4ull);
         P2_STAMP(trow, 4);   // published
+#ifndef GPAR_EXPERIMENT_OLD_DIAG
+        p3_diag_logdet(Cs, r0, p, t);
+#endif
     }
 #undef P2_STAMP
 }
@@ -990,7 +1309,7 @@ __device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const dou
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int v = 0; v < 4; ++v) T[mi][v] = Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] - acc[mi][v];
-        if (FLAGS) p2_wait(p, seen, c - fo, (unsigned long long)(c - fo) + 1);   // the triangle (with its inverse blocks and flags) is out
+        if (FLAGS) p2_wait(p, seen, c - fo, 4ull * (unsigned long long)(c - fo) + 4ull);   // the triangle (with its inverse blocks and flags) is out
         else __syncthreads();
         {
             pan_d2 lt[8];
@@ -1024,8 +1343,8 @@ __device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const dou
         p2_gload(B, ldb, brows, r0, bc0 + 64 * ufirst, t, xa);   // X[rb][ufirst] - or, for c = ufirst, the tile to be solved itself
         if (c > ufirst) {
             if (FLAGS) {   // every L[c][u] and L[c + 1][u], u < c, is out
-                p2_wait(p, seen, c - fo, (unsigned long long)(c - fo));
-                if (pair) p2_wait(p, seen, c + 1 - fo, (unsigned long long)(c - fo));
+                p2_wait(p, seen, c - fo, 4ull * (unsigned long long)(c - fo));
+                if (pair) p2_wait(p, seen, c + 1 - fo, 4ull * (unsigned long long)(c - fo));
             }
             pan_d2 la0[8], la1[8];
             p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * ufirst, t, la0);
@@ -1056,7 +1375,7 @@ __device__ __forceinline__ void p2_row_block_pairs(const PanelArgs& p, const dou
         solve_column(c, acc0);
         if (pair) {
             // the product (c + 1, c): X[rb][c] is in Xs (the strip has just left it there), L[c + 1][c] and the next tile to solve arrive now
-            if (FLAGS) p2_wait(p, seen, c + 1 - fo, (unsigned long long)(c - fo) + 1);   // team row c + 1 has solved (and published) its strip of column c
+            if (FLAGS) p2_wait(p, seen, c + 1 - fo, 4ull * (unsigned long long)(c - fo) + 4ull);   // team row c + 1 has solved (and published) its strip of column c
             pan_d2 lc[8];
             p2_gload(L, ldl, lrows, lr0 + 64 * (c + 1), lc0 + 64 * c, t, lc);
             p2_gload(B, ldb, brows, r0, bc0 + 64 * (c + 1), t, xa);
@@ -1110,6 +1429,7 @@ static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* 
     PanelArgs p{A, N, lda, k0, W / 64, logdet, info, nullptr};
     p.batch_a = batch_a;
     p.pairs = env_int("GPAR_PANEL_PAIRS", 1);
+    p.progressive = env_int("GPAR_PANEL_PROGRESSIVE", 1);
     if (p.S > PNL_MAX_S) return GPAR_ARG_ERROR(5);
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_panel2_kernel), P2_LDS_BYTES));
     if (!(prezeroed && potrf_flags_prezeroed(N, k0)))
@@ -1215,7 +1535,7 @@ __device__ __forceinline__ void grp_la_tile(const PanelArgs& p, int kq, int ti, 
                 double* dst = p.A + (size_t)(r0 + r) * p.lda + c0 + cc;
                 if (cc + 1 <= r) {
                     const pan_d2 v = *reinterpret_cast<const pan_d2*>(Xs + r * PNL_LD + cc);
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(dst), "v"(v) : "memory");
                 } else {
                     const double v = Xs[r * PNL_LD + cc];
                     asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
@@ -1322,6 +1642,7 @@ static int potrf_group_fused(double* A, int N, int lda, int k0, int W, int G, do
     g.p = PanelArgs{A, N, lda, k0, W / 64, logdet, info, nullptr};
     g.p.batch_a = batch_a;
     g.p.pairs = 1;
+    g.p.progressive = env_int("GPAR_PANEL_PROGRESSIVE", 1);
     g.G = G;
     g.la_base = la_base;
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_group_kernel), P2_LDS_BYTES));

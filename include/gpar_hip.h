@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define GPAR_ABI_VERSION 5
+#define GPAR_ABI_VERSION 6
 
 /* ---- kernel specification -------------------------------------------------------------------
  * A GPAR layer kernel (gpar/regression.py:92-180) is a sum of products of elementary kernels applied
@@ -142,6 +142,11 @@ int gpar_jit_stats(int* compiled, int* failures, int* cached);
 long long gpar_jit_compile(int kind, const gpar_kspec_t* ks, int dz, const char* arch, void* code_out, long long capacity, char* key_out,
                            int key_len, char* log, int log_len);
 int gpar_aot_stats(int* entries, int* loaded);
+/* (ABI v6) What ties an archive to the library that may use it: a hash of the sources this library generates for a probe structure
+ * covering every factor type and kernel kind, and of GPAR_ABI_VERSION.  The build step writes it into the archive's header; the
+ * library ignores an archive whose ABI version or fingerprint is not its own (stale code objects could have another argument
+ * layout or other arithmetic) and compiles at run time instead.  Needs no GPU.  [no reference counterpart: build hygiene] */
+unsigned long long gpar_aot_fingerprint(void);
 
 int gpar_abi_version(void);
 size_t gpar_sizeof_fspec(void);

@@ -3,6 +3,7 @@
 #include "../gpar_amd/csrc/panel2.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 using namespace gpar;
 
@@ -17,12 +18,14 @@ int main(int argc, char** argv) {
     for (int r = 0; r < N; ++r)
         for (int c = 0; c < 512 && c <= r; ++c) h[(size_t)r * 512 + c] = (r == c) ? 600.0 : 0.5 / (1 + (r - c) % 7);
     PanelArgs p{A, N, lda, 0, S, nullptr, nullptr, st};
+    p.progressive = argc > 2 ? atoi(argv[2]) : 1;
+    p.pairs = 1;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int R = (N + 63) / 64;
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; rep < 12; ++rep) {
         for (int r = 0; r < N; ++r) hipMemcpyAsync(A + (size_t)r * lda, h.data() + (size_t)r * 512, 512 * 8, hipMemcpyHostToDevice, 0);
         hipMemsetAsync(A + 8, 0, 56 * 8, 0);
         hipMemsetAsync(st, 0, 8 * nst, 0);
@@ -32,7 +35,19 @@ int main(int argc, char** argv) {
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        printf("panel2 kernel, N = %d (R = %d row blocks): %.1f us\n", N, R, ms * 1e3);
+        if (rep >= 9) printf("panel2 kernel, N = %d (R = %d row blocks): %.1f us\n", N, R, ms * 1e3);
+    }
+    {   // checksum of the factored panel (compare the two modes: same bits)
+        std::vector<double> out((size_t)N * 512);
+        for (int r = 0; r < N; ++r) hipMemcpy(out.data() + (size_t)r * 512, A + (size_t)r * lda, 512 * 8, hipMemcpyDeviceToHost);
+        unsigned long long h = 1469598103934665603ull;
+        for (int r = 0; r < N; ++r)
+            for (int c = 0; c < 512 && c <= r; ++c) {
+                unsigned long long v;
+                memcpy(&v, &out[(size_t)r * 512 + c], 8);
+                h = (h ^ v) * 1099511628211ull;
+            }
+        printf("progressive = %d: lower-trapezoid hash %016llx, L[N-1][511] = %.17g\n", p.progressive, h, out[(size_t)(N - 1) * 512 + 511]);
     }
     std::vector<long long> s(nst);
     hipMemcpy(s.data(), st, 8 * nst, hipMemcpyDeviceToHost);
@@ -46,6 +61,13 @@ int main(int argc, char** argv) {
                    us(at(t, c, 3)), us(at(t, c, 4)), us(at(t, c, 5)), us(at(t, c, 6)));
         printf("  t=%d diag: start %7.2f assembled %7.2f factored %7.2f inverses+stores %7.2f published %7.2f\n", t, us(at(t, t, 0)),
                us(at(t, t, 1)), us(at(t, t, 2)), us(at(t, t, 3)), us(at(t, t, 4)));
+    }
+    for (int t = 0; t < S; ++t) {
+        printf("  t=%d rounds end:", t);
+        for (int k = 0; k < 8; ++k) printf(" %7.2f", us(at(t, 10, k)));
+        printf("   helper (start r3 r4 r5 r6 r7 | end r3 r4 r5):");
+        for (int k = 0; k < 8; ++k) printf(" %7.2f", us(at(t, 9, k)));
+        printf("\n");
     }
     printf("bulk row blocks 8..15: per column c: start, chunks done, triangle available, in LDS, strip done\n");
     for (int rb = 8; rb < 16 && rb < R; rb += 7)
