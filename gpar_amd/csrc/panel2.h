@@ -697,12 +697,34 @@ __device__ __forceinline__ void p3_diag_block(double (&acc)[8], const double (&p
 // beside the factorisation instead of behind it.  The progress word counts QUARTERS of a column block for that reason.
 // (The replicated rows of a round reach the tile in LDS one round late - see below; wave 0 also leaves them in the 8 x 8 scratch
 // block S right away, which is where wave 3 takes the last diagonal 8 x 8 block of a block column from.)
+constexpr int P3_ELD = 18;                 // row pitch of an identity block (even: 16-byte row loads; 16 rows x 18 doubles)
+constexpr int P3_EBLK = 16 * P3_ELD;       // doubles per block; four blocks: 9 KB of the row block's (dead) second LDS tile
+
+// one wave: W_b (rows = rows of the inverse) from E_b = W_b^T
+__device__ __forceinline__ void p3_extract_inverse(double* __restrict__ T, const double* __restrict__ E, int b, int lane) {
+    const double* Eb = E + b * P3_EBLK;
+    double* Wb = T + p2_wblock(b);
+    const int i = lane & 15, j0 = lane >> 4;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Wb[(j0 + 4 * v) * PNL_LD + i] = Eb[i * P3_ELD + j0 + 4 * v];
+}
+
 struct P3Publish {
     double* dst = nullptr;             // the tile in global memory (row r0, column of the diagonal block); nullptr: nothing is published here
     int ld = 0, rows = 0;              // leading dimension; valid rows from r0
     unsigned long long* word = nullptr;
     unsigned long long base = 0ull;    // word value that means "every strip of this row block is out" (4 * trow)
+    bool add = false;                  // split team: the word is a sum fed by several workgroups - announce by +1 instead of a value
 };
+
+// rotate a double by `ROR` lanes within every row of 16 lanes (two 32-bit DPP moves: no LDS crossbar round trip)
+template <int ROR>
+__device__ __forceinline__ double p3_row_ror(double v) {
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, 0x120 + ROR, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), 0x120 + ROR, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 
 // refinement flag of diagonal block b (see P2_REFINE_RATIO): one wave; S != nullptr: its last eight pivots are still on their way
 // to the tile and are read from the scratch block
@@ -710,15 +732,15 @@ __device__ __forceinline__ void p3_block_flag(double* __restrict__ T, const doub
     const int l = lane & 15;
     double d = (S && l >= 8) ? S[(l - 8) * 8 + (l - 8)] : T[(16 * b + l) * PNL_LD + 16 * b + l];
     double mn = d, mx = d;
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
-        mn = fmin(mn, __shfl_xor(mn, off, 64));
-        mx = fmax(mx, __shfl_xor(mx, off, 64));
-    }
+    mn = fmin(mn, p3_row_ror<8>(mn)); mx = fmax(mx, p3_row_ror<8>(mx));
+    mn = fmin(mn, p3_row_ror<4>(mn)); mx = fmax(mx, p3_row_ror<4>(mx));
+    mn = fmin(mn, p3_row_ror<2>(mn)); mx = fmax(mx, p3_row_ror<2>(mx));
+    mn = fmin(mn, p3_row_ror<1>(mn)); mx = fmax(mx, p3_row_ror<1>(mx));
     if (lane == 0) T[p2_flag_slot(b)] = (mx > P2_REFINE_RATIO * mn) ? 1.0 : 0.0;
 }
 
 // wave-wide (64 lanes): block column b of the lower-triangular tile T, the inverse block W_b and its refinement flag, write-through
+// (a team row's diagonal tile is whole: no row test; rows of the diagonal 16 x 16 block store their pairs up to the diagonal)
 __device__ __forceinline__ void p3_store_column(const double* __restrict__ T, const double* __restrict__ S, int b, int lane, const P3Publish& pub) {
     const int r8 = lane >> 3, c2 = (lane & 7) * 2;
     pan_d2 v[8], wv[2];
@@ -732,65 +754,140 @@ __device__ __forceinline__ void p3_store_column(const double* __restrict__ T, co
 #pragma unroll
     for (int q = 0; q < 2; ++q) wv[q] = *reinterpret_cast<const pan_d2*>(T + (16 * (b >> 1) + 8 * q + r8) * PNL_LD + 32 + 16 * (b & 1) + c2);
     const double fl = T[p2_flag_slot(b)];
+    double* dst = pub.dst + (size_t)(16 * b + r8) * pub.ld + cc;
+    const size_t step = (size_t)8 * pub.ld;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int r = 16 * b + 8 * i + r8;
-        if (r < 64 && cc <= r && r < pub.rows) {
-            double* dst = pub.dst + (size_t)r * pub.ld + cc;
+        if (16 * b + 8 * i < 64 && (i >= 2 || c2 <= 8 * i + r8))
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(dst), "v"(v[i]) : "memory");
-        }
+        dst += step;
     }
+    double* wd = pub.dst + (size_t)(16 * (b >> 1) + r8) * pub.ld + 32 + 16 * (b & 1) + c2;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int r = 16 * (b >> 1) + 8 * q + r8;
-        if (r < pub.rows) {
-            double* dst = pub.dst + (size_t)r * pub.ld + 32 + 16 * (b & 1) + c2;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(dst), "v"(wv[q]) : "memory");
-        }
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(wd), "v"(wv[q]) : "memory");
+        wd += step;
     }
-    if (lane == 0 && 1 < pub.rows) {
-        double* dst = pub.dst + (size_t)pub.ld + 16 + b;
-        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(fl) : "memory");
+    if (lane == 0) {
+        double* fd = pub.dst + (size_t)pub.ld + 16 + b;
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(fd), "v"(fl) : "memory");
     }
 }
 
-// blocks (mi, ni), mi >= ni >= n0, in the order ni-major: the idx-th one
-__device__ __forceinline__ void p3_update_block(int n0, int idx, int& mi, int& ni) {
-    ni = n0;
-    int left = idx;
-    while (left >= 4 - ni) { left -= 4 - ni; ++ni; }
-    mi = ni + left;
+// The rank-8 updates of round JB of p3_diag:  T[mi][ni] -= L[mi][JB - 1] L[ni][JB - 1]^T  (K = 8) for the 16 x 16 blocks that reach
+// columns >= 8 JB + 8 - 6, 6, 3, 3, 1, 1, 0 of them for JB = 1 .. 7, in the order (1,1) (2,1) (3,1) (2,2) (3,2) (3,3) (the lists of the
+// later rounds are tails of it).  This instance takes the blocks FIRST, FIRST + STRIDE, ...; everything about the blocks is a
+// compile-time constant - as run-time loops over a block table this section was ~200 instructions and several exec-mask loops per
+// block, and it, not the factoring waves (0.65 us per round), set the length of rounds 1 - 4 (1.1 us with three blocks per wave).
+// Up to three blocks are loaded together, multiplied, stored: one LDS round trip per batch.
+template <int JB, int FIRST, int STRIDE>
+__device__ __forceinline__ void p3_update_round(double* __restrict__ T, int l15, int lk) {
+    constexpr int c0 = 8 * JB + 8, n0 = c0 >> 4, nblk = (4 - n0) * (5 - n0) / 2, g0 = n0 == 1 ? 0 : (n0 == 2 ? 3 : 5);
+    constexpr int mine = FIRST < nblk ? (nblk - FIRST + STRIDE - 1) / STRIDE : 0;
+    const int kb = 8 * (JB - 1) + lk;
+#pragma unroll
+    for (int bt = 0; bt < (mine + 2) / 3; ++bt) {
+        pan_d4 c[3];
+        double a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            const int k = 3 * bt + sl;
+            if (k < mine) {
+                const int g = g0 + FIRST + STRIDE * k, mi = (4025 >> (2 * g)) & 3, ni = (3733 >> (2 * g)) & 3;
+                const double* C = &T[(16 * mi + lk) * PNL_LD + 16 * ni + l15];
+                c[sl] = pan_d4{C[0], C[4 * PNL_LD], C[8 * PNL_LD], C[12 * PNL_LD]};
+                const double* a = &T[(16 * mi + l15) * PNL_LD + kb];
+                const double* b = &T[(16 * ni + l15) * PNL_LD + kb];
+                a0[sl] = -a[0]; a1[sl] = -a[4]; b0[sl] = b[0]; b1[sl] = b[4];
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            const int k = 3 * bt + sl;
+            if (k < mine) {
+                c[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[sl], b0[sl], c[sl], 0, 0, 0);
+                c[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[sl], b1[sl], c[sl], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            const int k = 3 * bt + sl;
+            if (k < mine) {
+                const int g = g0 + FIRST + STRIDE * k, mi = (4025 >> (2 * g)) & 3, ni = (3733 >> (2 * g)) & 3;
+                double* C = &T[(16 * mi + lk) * PNL_LD + 16 * ni + l15];
+                if (16 * ni >= c0 || 16 * ni + l15 >= c0) { C[0] = c[sl][0]; C[4 * PNL_LD] = c[sl][1]; C[8 * PNL_LD] = c[sl][2]; C[12 * PNL_LD] = c[sl][3]; }
+            }
+        }
+    }
+}
+
+// wave `w` (2 or 3) in round jb; solo: wave 2 takes every block (wave 3 is publishing)
+__device__ __forceinline__ void p3_update(double* __restrict__ T, int jb, int w, bool solo, int l15, int lk) {
+#define P3_UPDATE_CASE(JB)                                                       \
+    case JB:                                                                     \
+        if (solo) { if (w == 2) p3_update_round<JB, 0, 1>(T, l15, lk); }         \
+        else if (w == 2) p3_update_round<JB, 0, 2>(T, l15, lk);                  \
+        else p3_update_round<JB, 1, 2>(T, l15, lk);                              \
+        break;
+    switch (jb) {
+        P3_UPDATE_CASE(1) P3_UPDATE_CASE(2) P3_UPDATE_CASE(3) P3_UPDATE_CASE(4) P3_UPDATE_CASE(5) P3_UPDATE_CASE(6)
+        default: break;
+    }
+#undef P3_UPDATE_CASE
 }
 
 template <bool STAMP = false>
 __device__ __forceinline__ void p3_diag(double* __restrict__ T, int col0, const PanelArgs& p, int t, long long* __restrict__ st = nullptr,
-                                        double* __restrict__ S = nullptr, const P3Publish pub = P3Publish()) {
-    const int lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+                                        double* __restrict__ S = nullptr, const P3Publish pub = P3Publish(), double* __restrict__ E = nullptr) {
+    // (the wave index as a SCALAR: every `if (w == ..)` below is then a scalar branch, and the block tables of the rank-8 updates
+    // scalar arithmetic - as a vector value the compiler wrapped them in exec-mask loops, ~200 instructions per 16 x 16 block)
+    const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), l15 = lane & 15, lk = lane >> 4;
     const bool progressive = pub.dst != nullptr && S != nullptr;
     // dev aid (tools/time_panel2.hip): column 9 = the publishing wave's phases, column 10 = end of every round
 #define P3_STAMP(col, k)                                                                                             \
     do {                                                                                                              \
-        if (p.stamps && blockIdx.x < 16) p.stamps[((size_t)blockIdx.x * 17 + (col)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        if (p.stamps) p.stamps[((size_t)(col0 / 64 % 16) * 17 + (col)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
     } while (0)
-    double held[8];   // the lane's results of the previous round (threads 0-7: the replicated rows, not yet in the tile; wave 0's
-                      // identity lanes: the first half of their row of the inverse)
+    double held[8];   // threads 0-7: the replicated rows' results of the previous round, not yet in the tile (see below)
 #pragma unroll
     for (int q = 0; q < 8; ++q) held[q] = 0.0;
+    // the identity rows (see (1) above) live in E: four 16 x 16 blocks, E_b = I before block b's two rounds, W_b^T after them
+    if (E) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = t + 256 * q, b = e >> 8, i = (e >> 4) & 15, j = e & 15;
+            E[b * P3_EBLK + i * P3_ELD + j] = (i == j) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+    }
     for (int jb = 0; jb < 8; ++jb) {
         // (wave 1 owns rows 32-63: nothing of it is left below the last block)
         if (w == 0 || (w == 1 && jb < 7)) {
             if (STAMP && t == 0) st[3 * jb] = (long long)__builtin_readcyclecounter();
             const int row = l15 < 8 ? 8 * jb + l15 : 32 * w + 8 * lk + (l15 - 8);
-            double acc[8], prev[8];
-            const pan_d2* src = reinterpret_cast<const pan_d2*>(&T[row * PNL_LD + 8 * jb]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const pan_d2 v = src[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
-            // identity rows (see (1) above): block bq = jb / 2, its first (half = 0) or second round
+            // where this lane's eight values of column block jb (src) and jb - 1 (psrc) are, and whether it writes them back: a row
+            // of the tile - or, for wave 0's lanes 8-15 of DPP rows ga (both rounds of block bq) and ga + 1 (second round), which
+            // hold dead rows by then, row e of E_bq (psrc in the first round: a row whose first half is and stays zero)
             const int bq = jb >> 1, half = jb & 1, ga = 2 * (bq & 1), ii = l15 - 8;
-            const bool idl = w == 0 && l15 >= 8;
-            const bool idA = idl && lk == ga, idB = idl && lk == ga + 1;
+            const bool ident = E != nullptr && w == 0 && l15 >= 8 && (lk == ga || (half && lk == ga + 1));
+            const int erow = (lk == ga ? 0 : 8) + ii;
+            const double* src = &T[row * PNL_LD + 8 * jb];
+            const double* psrc = &T[row * PNL_LD + 8 * (jb - 1)];
+            bool wr = l15 >= 8 ? (row > 8 * jb + 7) : (t < 8 && jb == 7);
+            if (ident) {
+                const double* Eb = E + bq * P3_EBLK;
+                src = Eb + erow * P3_ELD + 8 * half;
+                psrc = half ? Eb + erow * P3_ELD : Eb + (8 + ii) * P3_ELD;
+                wr = true;
+            }
+            double acc[8], prev[8];
+            {
+                const pan_d2* sv = reinterpret_cast<const pan_d2*>(src);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const pan_d2 v = sv[q]; acc[2 * q] = v[0]; acc[2 * q + 1] = v[1]; }
+            }
             if (jb > 0) {
-                const pan_d2* ps = reinterpret_cast<const pan_d2*>(&T[row * PNL_LD + 8 * (jb - 1)]);
+                const pan_d2* ps = reinterpret_cast<const pan_d2*>(psrc);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { const pan_d2 v = ps[q]; prev[2 * q] = v[0]; prev[2 * q + 1] = v[1]; }
                 // The replicated rows of round jb - 1 go to LDS only now.  The two factoring waves do not synchronise inside a
@@ -802,32 +899,15 @@ __device__ __forceinline__ void p3_diag(double* __restrict__ T, int col0, const 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) hd[q] = pan_d2{held[2 * q], held[2 * q + 1]};
                 }
-                if (idA) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        prev[q] = half ? held[q] : 0.0;
-                        acc[q] = (!half && q == ii) ? 1.0 : 0.0;
-                    }
-                } else if (idB && half) {   // (in the block's first round these lanes still hold live rows of the tile)
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        prev[q] = 0.0;
-                        acc[q] = (q == ii) ? 1.0 : 0.0;
-                    }
-                }
                 p3_diag_block<true>(acc, prev);
             } else {
-                if (idA) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] = (q == ii) ? 1.0 : 0.0;
-                }
                 p3_diag_block<false>(acc, prev);
             }
             // rows below the block: written by their only holder (rows above it carry the strict upper triangle's scratch
             // through the same arithmetic and are dropped); the replicated rows: held by wave 0's first DPP row - in the last
-            // round, which wave 1 sits out, written at once
-            if (l15 >= 8 ? (row > 8 * jb + 7) : (t < 8 && jb == 7)) {
-                pan_d2* dst = reinterpret_cast<pan_d2*>(&T[row * PNL_LD + 8 * jb]);
+            // round, which wave 1 sits out, written at once; identity rows: back into E
+            if (wr) {
+                pan_d2* dst = reinterpret_cast<pan_d2*>(const_cast<double*>(src));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
             }
@@ -837,75 +917,32 @@ __device__ __forceinline__ void p3_diag(double* __restrict__ T, int col0, const 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sd[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
             }
-            if (half && (idA || idB)) {   // W_bq = (L_bq)^-1: lane i of A holds column i (rows 0-7 from the first round), lane i of B column 8 + i
-                double* Wb = T + p2_wblock(bq);
-                if (idA) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { Wb[j * PNL_LD + ii] = prev[j]; Wb[(8 + j) * PNL_LD + ii] = acc[j]; }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { Wb[j * PNL_LD + 8 + ii] = 0.0; Wb[(8 + j) * PNL_LD + 8 + ii] = acc[j]; }
-                }
-            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) held[q] = acc[q];
             if (STAMP && t == 0) st[3 * jb + 2] = (long long)__builtin_readcyclecounter();
         } else if (w >= 2) {
-            if (progressive && w == 3 && jb >= 2) {   // the publishing wave: block column (jb - 2) / 2 out, then announced
+            if (progressive && w == 3 && jb >= 2 && (jb & 1) == 0) {   // the publishing wave: block column (jb - 2) / 2 goes out
                 if (lane == 0) P3_STAMP(9, jb - 2);
-                if ((jb & 1) == 0) {
-                    const int b = (jb - 2) >> 1;
-                    p3_block_flag(T, S, b, lane);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    p3_store_column(T, S, b, lane, pub);
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(pub.word, pub.base + (unsigned long long)((jb - 1) >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                const int b = (jb - 2) >> 1;
+                p3_extract_inverse(T, E, b, lane);
+                p3_block_flag(T, S, b, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                p3_store_column(T, S, b, lane, pub);
             }
-            if (jb > 0) {
-                // T[mi][ni] -= L[mi][jb - 1] L[ni][jb - 1]^T  (K = 8) for the 16 x 16 blocks that reach columns >= 8 jb + 8: 6, 6, 3, 3, 1, 1, 0
-                // of them, dealt alternately over waves 2 and 3; a wave's (at most three) blocks are loaded together, multiplied,
-                // stored - one LDS round trip per round instead of one per block.
-                const int c0 = 8 * jb + 8, kb = 8 * (jb - 1) + lk, n0 = c0 >> 4;
-                const int nblk = (4 - n0) * (5 - n0) / 2;
-                pan_d4 c[3];
-                double a0[3], a1[3], b0[3], b1[3];
-#pragma unroll
-                for (int sl = 0; sl < 3; ++sl) {
-                    const int idx = 2 * sl + (w & 1);
-                    if (idx < nblk) {
-                        int mi, ni;
-                        p3_update_block(n0, idx, mi, ni);
-                        const double* C = &T[(16 * mi + lk) * PNL_LD + 16 * ni + l15];
-                        c[sl] = pan_d4{C[0], C[4 * PNL_LD], C[8 * PNL_LD], C[12 * PNL_LD]};
-                        const double* a = &T[(16 * mi + l15) * PNL_LD + kb];
-                        const double* b = &T[(16 * ni + l15) * PNL_LD + kb];
-                        a0[sl] = -a[0]; a1[sl] = -a[4]; b0[sl] = b[0]; b1[sl] = b[4];
-                    }
-                }
-#pragma unroll
-                for (int sl = 0; sl < 3; ++sl) {
-                    const int idx = 2 * sl + (w & 1);
-                    if (idx < nblk) {
-                        c[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[sl], b0[sl], c[sl], 0, 0, 0);
-                        c[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[sl], b1[sl], c[sl], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int sl = 0; sl < 3; ++sl) {
-                    const int idx = 2 * sl + (w & 1);
-                    if (idx < nblk) {
-                        int mi, ni;
-                        p3_update_block(n0, idx, mi, ni);
-                        double* C = &T[(16 * mi + lk) * PNL_LD + 16 * ni + l15];
-                        if (16 * ni + l15 >= c0) { C[0] = c[sl][0]; C[4 * PNL_LD] = c[sl][1]; C[8 * PNL_LD] = c[sl][2]; C[12 * PNL_LD] = c[sl][3]; }
-                    }
+            p3_update(T, jb, w, progressive && jb >= 2 && (jb & 1) == 0, l15, lk);
+            if (progressive && w == 3 && jb >= 3 && (jb & 1)) {
+                // the block column stored in the round before: its stores are acknowledged by now (the wait sits at the END of the
+                // round: at its start it stalled the round's barrier for ~0.7 us)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    if (pub.add) __hip_atomic_fetch_add(pub.word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else __hip_atomic_store(pub.word, pub.base + (unsigned long long)((jb - 1) >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
+        if (lane == 0 && w >= 1) P3_STAMP(10 + w, jb);   // (dev aid: when waves 1, 2, 3 reach the round's barrier)
         __syncthreads();
         if (t == 0) P3_STAMP(10, jb);
     }
@@ -969,6 +1006,137 @@ __device__ __forceinline__ void p2_wait(const PanelArgs& p, unsigned long long* 
     __syncthreads();
 }
 
+// ---- the split team (progressive mode, S <= 8) ------------------------------------------------------------------------------------
+// A team row t used to be ONE workgroup working through its columns 0 .. t - 1 left to right: the sums of column c are c tile
+// products that can only start when the row is done with column c - 1, so a late row (t = 6, 7) enters its LAST column - the strip
+// the next diagonal tile waits for - with five or six products (3 us each) still to do, and from the fifth step on those, not the
+// diagonal tile, paced the chain (tools/time_panel2: steps 14, 14, 16, 16, 19, 21, 24 us).  In a latency-bound panel the chip is
+// idle, so the team is split by TILE: tile (t, c), c <= t - 2, is a workgroup of its own (p2_team_tile: product u as soon as
+// X[t][u] and L[c][u] exist - one per step of the chain -, then the strip on diag(c)), and row t's CHAIN workgroup keeps the last
+// column and the diagonal tile: per step one product for column t - 1 and one for D = X X^T from the same staged operand.  Nobody
+// has more than two tile products per step.  Dispatch order, column by column: chain(c), then tiles (c + 2 .. S - 1, c) - every
+// wait is on a lower index, as before.  Words: tile (t, c) raises flag tf(t, c) when X[t][c] is out, for the tile-level waits; the
+// row's progress word is the SUM of +4 per published strip and +1 per published block column of the diagonal tile (atomic adds:
+// several workgroups feed it), which is what the bulk row blocks wait on, unchanged.
+__device__ __forceinline__ int p2_team_count(int S, int split) { return split ? S + (S - 1) * (S - 2) / 2 : S; }
+
+// team workgroup tw -> chain of row t (c = -1) or tile (t, c)
+__device__ __forceinline__ void p2_team_decode(int S, int tw, int& t, int& c) {
+    int col = 0, off = tw;
+    while (off >= 1 + max(0, S - 2 - col)) { off -= 1 + max(0, S - 2 - col); ++col; }
+    if (off == 0) { t = col; c = -1; }
+    else { t = col + 1 + off; c = col; }
+}
+
+// flag of tile (t, c), c < t <= 7: rows 2 and 3 of the panel's first diagonal tile, columns 9 .. 31 (strictly upper; zeroed with
+// the progress words by potrf_zero_flags; clear of the progress words in row 0, the refinement flags in row 1, the words of
+// potrf_group_kernel in column 8 and the inverse blocks from column 32 on)
+__device__ __forceinline__ unsigned long long* p2_tile_flag(const PanelArgs& p, int t, int c) {
+    const int q = t * (t - 1) / 2 + c;
+    const int r = q < 23 ? 2 : 3, col = q < 23 ? 9 + q : 9 + q - 23;
+    return reinterpret_cast<unsigned long long*>(p.A + (size_t)(p.k0 + r) * p.lda + p.k0 + col);
+}
+
+// all threads; returns once *word >= need (bounded like p2_wait) with this compute unit's stale lines dropped
+__device__ __forceinline__ void grp_wait(unsigned long long* word, unsigned long long need, int* info) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > PNL_SPIN_LIMIT) {
+                if (info) atomicCAS(info, 0, -77);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// tile (t, c) of the split team: X[t][c] = (A[t][c] - sum_{u<c} X[t][u] L[c][u]^T) L[c][c]^-T, published
+__device__ __forceinline__ void p2_team_tile(const PanelArgs& p, int trow, int c, double* __restrict__ psm) {
+    double* Cs = psm;
+    double* Xs = psm + PNL_TILE;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    double* A = p.A;
+    const int r0 = p.k0 + 64 * trow, l0 = p.k0 + 64 * c;
+    pan_d4 acc[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) acc[mi] = pan_d4{0.0, 0.0, 0.0, 0.0};
+    pan_d2 ct[8];   // the tile itself (last written by an earlier launch on the stream, or by the update tiles of a fused launch that
+                    // this row has been waiting for)
+    p2_gload(A, p.lda, p.N, r0, l0, t, ct);
+    for (int u = 0; u < c; ++u) {
+        grp_wait(p2_tile_flag(p, trow, u), 1ull, p.info);
+        grp_wait(p2_tile_flag(p, c, u), 1ull, p.info);
+        pan_d2 xa[8], la[8];
+        p2_gload(A, p.lda, p.N, r0, p.k0 + 64 * u, t, xa);
+        p2_gload(A, p.lda, p.N, l0, p.k0 + 64 * u, t, la);
+        p2_sstore(Cs, t, la);
+        p2_sstore(Xs, t, xa);
+        __syncthreads();
+        p2_chunk(Cs, Xs, acc, w, l15, lk);
+        __syncthreads();
+    }
+    p2_sstore(Xs, t, ct);
+    __syncthreads();
+    pan_d4 T[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) T[mi][v] = Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] - acc[mi][v];
+    grp_wait(pnl_flag(p, c), 4ull * (unsigned long long)c + 4ull, p.info);   // L[c][c] with its inverse blocks and flags
+    {
+        pan_d2 lt[8];
+        p2_gload(A, p.lda, p.N, l0, l0, t, lt);
+        p2_sstore(Cs, t, lt);
+    }
+    __syncthreads();
+    p2_strip(Cs, T, l15, lk);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] = T[mi][v];
+    __syncthreads();
+    p2_gstore(A, p.lda, p.N, r0, l0, Xs, t, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __hip_atomic_fetch_add(pnl_flag(p, trow), 4ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p2_tile_flag(p, trow, c), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// p2_wait without the acquire fence: for data that is then read with L1-bypassing (sc1) loads only - the block columns of a
+// diagonal tile in the progressive last strip; their producer stored them write-through
+__device__ __forceinline__ void p2_wait_nofence(const PanelArgs& p, unsigned long long* __restrict__ seen, int trow, unsigned long long need) {
+    const bool ok = seen[trow] >= need;
+    __syncthreads();
+    if (ok) return;
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        unsigned long long v;
+        while ((v = __hip_atomic_load(pnl_flag(p, trow), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > PNL_SPIN_LIMIT) {
+                if (p.info) atomicCAS(p.info, 0, -77);
+                v = need;
+                break;
+            }
+        }
+        seen[trow] = v;
+    }
+    __syncthreads();
+}
+
+// 16 bytes past this compute unit's L1 (two 8-byte relaxed agent-scope loads = global_load_dwordx2 sc1, which the compiler counts)
+__device__ __forceinline__ pan_d2 p2_load_sc1(const double* __restrict__ src) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(src);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return pan_d2{__longlong_as_double((long long)a), __longlong_as_double((long long)b)};
+}
+
 // One row block of the panel / of a triangular-solve block.
 //   L (ldl, lrows rows): the triangular factor's tiles, read at rows lr0 + 64 c, columns lc0 + 64 u;
 //   B (ldb, brows rows): the right-hand sides / the panel's own rows, read and overwritten at rows r0, columns bc0 + 64 c.
@@ -995,17 +1163,67 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
     // dev aid (tools/time_panel2.hip): 100 MHz wall-clock stamps of the first 16 row blocks, normally off
 #define P2_STAMP(col, k)                                                                                              \
     do {                                                                                                              \
-        if (FLAGS && p.stamps && t == 0 && blockIdx.x < 16)                                                           \
-            p.stamps[((size_t)blockIdx.x * 17 + (col)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime();      \
+        if (FLAGS && TEAM && p.stamps && t == 0)                                                                      \
+            p.stamps[((size_t)trow * 17 + (col)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime();            \
     } while (0)
     const bool progressive = FLAGS && TEAM && p.progressive;
+    const bool split = progressive && p.split;   // this workgroup is row trow's CHAIN workgroup: last column + diagonal tile only
     bool parked = false;   // TEAM: the row block's diagonal tile is in Cs and the last X is on its way out (progressive last strip)
-    for (int c = ufirst; c < ncol; ++c) {
+    // D += X X^T for the tiles on and below the diagonal of this row block's diagonal tile, X = the tile in Xs
+    auto daccum_from_xs = [&]() {
+        const double* xa0 = Xs + (16 * p2_dtile_m(w, 0) + l15) * PNL_LD + lk;
+        const double* xa1 = Xs + (16 * p2_dtile_m(w, 1) + l15) * PNL_LD + lk;
+        const double* xa2 = Xs + (16 * p2_dtile_m(w, 2) + l15) * PNL_LD + lk;
+        const double* xb0 = Xs + (16 * p2_dtile_n(w, 0) + l15) * PNL_LD + lk;
+        const double* xb1 = Xs + (16 * p2_dtile_n(w, 1) + l15) * PNL_LD + lk;
+        const double* xb2 = Xs + (16 * p2_dtile_n(w, 2) + l15) * PNL_LD + lk;
+        double fa[2][3], fb[2][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { fa[0][q] = (q == 0 ? xa0 : q == 1 ? xa1 : xa2)[0]; fb[0][q] = (q == 0 ? xb0 : q == 1 ? xb1 : xb2)[0]; }
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4) {
+            const int cur = k4 & 1, nxt = cur ^ 1;
+            if (k4 + 1 < 16) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    fa[nxt][q] = (q == 0 ? xa0 : q == 1 ? xa1 : xa2)[4 * (k4 + 1)];
+                    fb[nxt][q] = (q == 0 ? xb0 : q == 1 ? xb1 : xb2)[4 * (k4 + 1)];
+                }
+            }
+            dacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][0], fb[cur][0], dacc[0], 0, 0, 0);
+            dacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][1], fb[cur][1], dacc[1], 0, 0, 0);
+            if (w < 2) dacc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][2], fb[cur][2], dacc[2], 0, 0, 0);
+        }
+    };
+    for (int c = split ? max(ufirst, ncol - 1) : ufirst; c < ncol; ++c) {
         P2_STAMP(c, 0);
         pan_d4 acc[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[mi] = pan_d4{0.0, 0.0, 0.0, 0.0};
         pan_d2 xa[8];   // the row block's own tile of column block u (operand of chunk u), finally of column block c itself
+        if (split) {
+            // chain workgroup of the split team: product u for the last column and for D as soon as tiles (trow, u) and (c, u) are out
+            // (X[trow][u] is out ~3 us after diag(u); L[c][u], u = c - 1, is the last strip of the row before and arrives with the
+            // start of diag(c): the D product runs while that is awaited, only the product for the last column behind it)
+            pan_d2 xt[8];   // the tile to be solved: requested ahead of the products (nobody else writes it in this launch)
+            p2_gload(B, ldb, brows, r0, bc0 + 64 * c, t, xt);
+            for (int u = 0; u < c; ++u) {
+                grp_wait(p2_tile_flag(p, trow, u), 1ull, p.info);
+                p2_gload(B, ldb, brows, r0, bc0 + 64 * u, t, xa);
+                p2_sstore(Xs, t, xa);
+                __syncthreads();
+                daccum_from_xs();
+                grp_wait(p2_tile_flag(p, c, u), 1ull, p.info);
+                pan_d2 la[8];
+                p2_gload(L, ldl, lrows, lr0 + 64 * c, lc0 + 64 * u, t, la);
+                p2_sstore(Cs, t, la);
+                __syncthreads();
+                p2_chunk(Cs, Xs, acc, w, l15, lk);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xa[q] = xt[q];
+        } else {
         p2_gload(B, ldb, brows, r0, bc0 + 64 * ufirst, t, xa);
         if (c > ufirst) {
             if (FLAGS) p2_wait(p, seen, c, 4ull * (unsigned long long)c);   // every L[c][u], u < c, is out
@@ -1023,6 +1241,7 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
                 __builtin_amdgcn_sched_barrier(0);   // the requests go out before the products, not in the middle of them
                 p2_chunk(Cs, Xs, acc, w, l15, lk);
             }
+        }
         }
         __syncthreads();
         P2_STAMP(c, 1);   // chunks done
@@ -1043,22 +1262,34 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
             p2_gload(B, ldb, brows, r0, bc0 + 64 * trow, t, dt);
             const double* Lt = L + (size_t)(lr0 + 64 * c) * ldl + lc0 + 64 * c;
             const int lvalid = lrows - (lr0 + 64 * c);   // valid rows of that tile (a team row's diagonal tile: 64)
-            auto fetch = [&](int jb) {
-                // rows 16 jb .. 63 of columns 16 jb .. 16 jb + 15 (512 pairs at most), W_jb (128 pairs), the refinement flag
-                pan_d2 v0, v1, v2;
+            // rows 16 jb .. 63 of columns 16 jb .. 16 jb + 15 (512 pairs at most), W_jb (128 pairs), the refinement flag: requested
+            // (fetch_issue, past the L1: the owner stored them write-through, so no acquire fence is needed) - possibly ahead of time,
+            // under the strip steps of the blocks before, when the owner is that far ahead - and put into Cs (fetch_land).  The strip
+            // takes the tile in two HALVES of two block columns: per step one wait, one landing, three barriers - taken block by block
+            // (1.6 us per block, of which 0.5 arithmetic) the follower, not the factorisation, paced the chain.
+            pan_d2 fv[2][3];
+            double ffl[2] = {0.0, 0.0};
+            auto fetch_issue = [&](int jb, int slot) {
                 const int e0 = t, e1 = t + 256;
                 const int ra = 16 * jb + (e0 >> 3), rb_ = 16 * jb + (e1 >> 3), cc = 16 * jb + (e0 & 7) * 2;
-                v0 = *reinterpret_cast<const pan_d2*>(Lt + (size_t)min(ra, lvalid - 1) * ldl + cc);
-                v1 = *reinterpret_cast<const pan_d2*>(Lt + (size_t)min(min(rb_, 63), lvalid - 1) * ldl + cc);
+                fv[slot][0] = p2_load_sc1(Lt + (size_t)min(min(ra, 63), lvalid - 1) * ldl + cc);
+                fv[slot][1] = p2_load_sc1(Lt + (size_t)min(min(rb_, 63), lvalid - 1) * ldl + cc);
                 const int wr = 16 * (jb >> 1) + ((t & 127) >> 3), wc = 32 + 16 * (jb & 1) + (t & 7) * 2;
-                v2 = *reinterpret_cast<const pan_d2*>(Lt + (size_t)min(wr, lvalid - 1) * ldl + wc);
-                double fl = 0.0;
-                if (t == 255) fl = Lt[(size_t)min(1, lvalid - 1) * ldl + 16 + jb];
-                if (ra < 64) *reinterpret_cast<pan_d2*>(Cs + ra * PNL_LD + cc) = v0;
-                if (rb_ < 64) *reinterpret_cast<pan_d2*>(Cs + rb_ * PNL_LD + cc) = v1;
-                if (t < 128) *reinterpret_cast<pan_d2*>(Cs + wr * PNL_LD + wc) = v2;
-                if (t == 255) Cs[p2_flag_slot(jb)] = fl;
+                fv[slot][2] = p2_load_sc1(Lt + (size_t)min(wr, lvalid - 1) * ldl + wc);
+                if (t == 255)
+                    ffl[slot] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(Lt + (size_t)min(1, lvalid - 1) * ldl + 16 + jb),
+                                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             };
+            auto fetch_land = [&](int jb, int slot) {
+                const int e0 = t, e1 = t + 256;
+                const int ra = 16 * jb + (e0 >> 3), rb_ = 16 * jb + (e1 >> 3), cc = 16 * jb + (e0 & 7) * 2;
+                const int wr = 16 * (jb >> 1) + ((t & 127) >> 3), wc = 32 + 16 * (jb & 1) + (t & 7) * 2;
+                if (ra < 64) *reinterpret_cast<pan_d2*>(Cs + ra * PNL_LD + cc) = fv[slot][0];
+                if (rb_ < 64) *reinterpret_cast<pan_d2*>(Cs + rb_ * PNL_LD + cc) = fv[slot][1];
+                if (t < 128) *reinterpret_cast<pan_d2*>(Cs + wr * PNL_LD + wc) = fv[slot][2];
+                if (t == 255) Cs[p2_flag_slot(jb)] = ffl[slot];
+            };
+            bool ahead = false;   // the next half's data have been requested already
             auto xout = [&](int jb) {   // columns 16 jb .. + 15 of X: own rows -> Xs (all rows -> global after the next barrier)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * jb + lk + 4 * v] = T[jb][v];
@@ -1092,26 +1323,48 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
                     }
                 }
             };
-#define P2_PROGRESSIVE_STEP(JB)                                                                                  \
-            p2_wait(p, seen, c, 4ull * (unsigned long long)c + (unsigned long long)(JB) + 1ull);                 \
-            if ((JB) == 0) P2_STAMP(c, 2);                                                                       \
-            if ((JB) == 3) P2_STAMP(c, 3);                                                                       \
-            fetch(JB);                                                                                           \
+#define P2_PROGRESSIVE_STEP(JA)                                                                                  \
+            if (!ahead) {                                                                                        \
+                p2_wait_nofence(p, seen, c, 4ull * (unsigned long long)c + (unsigned long long)(JA) + 2ull);     \
+                fetch_issue(JA, 0);                                                                              \
+                fetch_issue((JA) + 1, 1);                                                                        \
+            }                                                                                                    \
+            if ((JA) == 0) P2_STAMP(c, 2);                                                                       \
+            if ((JA) == 2) P2_STAMP(c, 3);                                                                       \
+            fetch_land(JA, 0);                                                                                   \
+            fetch_land((JA) + 1, 1);                                                                             \
             __syncthreads();                                                                                     \
-            p2_strip_step<JB>(Cs, T, l15, lk);                                                                   \
-            xout(JB);                                                                                            \
-            dself(JB);                                                                                           \
+            ahead = (JA) == 0 && seen[c] >= 4ull * (unsigned long long)c + 4ull;                                 \
+            if (ahead) {                                                                                         \
+                fetch_issue(2, 0);                                                                               \
+                fetch_issue(3, 1);                                                                               \
+            }                                                                                                    \
+            p2_strip_step<JA>(Cs, T, l15, lk);                                                                   \
+            p2_strip_step<(JA) + 1>(Cs, T, l15, lk);                                                             \
+            xout(JA);                                                                                            \
+            xout((JA) + 1);                                                                                      \
+            dself(JA);                                                                                           \
+            dself((JA) + 1);                                                                                     \
             __syncthreads();                                                                                     \
-            if ((JB) == 3) P2_STAMP(c, 4);                                                                       \
-            xstore(JB);                                                                                          \
-            dcross(JB);
+            if ((JA) == 2) P2_STAMP(c, 4);                                                                       \
+            xstore(JA);                                                                                          \
+            xstore((JA) + 1);                                                                                    \
+            dcross(JA);                                                                                          \
+            dcross((JA) + 1);
             P2_PROGRESSIVE_STEP(0)
-            P2_PROGRESSIVE_STEP(1)
             P2_PROGRESSIVE_STEP(2)
-            P2_PROGRESSIVE_STEP(3)
 #undef P2_PROGRESSIVE_STEP
             P2_STAMP(c, 5);   // diagonal-tile accumulation done
-            __syncthreads();  // every wave is done with the triangle in Cs
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X is out (the last half's stores rode out its cross products) ...
+            __syncthreads();  // ... and every wave is done with the triangle in Cs
+            if (t == 0) {     // announced at once: the next row's chain workgroup takes X as the operand of its last product
+                if (split) {
+                    __hip_atomic_fetch_add(pnl_flag(p, trow), 4ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p2_tile_flag(p, trow, ncol - 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    __hip_atomic_store(pnl_flag(p, trow), 4ull * (unsigned long long)ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             p2_sstore(Cs, t, dt);
             parked = true;
             P2_STAMP(c, 6);
@@ -1146,30 +1399,7 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
         if (last) p2_gload(B, ldb, brows, r0, bc0 + 64 * trow, t, dt);
         p2_gstore(B, ldb, brows, r0, bc0 + 64 * c, Xs, t, TEAM);
         if (TEAM) {
-            // D += X X^T for the tiles on and below the diagonal of this row block's diagonal tile
-            const double* xa0 = Xs + (16 * p2_dtile_m(w, 0) + l15) * PNL_LD + lk;
-            const double* xa1 = Xs + (16 * p2_dtile_m(w, 1) + l15) * PNL_LD + lk;
-            const double* xa2 = Xs + (16 * p2_dtile_m(w, 2) + l15) * PNL_LD + lk;
-            const double* xb0 = Xs + (16 * p2_dtile_n(w, 0) + l15) * PNL_LD + lk;
-            const double* xb1 = Xs + (16 * p2_dtile_n(w, 1) + l15) * PNL_LD + lk;
-            const double* xb2 = Xs + (16 * p2_dtile_n(w, 2) + l15) * PNL_LD + lk;
-            double fa[2][3], fb[2][3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { fa[0][q] = (q == 0 ? xa0 : q == 1 ? xa1 : xa2)[0]; fb[0][q] = (q == 0 ? xb0 : q == 1 ? xb1 : xb2)[0]; }
-#pragma unroll
-            for (int k4 = 0; k4 < 16; ++k4) {
-                const int cur = k4 & 1, nxt = cur ^ 1;
-                if (k4 + 1 < 16) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        fa[nxt][q] = (q == 0 ? xa0 : q == 1 ? xa1 : xa2)[4 * (k4 + 1)];
-                        fb[nxt][q] = (q == 0 ? xb0 : q == 1 ? xb1 : xb2)[4 * (k4 + 1)];
-                    }
-                }
-                dacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][0], fb[cur][0], dacc[0], 0, 0, 0);
-                dacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][1], fb[cur][1], dacc[1], 0, 0, 0);
-                if (w < 2) dacc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][2], fb[cur][2], dacc[2], 0, 0, 0);
-            }
+            daccum_from_xs();
             P2_STAMP(c, 5);   // diagonal-tile accumulation done
             if (!last) {
                 p2_publish(p, trow, 4ull * (unsigned long long)c + 4ull);
@@ -1203,10 +1433,7 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Cs[(16 * mi + lk + 4 * v) * PNL_LD + 16 * ni + l15] -= dacc[q][v];
             }
-        if (parked) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last block's stores of X rode out the assembly
         __syncthreads();
-        if (parked && t == 0)
-            __hip_atomic_store(pnl_flag(p, trow), 4ull * (unsigned long long)ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         P2_STAMP(trow, 1);   // diagonal tile assembled
         P3Publish pub;
         pub.dst = B + (size_t)r0 * ldb + bc0 + 64 * trow;
@@ -1214,6 +1441,7 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
         pub.rows = brows - r0;
         pub.word = pnl_flag(p, trow);
         pub.base = 4ull * (unsigned long long)trow;
+        pub.add = split;
         double* Sd = psm + 2 * PNL_TILE + 16;   // 8 x 8 scratch block behind the progress cache
 #ifdef GPAR_EXPERIMENT_OLD_DIAG
         pnl_diag(Cs, r0, p, t);
@@ -1221,11 +1449,13 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
         p2_inverse_blocks(Cs, w, lane);
         __syncthreads();
 #else
-        p3_diag(Cs, r0, p, t, nullptr, progressive ? Sd : nullptr, pub);
-        // (every round ends with a barrier: the tile, W_0 .. W_3 included, is complete in LDS here)
+        p3_diag(Cs, r0, p, t, nullptr, progressive ? Sd : nullptr, pub, Xs);
+        // (every round ends with a barrier: the tile is complete in LDS here, the inverse blocks - those not yet taken out by the
+        // publishing wave - transposed in Xs)
 #endif
         P2_STAMP(trow, 2);   // factored
         if (!progressive) {
+            p3_extract_inverse(Cs, Xs, w, lane);
             p3_block_flag(Cs, nullptr, w, lane);
             __syncthreads();
             {   // the lower triangle in 16-byte write-through stores (the pair that holds the diagonal element of an even row also
@@ -1261,6 +1491,7 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
         } else {
             // block columns 0 .. 2 went out during the factorisation; the last one now (wave 3: a handful of stores)
             if (w == 3) {
+                p3_extract_inverse(Cs, Xs, 3, lane);
                 p3_block_flag(Cs, nullptr, 3, lane);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1269,7 +1500,13 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
             }
         }
         P2_STAMP(trow, 3);   // stores issued
-        p2_publish(p, trow, 4ull * (unsigned long long)trow + 4ull);
+        if (split) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) __hip_atomic_fetch_add(pnl_flag(p, trow), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            p2_publish(p, trow, 4ull * (unsigned long long)trow + 4ull);
+        }
         P2_STAMP(trow, 4);   // published
 #ifndef GPAR_EXPERIMENT_OLD_DIAG
         p3_diag_logdet(Cs, r0, p, t);
@@ -1401,12 +1638,14 @@ __global__ __launch_bounds__(256, 2) void potrf_panel2_kernel(PanelArgs p) {
     // own matrix with a smaller row index, i.e. a smaller dispatch index: any number of matrices is safe.
     const int batch = gridDim.y, R = gridDim.x;
     const int lin = blockIdx.x + R * blockIdx.y;
-    int rb, b;
-    if (lin < p.S * batch) {
+    const int NT = p2_team_count(p.S, p.split);   // team workgroups per matrix (split team: chains + tiles)
+    int rb, b, tile_c = -1;
+    if (lin < NT * batch) {
         rb = lin / batch;
         b = lin - rb * batch;
+        if (p.split) p2_team_decode(p.S, rb, rb, tile_c);
     } else {
-        const int idx = lin - p.S * batch;
+        const int idx = lin - NT * batch;
         rb = p.S + idx / batch;
         b = idx % batch;
     }
@@ -1414,7 +1653,10 @@ __global__ __launch_bounds__(256, 2) void potrf_panel2_kernel(PanelArgs p) {
     if (p.logdet) p.logdet += b;
     if (p.info) p.info += b;
     const int r0 = p.k0 + 64 * rb;
-    if (rb < p.S) {
+    if (tile_c >= 0) {
+        __builtin_amdgcn_s_setprio(2);
+        p2_team_tile(p, rb, tile_c, psm);
+    } else if (rb < p.S) {
         __builtin_amdgcn_s_setprio(3);   // the chain: never lose an issue arbitration to bulk work on the same compute unit
         p2_row_block<true, true>(p, p.A, p.lda, p.N, p.k0, p.k0, p.A, p.lda, p.N, r0, p.k0, rb, 0, rb, psm);
     } else if (p.pairs) {
@@ -1430,12 +1672,17 @@ static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* 
     p.batch_a = batch_a;
     p.pairs = env_int("GPAR_PANEL_PAIRS", 1);
     p.progressive = env_int("GPAR_PANEL_PROGRESSIVE", 1);
+    p.split = p.progressive && p.S <= 8 && env_int("GPAR_PANEL_SPLIT", 1);
     if (p.S > PNL_MAX_S) return GPAR_ARG_ERROR(5);
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_panel2_kernel), P2_LDS_BYTES));
     if (!(prezeroed && potrf_flags_prezeroed(N, k0)))
-        for (int b = 0; b < batch; ++b)
+        for (int b = 0; b < batch; ++b) {
             GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)b * batch_a + (size_t)k0 * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream));
-    const int R = (N - k0 + 63) / 64;
+            if (p.split)   // the tile flags: rows 2 and 3, columns 9 .. 31 (rows that exist: a team row block is whole)
+                for (int r = 2; r < 4; ++r)
+                    GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)b * batch_a + (size_t)(k0 + r) * lda + k0 + 9, 0, 23 * sizeof(double), stream));
+        }
+    const int R = (N - k0 + 63) / 64 - p.S + (p.split ? p.S + (p.S - 1) * (p.S - 2) / 2 : p.S);
     hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R, batch), dim3(256), P2_LDS_BYTES, stream, p);
     GPAR_LAUNCH_CHECK();
     return 0;
@@ -1471,22 +1718,6 @@ struct GroupArgs {
 
 __device__ __forceinline__ unsigned long long* grp_word(double* A, int lda, int arb, int which) {
     return reinterpret_cast<unsigned long long*>(A + (size_t)(64 * (arb - 1) + 2 + which) * lda + 64 * (arb - 1) + 8);
-}
-
-// all threads; returns once *word >= need (bounded like p2_wait) with this compute unit's stale lines dropped
-__device__ __forceinline__ void grp_wait(unsigned long long* word, unsigned long long need, int* info) {
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > PNL_SPIN_LIMIT) {
-                if (info) atomicCAS(info, 0, -77);
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
 }
 
 // one 64 x 64 tile (ti, tj) of panel q's columns (kq = its first column, q >= 1): C -= X_i X_j^T over the 8 q column blocks of the
@@ -1556,15 +1787,16 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     const int R0 = (p.N - p.k0 + 63) / 64;     // row blocks from k0
     const int TD = S * (S + 1) / 2;            // tiles of a panel's diagonal block
     const int kb0 = p.k0 / 64;
+    const int NT = p2_team_count(S, p.split);   // team workgroups per matrix and panel (split team: chains + tiles)
     int lin = blockIdx.x + gridDim.x * blockIdx.y;
-    int rb, b;
+    int rb, b, tile_c = -1;
     // ---- which segment: panel 0's rows, then per panel q >= 1 (a) diagonal-block tiles, (b) team rows, (c) tiles below, (d) bulk rows
     int q = 0, seg = 0;
-    if (lin >= R0 * batch) {
-        lin -= R0 * batch;
+    if (lin >= (R0 - S + NT) * batch) {
+        lin -= (R0 - S + NT) * batch;
         for (q = 1; q < g.G; ++q) {
             const int Rq = R0 - S * q;
-            const int sizes[4] = {TD * batch, S * batch, (Rq - S) * S * batch, (Rq - S) * batch};
+            const int sizes[4] = {TD * batch, NT * batch, (Rq - S) * S * batch, (Rq - S) * batch};
             for (seg = 1; seg <= 4; ++seg) {
                 if (lin < sizes[seg - 1]) break;
                 lin -= sizes[seg - 1];
@@ -1576,11 +1808,12 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     const bool last = q == g.G - 1;
     if (seg == 0) {
         // teams of all matrices first, as in potrf_panel2_kernel
-        if (lin < S * batch) {
+        if (lin < NT * batch) {
             rb = lin / batch;
             b = lin - rb * batch;
+            if (p.split) p2_team_decode(S, rb, rb, tile_c);
         } else {
-            const int idx = lin - S * batch;
+            const int idx = lin - NT * batch;
             rb = S + idx / batch;
             b = idx % batch;
         }
@@ -1590,6 +1823,7 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     } else if (seg == 2) {
         rb = lin / batch;
         b = lin - rb * batch;
+        if (p.split) p2_team_decode(S, rb, rb, tile_c);
     } else {
         rb = S + lin / batch;
         b = lin % batch;
@@ -1613,10 +1847,12 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     const int r0 = kq + 64 * rb;
     const unsigned long long counted = g.la_base + (unsigned long long)(S * (q - 1));   // tiles this row has counted before panel q's
     if (rb < S) {
-        __builtin_amdgcn_s_setprio(3);
+        if (tile_c >= 0) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
         if (q > 0) grp_wait(grp_word(p.A, p.lda, kq / 64 + rb, 1), counted + (unsigned long long)rb + 1ull, p.info);
         p.k0 = kq;
-        p2_row_block<true, true>(p, p.A, p.lda, p.N, kq, kq, p.A, p.lda, p.N, r0, kq, rb, 0, rb, psm);
+        if (tile_c >= 0) p2_team_tile(p, rb, tile_c, psm);
+        else p2_row_block<true, true>(p, p.A, p.lda, p.N, kq, kq, p.A, p.lda, p.N, r0, kq, rb, 0, rb, psm);
     } else {
         if (q > 0) grp_wait(grp_word(p.A, p.lda, kq / 64 + rb, 1), counted + (unsigned long long)S, p.info);
         p.k0 = kq;
@@ -1626,12 +1862,13 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     }
 }
 
-static long long potrf_group_workgroups(int N, int k0, int S, int G) {
+static long long potrf_group_workgroups(int N, int k0, int S, int G, int split) {
     const int R0 = (N - k0 + 63) / 64;
-    long long per = R0;
+    const int NT = split ? S + (S - 1) * (S - 2) / 2 : S;
+    long long per = R0 - S + NT;
     for (int q = 1; q < G; ++q) {
         const int Rq = R0 - S * q;
-        per += S * (S + 1) / 2 + S + (long long)(Rq - S) * S + (Rq - S);
+        per += S * (S + 1) / 2 + NT + (long long)(Rq - S) * S + (Rq - S);
     }
     return per;
 }
@@ -1643,10 +1880,11 @@ static int potrf_group_fused(double* A, int N, int lda, int k0, int W, int G, do
     g.p.batch_a = batch_a;
     g.p.pairs = 1;
     g.p.progressive = env_int("GPAR_PANEL_PROGRESSIVE", 1);
+    g.p.split = g.p.progressive && g.p.S <= 8 && env_int("GPAR_PANEL_SPLIT", 1);
     g.G = G;
     g.la_base = la_base;
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_group_kernel), P2_LDS_BYTES));
-    hipLaunchKernelGGL(potrf_group_kernel, dim3((unsigned)potrf_group_workgroups(N, k0, W / 64, G), batch), dim3(256), P2_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL(potrf_group_kernel, dim3((unsigned)potrf_group_workgroups(N, k0, W / 64, G, g.p.split), batch), dim3(256), P2_LDS_BYTES, stream, g);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

@@ -625,6 +625,32 @@ class GPAR:
         # one stack (n* x S x p) and S views of it, instead of S stacks of p columns each
         return list(torch.stack(columns, dim=2).permute(1, 0, 2).unbind(0))
 
+    def moments(self, x, w, latent=False):
+        """(mean, variance), n* x p each, of the samples `sample` would draw at x - in closed form, which exists when `replace`
+        feeds the layers' MEANS forward (reference model.py:245-277 with `_update_inputs` :291-322 and obs = None): the inputs
+        of every layer are then deterministic, x_{i+1} = [x_i, mean_i(x_i)], and a draw of layer i at point j is
+        N(mean_i(x_i)_j, var_i(x_i)_j [+ noise_i / w_ij]).  What the Monte-Carlo mean and spread of `predict` converge to,
+        without a sample, an n* x n* covariance or a factorisation of one (an addition: the reference only samples)."""
+        if not self.replace:
+            raise ValueError("closed-form predictive moments need replace=True: otherwise samples, not means, are fed forward")
+        return _retry_unfused(lambda: self._moments(x, w, latent), self.layers, (x, w), rewind=True)
+
+    def _moments(self, x, w, latent):
+        eng = get_engine()
+        x = eng.tensor(x)
+        if x.dim() == 1:
+            x = x[:, None]
+        w = eng.tensor(w)
+        means, variances = [], []
+        for i, (is_last, model) in enumerate(last(self.layers)):
+            f, noise = model()
+            mean, var = f.marginal_moments(x, None if latent else self._noise_over(noise, w[:, i]))
+            means.append(mean.reshape(-1, 1))
+            variances.append(var.reshape(-1, 1))
+            if not is_last:
+                x = torch.cat([x, mean.reshape(-1, 1)], dim=1)
+        return torch.cat(means, dim=1), torch.cat(variances, dim=1)
+
     # ---- helpers -----------------------------------------------------------------------------------
     @staticmethod
     def _noise_over(noise, w):

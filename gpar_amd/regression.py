@@ -370,6 +370,35 @@ class GPARRegressor:
         return [self._untransform_y(self._unnormalise_y(s)).detach()
                 for s in gpar.sample_many(x, w, num_samples, latent=latent, marginal=marginal)]
 
+    def predict_moments(self, x, w=None, latent=False, _conditioned=None):
+        """Predictive means and variances (two n* x p arrays) of the conditioned model at x in CLOSED FORM - for `replace=True`,
+        where posterior means are fed forward and the predictive law of every output at every point is Gaussian.  These are
+        the limits of `predict`'s Monte-Carlo mean and of the variance of its samples (central 95 % bounds: mean -+ 1.96 sd);
+        no sampling, no n* x n* covariance.  An addition behind the reference's API (it only samples, regression.py:566-597);
+        raises ValueError for `replace=False`, where sampled values are fed forward and no closed form exists."""
+        if not self.is_conditioned:
+            raise RuntimeError("Must condition or fit model before predicting.")
+        if not self.replace:
+            raise ValueError("closed-form predictive moments need replace=True")
+        probe = torch.tensor([-1.5, 0.25, 3.0], dtype=torch.float64)
+        if not torch.equal(self._untransform_y(probe), probe):
+            raise ValueError("closed-form predictive moments need the identity output transform (a non-linear map of a Gaussian is not Gaussian)")
+        x = _uprank(_to_engine(x))
+        w = _default_weights(x.shape[0], self.p) if w is None else _uprank(_to_torch(w))
+        gpar = _conditioned
+        if gpar is None:
+            gpar = _construct_gpar(self, self.vs, self.m, self.p) | (self.x, self.y, self.w)
+        with torch.no_grad():
+            mean, var = gpar.moments(x, w, latent=latent)
+            # un-normalisation is affine (y = y_n * std + mean): apply it to the mean, its slope squared to the variance
+            zero = torch.zeros(1, self.p, dtype=mean.dtype, device=mean.device)
+            one = torch.ones(1, self.p, dtype=mean.dtype, device=mean.device)
+            shift = self._unnormalise_y(zero)
+            slope = self._unnormalise_y(one) - shift
+            mean = self._unnormalise_y(mean)
+            var = var * slope ** 2
+        return mean.cpu().numpy(), var.cpu().numpy()
+
     def sample(self, x, w=None, p=None, posterior=False, num_samples=1, latent=False, _conditioned=None):
         """Draw samples from the prior or the posterior at inputs x; a single ndarray for num_samples=1, otherwise
         a list (reference regression.py:508-564).  (`_conditioned`: an already conditioned GPAR, used by the

@@ -1,15 +1,29 @@
-"""Oracle (TEST INFRASTRUCTURE): a self-contained numpy GPAR log marginal likelihood and posterior-mean chain.
+"""Oracle (TEST INFRASTRUCTURE): a self-contained numpy GPAR - log marginal likelihood, conditioning chain, predictive moments,
+finite-difference gradients.
 
 Restates the orchestration of /root/reference/gpar/model.py:178-243 (`GPAR.logpdf`), :279-322 (`_obs`,
-`_update_inputs`), :325-362 (`per_output`) and the per-layer kernel of /root/reference/gpar/regression.py:92-180
-directly from a `{name: value}` dictionary of hyper-parameters (the dictionary `GPARRegressor.get_variables()`
-returns), without importing anything from the product.  Dense and inducing-point (VFE) paths.
+`_update_inputs`), :325-362 (`per_output`), :116-149 (`GPAR.__or__`: conditioning), :245-277 (`GPAR.sample`) and the per-layer
+kernel of /root/reference/gpar/regression.py:92-180 directly from a `{name: value}` dictionary of hyper-parameters (the
+dictionary `GPARRegressor.get_variables()` returns), without importing anything from the product: own kernels, own
+missing-data bookkeeping, `slogdet` + `solve` (oracle/gp_ref.py) instead of any factorisation the product composes.  Dense and
+inducing-point (VFE) paths.
+
+What each public function pins:
+  gpar_logpdf            GPARRegressor.logpdf / GPAR.logpdf (values);
+  gpar_predict_moments   condition + predict when `replace=True` (regression.py:339-389, 566-597; model.py:116-149, 245-277, 291-322):
+                         the posterior mean replaces every sampled column, so layer i's inputs at x* are deterministic and every
+                         sample of layer i is a draw from N(mean_i(x*_i), cov_i(x*_i) [+ noise_i / w*]) - predictive means and
+                         variances in closed form, which the Monte-Carlo `predict` converges to and the product's analytic
+                         `predict_moments` must equal;
+  fd_gradient            the gradient `fit` needs (regression.py:434-459, autograd there): central differences of gpar_logpdf in
+                         every entry of the hyper-parameter dictionary, with `bounds` / `to_unconstrained` (varz's `bnd` map,
+                         regression.py:101-173) to carry it to the optimiser's variables.
 """
 import numpy as np
 
 from . import gp_ref
 
-__all__ = ["layer_spec", "gpar_logpdf"]
+__all__ = ["layer_spec", "gpar_logpdf", "gpar_predict_moments", "fd_gradient", "bounds", "to_unconstrained"]
 
 
 def _indices(m, pi, markov):
@@ -119,3 +133,123 @@ def gpar_logpdf(x, y, w, hypers, config, impute=False, replace=False, eps=1e-12,
                 x_ind = np.concatenate([x_ind, estimate(x_ind)[:, None]], axis=1)
             x = np.concatenate([x, col[:, None]], axis=1)
     return total
+
+
+def _normalisation(y, normalise_y):
+    """Per-output mean and POPULATION standard deviation over the observed entries (regression.py:339-389; lab's B.std is ddof = 0;
+    an output with zero spread keeps scale 1, :366-370)."""
+    p = y.shape[1]
+    if not normalise_y:
+        return np.zeros(p), np.ones(p)
+    mean = np.array([np.mean(y[~np.isnan(y[:, i]), i]) for i in range(p)])
+    std = np.array([np.std(y[~np.isnan(y[:, i]), i]) for i in range(p)])
+    std = np.where(std > 0, std, 1.0)
+    return mean, std
+
+
+def gpar_predict_moments(x, y, w, hypers, config, xs, ws=None, latent=False, impute=True, replace=True, eps=1e-12, x_ind=None,
+                         normalise_y=True):
+    """Predictive mean and variance (n* x p each) of a GPAR conditioned on (x, y, w), at inputs xs, for `replace=True`.
+
+    Conditioning (model.py:116-149 through `_update_inputs`, :291-322): layer i sees the rows `per_output` keeps, is conditioned
+    on its observed entries, and hands the next layer the column in which observed entries are REPLACED by the posterior mean and
+    missing ones imputed by it (impute and replace: the whole column is the posterior mean, :310-311).  Prediction (model.py:245-277
+    with obs = None: `estimate` is the mean of the conditioned layer): x*_{i+1} = [x*_i, mean_i(x*_i)], a deterministic chain, so
+    the draws of layer i are N(mean_i(x*_i), cov_i(x*_i)) + (unless `latent`) N(0, noise_i / w*_i) and the Monte-Carlo mean /
+    variance of `predict` have these limits.  Outputs are un-normalised as regression.py:551-552 does."""
+    if not replace:
+        raise ValueError("closed-form predictive moments exist only for replace=True (otherwise samples are fed forward)")
+    x = np.asarray(x, dtype=np.float64)
+    x = x[:, None] if x.ndim == 1 else x
+    xs = np.asarray(xs, dtype=np.float64)
+    xs = xs[:, None] if xs.ndim == 1 else xs
+    y = np.asarray(y, dtype=np.float64)
+    y = y[:, None] if y.ndim == 1 else y
+    w = np.ones_like(y) if w is None else np.asarray(w, dtype=np.float64)
+    m, p = x.shape[1], y.shape[1]
+    ws = np.ones((xs.shape[0], p)) if ws is None else np.asarray(ws, dtype=np.float64)
+    offset, scale = _normalisation(y, normalise_y)
+    y = (y - offset) / scale
+    sparse = x_ind is not None
+    if sparse:
+        x_ind = np.asarray(x_ind, dtype=np.float64)
+        x_ind = x_ind[:, None] if x_ind.ndim == 1 else x_ind
+    available = ~np.isnan(y)
+    means, variances = [], []
+    for i in range(p):
+        mask = available[:, i].copy()
+        if impute and i < p - 1:
+            mask |= available[:, i + 1:].any(axis=1)
+        x, yi, wi = x[mask], y[mask, i], w[mask, i]
+        y, w, available = y[mask], w[mask], available[mask]
+        spec, noise = layer_spec(hypers, m, i, config)
+        have = ~np.isnan(yi)
+
+        def posterior(points):
+            if sparse:
+                return gp_ref.vfe_posterior(spec, x[have], yi[have], noise / wi[have], x_ind, points, eps=eps)
+            return gp_ref.posterior(spec, x[have], yi[have], noise / wi[have], points, eps=eps)
+
+        mean_s, cov_s = posterior(xs)
+        var_s = np.diag(cov_s) + (0.0 if latent else noise / ws[:, i])
+        means.append(mean_s * scale[i] + offset[i])
+        variances.append(var_s * scale[i] ** 2)
+        if i < p - 1:
+            col = yi.copy()
+            mean_x = posterior(x)[0]
+            if impute:
+                col[~have] = mean_x[~have]
+            col[have] = mean_x[have]   # replace
+            if sparse:
+                x_ind = np.concatenate([x_ind, posterior(x_ind)[0][:, None]], axis=1)
+            x = np.concatenate([x, col[:, None]], axis=1)
+            xs = np.concatenate([xs, mean_s[:, None]], axis=1)
+    return np.stack(means, axis=1), np.stack(variances, axis=1)
+
+
+def bounds(name):
+    """(lower, upper) of the optimiser's map for a hyper-parameter name, or None for an unconstrained one
+    (regression.py:101-173: varz `bnd` defaults [1e-4, 1e4]; the RQ shapes [1e-3, 1e3]; the noise lower bound 1e-8; the additive
+    constant of the input-linear term is `vs.get`, unconstrained)."""
+    if name.endswith("/input/lin/const"):
+        return None
+    if name.endswith("/alpha"):
+        return 1e-3, 1e3
+    if name.endswith("/noise"):
+        return 1e-8, 1e4
+    return 1e-4, 1e4
+
+
+def to_unconstrained(name, value, grad):
+    """d / d(latent) from d / d(value) for varz's bounded map value = lower + (upper - lower) sigmoid(latent):
+    d value / d latent = (value - lower)(upper - value) / (upper - lower)."""
+    b = bounds(name)
+    if b is None:
+        return np.asarray(grad, dtype=np.float64)
+    lo, hi = b
+    value = np.asarray(value, dtype=np.float64)
+    return np.asarray(grad, dtype=np.float64) * (value - lo) * (hi - value) / (hi - lo)
+
+
+def fd_gradient(x, y, w, hypers, config, names=None, rel_step=1e-3, **kw):
+    """{name: d gpar_logpdf / d hypers[name]} by fourth-order central differences, entry by entry:
+    (-f(+2h) + 8 f(+h) - 8 f(-h) + f(-2h)) / 12h with h = rel_step * max(|value|, 1e-3).  The wide step is deliberate: with
+    inducing points the value goes through K_zz^-1 at a jitter of 1e-12 and carries rounding noise of ~1e-8 relative, which a
+    step of 1e-6 turns into 1e-4 of the gradient; at h = 1e-3 the noise term is 1e-7 and the truncation term (h^4) below it."""
+    out = {}
+    for name in (sorted(hypers) if names is None else names):
+        base = np.array(hypers[name], dtype=np.float64)
+        grad = np.zeros_like(base)
+        flat = base.reshape(-1)
+        for j in range(flat.size):
+            h = rel_step * max(abs(flat[j]), 1e-3)
+            vals = {}
+            for k in (-2, -1, 1, 2):
+                moved = flat.copy()
+                moved[j] += k * h
+                trial = dict(hypers)
+                trial[name] = moved.reshape(base.shape)
+                vals[k] = gpar_logpdf(x, y, w, trial, config, **kw)
+            grad.reshape(-1)[j] = (-vals[2] + 8.0 * vals[1] - 8.0 * vals[-1] + vals[-2]) / (12.0 * h)
+        out[name] = grad
+    return out

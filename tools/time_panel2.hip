@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
     PanelArgs p{A, N, lda, 0, S, nullptr, nullptr, st};
     p.progressive = argc > 2 ? atoi(argv[2]) : 1;
     p.pairs = 1;
+    p.split = p.progressive && (argc > 3 ? atoi(argv[3]) : 1);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -28,9 +29,11 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 12; ++rep) {
         for (int r = 0; r < N; ++r) hipMemcpyAsync(A + (size_t)r * lda, h.data() + (size_t)r * 512, 512 * 8, hipMemcpyHostToDevice, 0);
         hipMemsetAsync(A + 8, 0, 56 * 8, 0);
+        hipMemsetAsync(A + 2 * (size_t)lda + 8, 0, 56 * 8, 0);
+        hipMemsetAsync(A + 3 * (size_t)lda + 8, 0, 56 * 8, 0);
         hipMemsetAsync(st, 0, 8 * nst, 0);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R), dim3(256), P2_LDS_BYTES, 0, p);
+        hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R - S + (p.split ? S + (S - 1) * (S - 2) / 2 : S)), dim3(256), P2_LDS_BYTES, 0, p);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -47,7 +50,7 @@ int main(int argc, char** argv) {
                 memcpy(&v, &out[(size_t)r * 512 + c], 8);
                 h = (h ^ v) * 1099511628211ull;
             }
-        printf("progressive = %d: lower-trapezoid hash %016llx, L[N-1][511] = %.17g\n", p.progressive, h, out[(size_t)(N - 1) * 512 + 511]);
+        printf("progressive = %d split = %d: lower-trapezoid hash %016llx, L[N-1][511] = %.17g\n", p.progressive, p.split, h, out[(size_t)(N - 1) * 512 + 511]);
     }
     std::vector<long long> s(nst);
     hipMemcpy(s.data(), st, 8 * nst, hipMemcpyDeviceToHost);
@@ -68,7 +71,17 @@ int main(int argc, char** argv) {
         printf("   helper (start r3 r4 r5 r6 r7 | end r3 r4 r5):");
         for (int k = 0; k < 8; ++k) printf(" %7.2f", us(at(t, 9, k)));
         printf("\n");
+        for (int ww = 1; ww < 4; ++ww) {
+            printf("      wave %d at the barrier:", ww);
+            for (int k = 0; k < 8; ++k) printf(" %7.2f", us(at(t, 10 + ww, k)));
+            printf("\n");
+        }
     }
+    for (int t = 1; t < S; ++t)
+        for (int cc = 13; cc < 15; ++cc) {
+            printf("  t=%d last strip, sub-step %d: flag/issue %7.2f landed %7.2f strip %7.2f xout+dself %7.2f barrier %7.2f xstore+dcross %7.2f\n", t, cc - 12,
+                   us(at(t, cc, 0)), us(at(t, cc, 1)), us(at(t, cc, 2)), us(at(t, cc, 3)), us(at(t, cc, 4)), us(at(t, cc, 5)));
+        }
     printf("bulk row blocks 8..15: per column c: start, chunks done, triangle available, in LDS, strip done\n");
     for (int rb = 8; rb < 16 && rb < R; rb += 7)
         for (int c = 0; c < S; ++c)
