@@ -267,10 +267,19 @@ class GPARRegressor:
         inducing locations comes from the same device passes as the joint gradient of `fix=False`)."""
         self.condition(x, y, w)
         if greedy:
+            # (as the reference, regression.py:409-410 and its test tests/test_regression.py:241-243; the search itself is
+            # `greedy_order` below - an addition, not a change of this call)
             raise NotImplementedError("Greedy search is not implemented yet.")
         if optimise_x_ind and not self.sparse:
             raise ValueError("optimise_x_ind needs inducing points (x_ind)")
+        self._train(range(self.p), fix, optimise_x_ind, **kw_args)
+
+    def _train(self, layers, fix=True, optimise_x_ind=False, concurrent=True, **kw_args):
+        """Train the given layers of the conditioned model, one after the other (or, where they do not feed one another, on the
+        engine's worker streams); returns {layer: final value of its objective}."""
         self._x_ind_trainable = bool(optimise_x_ind) or getattr(self, "_x_ind_trainable", False)
+        layers = list(layers)
+        finals = {}
         eng = get_engine()
         x_dev, y_dev, w_dev = eng.tensor(self.x), eng.tensor(self.y), eng.tensor(self.w)
         if y_dev.is_cuda and host_masks():
@@ -299,24 +308,79 @@ class GPARRegressor:
             names = [f"{pi}/*"] if fix else [f"{i}/*" for i in range(pi + 1)]
             if optimise_x_ind:
                 names = names + ["x_ind"]
-            minimise_l_bfgs_b(objective, self.vs, names=names, **kw_args)
+            finals[pi] = minimise_l_bfgs_b(objective, self.vs, names=names, **kw_args)
             if optimise_x_ind and "x_ind" in self.vs:
                 self.x_ind = self.vs["x_ind"].detach().clone()
 
         from .parallel import layers_train_independently
 
         streams = eng.worker_streams(rows=self.n) if hasattr(eng, "worker_streams") else []
-        if fix and self.p > 1 and len(streams) > 1 and layers_train_independently(self, y_dev):
+        if concurrent and fix and len(layers) > 1 and len(streams) > 1 and layers_train_independently(self, y_dev):
             # Layers whose inputs are data and whose hyper-parameters are their own train independently of one another:
             # two host threads, each on its own stream, keep two L-BFGS-B drivers in flight so that one layer's
             # latency-bound stretches (panel chains, host-side optimiser steps) run under the other's GEMMs.  The result
             # is the serial one: every evaluation is the same deterministic device computation.
             with torch.no_grad():  # lazily created variables must all exist before the store is shared between threads
                 _construct_gpar(self, self.vs, self.m, self.p).logpdf(x_dev[:2], y_dev[:2], w_dev[:2])
-            _run_on_streams(eng, streams, [[pi for pi in range(k, self.p, len(streams))] for k in range(len(streams))], train_layer)
+            _run_on_streams(eng, streams, [layers[k::len(streams)] for k in range(len(streams))], train_layer)
         else:
-            for pi in range(self.p):
+            for pi in layers:
                 train_layer(pi)
+        return finals
+
+    def greedy_order(self, x, y, w=None, **kw_args):
+        """Greedy search for the ORDER of the outputs - the reference's open item (regression.py:400 `greedy`, :409-410
+        NotImplementedError, todo.tasks:8; Requeima et al. 2019, section 5: "greedily select the output that maximises the
+        log marginal likelihood conditioned on the already selected ones") as an ADDITION: `fit(greedy=True)` keeps raising.
+
+        Position by position: every remaining output is trained as the next layer - inputs x and the outputs chosen so far,
+        exactly the layer `fit(fix=True)` would train there, same initial values, same L-BFGS-B keyword arguments (`iters`,
+        `f_calls`, `trace`) - and the one with the largest trained log marginal likelihood of that layer is kept.  That is
+        p (p + 1) / 2 layer fits; the candidates of a position are independent of one another and are trained concurrently on the
+        engine's worker streams where layers do not feed one another (complete data, no `replace`, no inducing points).
+
+        Returns (order, values): `order[i]` is the column of y placed at position i, `values[i]` the log marginal likelihood of
+        that layer after training (of the normalised outputs, as `fit` sees them).  The trained hyper-parameters of the chosen
+        chain are kept in `self.greedy_vs_` (layer i there belongs to output `order[i]`): `reg.vs = reg.greedy_vs_.copy();
+        reg.fit(x, y[:, order], ...)` continues from them.  `self` is conditioned on (x, y, w) in the GIVEN order, as after
+        `condition`."""
+        from .vars import Vars
+
+        self.condition(x, y, w)
+        eng = get_engine()
+        x_host, y_host, w_host = self.x, self.y, self.w
+        order, values, remaining = [], [], list(range(self.p))
+        chain_vs = Vars(dtype=torch.float64)
+        config = dict(self.model_config)
+        streams = eng.worker_streams(rows=self.n) if hasattr(eng, "worker_streams") else []
+        independent = not self.replace and not self.sparse and not bool(torch.isnan(y_host).any())
+        for k in range(self.p):
+            results = {}
+
+            def trial(c):
+                cols = order + [c]
+                reg = GPARRegressor(replace=self.replace, impute=self.impute, x_ind=self.x_ind, normalise_y=False,
+                                    sparse_method=self.sparse_method, **config)
+                reg.vs = chain_vs.copy(detach=True)
+                reg.condition(x_host, y_host[:, cols], w_host[:, cols])
+                final = reg._train([k], fix=True, concurrent=False, **kw_args)[k]
+                results[c] = (-float(final), reg.vs)
+
+            if independent and len(streams) > 1 and len(remaining) > 1:
+                lanes = min(len(streams), len(remaining))
+                _run_on_streams(eng, streams[:lanes], [remaining[j::lanes] for j in range(lanes)], trial)
+            else:
+                for c in remaining:
+                    trial(c)
+            # (ties - identical columns - go to the lower column index: the order of `remaining`)
+            best = max(remaining, key=lambda c: (results[c][0], -c))
+            order.append(best)
+            values.append(results[best][0])
+            chain_vs = results[best][1]
+            remaining.remove(best)
+        self.greedy_vs_ = chain_vs
+        self.greedy_order_ = list(order)
+        return order, values
 
     def _prepare_kernels(self, m, p, rows, training=False, inputs=False):
         """Have the engine compile the layers' run-time specialised device kernels up front and concurrently (HipEngine.prepare);

@@ -812,3 +812,26 @@ def test_one_call_objective_and_gradient_return_the_same_bits(monkeypatch, kw, n
         assert np.array_equal(g, got["0"][1][name]), name
     for name, v in got["4096fit"].items():
         assert np.array_equal(v, got["0fit"][name]), name
+
+
+def test_greedy_order_is_the_same_on_both_engines():
+    """`GPARRegressor.greedy_order` (the reference's unimplemented greedy search, gpar/regression.py:400, 409-410) on the HIP engine
+    - candidates of a position trained concurrently on the worker streams - and on the numpy engine: the same order and, after the
+    same number of L-BFGS-B iterations from the same initial values, the same trained layer likelihoods (rtol 1e-6; the iterates
+    agree to rounding, `test_fit_matches_oracle_training`)."""
+    from gpar_amd.regression import GPARRegressor
+
+    x = np.linspace(0, 1, 200)
+    f1 = -np.sin(10 * np.pi * (x + 1)) / (2 * x + 1) - x**4
+    f2 = np.cos(f1) ** 2 + np.sin(3 * x)
+    f3 = f2 * f1**2 + 3 * x
+    y = np.stack([f3, f1, f2], axis=1) + 0.1 * np.random.default_rng(1).standard_normal((200, 3))
+    x, y = x[::2], y[::2]
+
+    def run():
+        reg = GPARRegressor(scale=0.1, linear=True, linear_scale=10.0, nonlinear=True, nonlinear_scale=0.1, noise=0.1, normalise_y=False)
+        return reg.greedy_order(x, y, iters=15)
+
+    ref, got = _on("oracle", run), _on("hip", run)
+    assert got[0] == ref[0] == [1, 2, 0]
+    np.testing.assert_allclose(got[1], ref[1], rtol=1e-6)
