@@ -13,7 +13,12 @@ prints ONE JSON line.  Besides the contract fields it carries
   cpu_baseline  the reference's CPU path restated on torch-CPU fp64 operators (oracle/torch_cpu.py, kind "port"), timed
                 on this box's host cores on a bounded sample of the same workload;
   fit_predict   wall-clock of `fit(iters=20)` + `predict(num_samples=100)` at the same size (the other half of BASELINE's metric);
-  config_grid   log marginal likelihood wall-clock of BASELINE.json's other configurations (C2, C4, C5; C5 with its predict leg).
+  config_grid   log marginal likelihood wall-clock of BASELINE.json's other configurations (C1, C2, C4, C5; C2 / C5 with their
+                predict legs), each with the torch-CPU port timed beside it (`cpu_baseline`: C1 and C2 in full, C4 and C5 one
+                full-size layer x p), the lone factorisation n = 1024 .. 16384, and `p1_ms_per_step` (the evaluation one rank
+                runs at N = 8);
+  small_n       the small-problem crossover: logpdf and fit(iters=20) at n = 100, 400, 1024, 2048 (m = 2, p = 4), GPU and CPU.
+BASELINE.md section 4's table can be filled from this one line.
 """
 import argparse
 import json
@@ -190,14 +195,16 @@ def main():
     launches, ms, busy, flops = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     lib.gpar_profile_read(ctypes.byref(launches), ctypes.byref(ms), ctypes.byref(busy), ctypes.byref(flops), 1)
     busy_ms = [1e3 * timing.get("busy_s", 0.0) / max(args.steps, 1)]
+    collective_ms = [1e3 * timing.get("collective_s", 0.0) / max(args.steps, 1)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor(busy_ms, dtype=torch.float64, device=eng.device)
+        mine = torch.tensor(busy_ms + collective_ms, dtype=torch.float64, device=eng.device)
         everyone = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(everyone, mine)
-        busy_ms = [float(b.item()) for b in everyone]
+        busy_ms = [float(b[0].item()) for b in everyone]
+        collective_ms = [float(b[1].item()) for b in everyone]
 
     out = {
         "metric": "logpdf_per_s",
@@ -215,12 +222,17 @@ def main():
         "config": {
             "workload": f"C3 dense GPAR log marginal likelihood: n={n} m={m} p={p} markov=2 linear+nonlinear output kernels, "
                         f"noise=0.1, inputs resident in HBM",
-            "parallelism": f"layer-parallel x{world} (layer i on rank i mod {world}; 8-byte all-reduce only)",
+            "parallelism": f"layer-parallel x{world} (layer i on rank i mod {world}; 8-byte all-reduce only)"
+                           + ("" if world > 1 else "; no N > 1 run of this code exists in the builder's records - the multi-GPU path is exercised "
+                                                   "on CPU ranks (gloo) and on 1-rank RCCL only, its scaling is predicted from one box (DESIGN section 6)"),
             "logpdf": float(value),
             "layers_per_rank": [len(range(r, p, world)) for r in range(world)],
+            "layers_of_rank": [list(range(r, p, world)) for r in range(world)],
         },
-        # wall-clock each rank spent on its own layers per step, up to the collective: the slowest one bounds the step
+        # wall-clock each rank spent on its own layers per step, up to the collective (the slowest one bounds the step), and in the
+        # 8-byte all-reduce (for a fast rank: the wait for the slowest)
         "per_rank_busy_ms": busy_ms,
+        "per_rank_collective_ms": collective_ms,
         # is the oracle pinned against the real reference?  tests/golden/reference_cases.json is written by
         # tests/golden/make_reference_golden.py wherever gpar + stheno are installed (not here: no network)
         "parity_pin": parity_pin(),
@@ -309,9 +321,17 @@ def main():
         # the other BASELINE.json configurations on the same GPU, in the same run (parity-test cases, not the headline)
         del x, y, w
         try:
-            out["config_grid"] = config_grid_leg(eng)
+            out["config_grid"] = config_grid_leg(eng, cpu=not args.no_cpu)
         except Exception as exc:
             out["config_grid"] = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            out["config_grid"]["p1_ms_per_step"] = p1_leg(eng, n, m)
+        except Exception as exc:
+            out["config_grid"]["p1_ms_per_step"] = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            out["small_n"] = small_n_leg(eng) if not args.no_cpu else None
+        except Exception as exc:
+            out["small_n"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_leg(x_np, y_np, m, p, budget_s=args.cpu_budget)
     emit()
@@ -319,6 +339,32 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     watchdog.cancel()
+
+
+def p1_leg(eng, n, m, evals=5):
+    """One layer of the headline workload alone on the GPU - the evaluation ONE RANK runs when the eight layers of C3 are spread
+    over eight GPUs (Gram build + gpar_potrf + value; the widest layer: two output columns in its inputs)."""
+    import torch
+
+    from gpar_amd.regression import _construct_gpar
+
+    x_np, y_np = synthetic(n, m + 2, 1, seed=4321)   # (m + 2 input columns stand for [x, y_(i-2), y_(i-1)] under markov = 2)
+    reg = c3_regressor()
+    gpar = _construct_gpar(reg, reg.vs, m + 2, 1)
+    x, y = eng.tensor(x_np), eng.tensor(y_np)
+    w = torch.ones_like(y)
+    for _ in range(2):
+        float(gpar.logpdf(x, y, w))
+    times = []
+    for _ in range(evals):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        float(gpar.logpdf(x, y, w))
+        torch.cuda.synchronize()
+        times.append(1e3 * (time.perf_counter() - t0))
+    flops = float(n) ** 3 / 3.0 + float(n) ** 2
+    return {"ms_best": min(times), "ms_median": float(np.median(times)), "frac_of_fp64_matrix_peak": flops / (min(times) * 1e-3) * 1e-12 / FP64_MATRIX_PEAK_TFLOPS,
+            "note": "a single dense layer at n = %d with %d input columns: what each rank evaluates per step at N = 8" % (n, m + 2)}
 
 
 def parity_pin():
@@ -407,7 +453,20 @@ def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=20, num_samples=1
         mean = sharded_predict(reg, xs, num_samples=num_samples, latent=True)   # (samples stay on the device; gpar_sample_stats)
     sync()
     t2 = time.perf_counter()
-    leg = {"fit_ms": 1e3 * (t1 - t0), "fit_iters": fit_iters, "fit_evaluations": optimise.evaluation_count() - evals_before,
+    evaluations = optimise.evaluation_count() - evals_before
+    # algorithmic flops: one training evaluation of one layer = n^3 / 3 (factorisation) + 2 n^3 / 3 (inverse from the
+    # factor) = n^3; predict = p conditionings (n^3 / 3 each) + per (layer, sample) n^2 n* + n n*^2 + n*^3 / 3
+    fit_flops = evaluations * float(n) ** 3
+    predict_flops = p * float(n) ** 3 / 3.0 + p * num_samples * (float(n) ** 2 * n_star + float(n) * n_star**2 + n_star**3 / 3.0)
+    leg = {"fit_ms": 1e3 * (t1 - t0), "fit_iters": fit_iters, "fit_evaluations": evaluations,
+           "fit_algorithmic_flops": fit_flops,
+           "fit_frac_of_fp64_matrix_peak": fit_flops / max(t1 - t0, 1e-9) * 1e-12 / FP64_MATRIX_PEAK_TFLOPS / world,
+           "predict_algorithmic_flops": predict_flops,
+           "predict_frac_of_fp64_matrix_peak": predict_flops / max(t2 - t1, 1e-9) * 1e-12 / FP64_MATRIX_PEAK_TFLOPS / world,
+           "flops_note": "SURVEY 8(d): training evaluation of a layer = n^3 (n^3/3 factorisation + 2n^3/3 inverse), one evaluation per "
+                         "L-BFGS-B function call of each layer's own optimisation; predict = p n^3/3 + p S (n^2 n* + n n*^2 + n*^3/3): the "
+                         "REFERENCE's algorithm (a triangular solve of n* columns per layer and sample) - fractions are algorithmic "
+                         "flops / wall-clock / (78.6 TF x GPUs), whatever the implementation shares between samples",
            "predict_ms": 1e3 * (t2 - t1), "num_samples": num_samples, "n_star": n_star,
            "fit_predict_ms": 1e3 * (t2 - t0), "predict_mean_abs": float(np.mean(np.abs(mean))), "n_gpus": world, "fit_parallelism": fit_mode,
            "timing": "barrier-bracketed wall-clock on rank 0; predict = joint ancestral sampling exactly as the reference's "
@@ -432,13 +491,14 @@ def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=20, num_samples=1
 
 
 GRID = {
+    "C1": dict(n=25, m=1, p=3, kw=dict(scale=0.1, linear=True, linear_scale=10.0, nonlinear=True, nonlinear_scale=0.1, noise=0.1)),
     "C2": dict(n=4096, m=2, p=4, kw=dict(scale=0.5, linear=True, nonlinear=False, noise=0.1)),
     "C4": dict(n=65536, m=8, p=4, M=1024, kw=dict(scale=0.5, linear=True, nonlinear=True, noise=0.1)),
     "C5": dict(n=8192, m=3, p=16, kw=dict(scale=0.5, per=True, rq=True, linear=True, nonlinear=True, noise=0.1)),
 }
 
 
-def config_grid_leg(eng, evals=5, warmup=2):
+def config_grid_leg(eng, evals=5, warmup=2, cpu=True):
     """Log marginal likelihood of BASELINE.json's other configurations (C2 dense n = 4096, C4 inducing points n = 65536 / M = 1024,
     C5 periodic + RQ n = 8192 p = 16) on one GPU: best and median wall-clock of `evals` evaluations each, with the algorithmic
     flop count against the fp64 matrix peak; C5 also times its second leg, predict(num_samples=200)."""
@@ -449,7 +509,7 @@ def config_grid_leg(eng, evals=5, warmup=2):
     grid = {}
     for name, cfg in GRID.items():
         n, m, p = cfg["n"], cfg["m"], cfg["p"]
-        x_np, y_np = synthetic(n, m, p)
+        x_np, y_np = paper_synthetic() if name == "C1" else synthetic(n, m, p)
         kw = dict(cfg["kw"], normalise_y=False)
         if "M" in cfg:
             kw["x_ind"] = np.random.default_rng(3).uniform(0, 1, (cfg["M"], m))
@@ -519,6 +579,11 @@ def config_grid_leg(eng, evals=5, warmup=2):
             rec["predict_200_samples_ms"] = 1e3 * (time.perf_counter() - t0)
             rec["predict_n_star"] = 2048
             rec["predict_finite"] = bool(np.isfinite(mean).all() and np.isfinite(lo).all() and np.isfinite(hi).all())
+        if cpu:
+            try:
+                rec["cpu_baseline"] = cpu_config_leg(name, cfg, x_np, y_np, kw)
+            except Exception as exc:  # noqa: BLE001 - the GPU numbers must survive a failure of the baseline
+                rec["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
         grid[name] = rec
         del x, y, reg
         torch.cuda.empty_cache()
@@ -526,7 +591,130 @@ def config_grid_leg(eng, evals=5, warmup=2):
     return grid
 
 
-def lone_factorisation_leg(eng, sizes=(1024, 2048, 4096, 8192)):
+def paper_synthetic(seed=1, n=200, noise=0.1):
+    """BASELINE.json configs[0]: the data of the reference's examples/paper/synthetic.py:11-23 (three chained outputs, every 8th
+    point of a 200-point grid observed: n = 25)."""
+    x = np.linspace(0, 1, n)
+    f1 = -np.sin(10 * np.pi * (x + 1)) / (2 * x + 1) - x**4
+    f2 = np.cos(f1) ** 2 + np.sin(3 * x)
+    f3 = f2 * f1**2 + 3 * x
+    y = np.stack([f1, f2, f3], axis=1) + noise * np.random.default_rng(seed).standard_normal((n, 3))
+    return x[::8, None], y[::8]
+
+
+def layer_specs(kw, m, p):
+    """[(kernel dict, noise)] of the layers of GPARRegressor(**kw) at its initial hyper-parameters, for the torch-CPU port: read off
+    the product's host-side model objects (on the numpy engine, no GPU involved)."""
+    from gpar_amd.engine import set_engine
+    from gpar_amd.regression import GPARRegressor, _construct_gpar
+    from oracle import kernels as ok
+    from oracle.engine import OracleEngine
+
+    previous = set_engine(OracleEngine())
+    try:
+        reg = GPARRegressor(**{k: v for k, v in kw.items() if k != "x_ind"})
+        gpar = _construct_gpar(reg, reg.vs, m, p)
+        out = []
+        for pi in range(p):
+            f, noise = gpar.layers[pi]()
+            out.append((ok.spec_to_dict(f.kernel.resolve(m + pi)), float(noise)))
+        return out
+    finally:
+        set_engine(previous)
+
+
+def cpu_config_leg(name, cfg, x_np, y_np, kw):
+    """The torch-CPU port (oracle/torch_cpu.py, the operators the reference's lab.torch backend dispatches to) on one BASELINE
+    configuration: C1 and C2 every layer; C4 (inducing points) and C5 the last, widest layer at full size x p."""
+    import torch
+
+    from oracle import torch_cpu as tc
+
+    threads = tc.set_threads()
+    n, m, p = cfg["n"], cfg["m"], cfg["p"]
+    specs = layer_specs(kw, m, p)
+    x_all = torch.as_tensor(np.concatenate([x_np, y_np], axis=1))
+    layers = range(p) if name in ("C1", "C2") else [p - 1]
+    total, stages_sum = 0.0, {}
+    for pi in layers:
+        spec, noise = specs[pi]
+        design = x_all[:, : m + pi]
+        best = None
+        for _ in range(3 if n <= 1024 else 1):
+            if "M" in cfg:
+                value, stages = tc.layer_vfe_bound(spec, design, y_np[:, pi], np.full(n, noise),
+                                                   np.concatenate([kw["x_ind"], np.zeros((cfg["M"], pi))], axis=1))
+            else:
+                value, stages, _ = tc.layer_logpdf(spec, design, y_np[:, pi], np.full(n, noise))
+            if best is None or sum(stages.values()) < sum(best.values()):
+                best = stages
+        total += sum(best.values())
+        for k, v in best.items():
+            stages_sum[k] = stages_sum.get(k, 0.0) + v
+    scale = 1.0 if name in ("C1", "C2") else float(p)
+    return {"logpdf_ms": 1e3 * total * scale, "cores": threads, "kind": "port",
+            "sample": ("every layer, full size" if scale == 1.0 else f"the last (widest) layer at full size x p = {p}"
+                       + ("; inducing inputs of that layer: the given ones extended by zero columns" if "M" in cfg else "")),
+            "stages_ms": {k: 1e3 * v * scale for k, v in stages_sum.items()}}
+
+
+def small_n_leg(eng, sizes=(100, 400, 1024, 2048), m=2, p=4, iters=20):
+    """The small-problem regime (where GPAR is used most: tens to a few thousand observations): logpdf and fit(iters=20) on the
+    GPU and with the torch-CPU port, same data and initial hyper-parameters (C2's model: linear output dependence)."""
+    import torch
+
+    from gpar_amd.regression import GPARRegressor
+    from oracle import torch_cpu as tc
+
+    kw = dict(scale=0.5, linear=True, nonlinear=False, noise=0.1, normalise_y=False)
+    rows = []
+    threads = tc.set_threads()
+    for n in sizes:
+        x_np, y_np = synthetic(n, m, p)
+        x, y = eng.tensor(x_np), eng.tensor(y_np)
+        reg = GPARRegressor(**kw)
+        for _ in range(3):
+            reg.logpdf(x, y)
+        times = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            float(reg.logpdf(x, y))
+            torch.cuda.synchronize()
+            times.append(1e3 * (time.perf_counter() - t0))
+        fit_ms = None
+        for _ in range(2):   # (the second fit of a size: the first pays first-use costs)
+            trainee = GPARRegressor(**kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            trainee.fit(x_np, y_np, iters=iters)
+            torch.cuda.synchronize()
+            fit_ms = 1e3 * (time.perf_counter() - t0)
+        specs = layer_specs(kw, m, p)
+        x_all = torch.as_tensor(np.concatenate([x_np, y_np], axis=1))
+        cpu_logpdf = 0.0
+        for pi in range(p):
+            best = min(sum(tc.layer_logpdf(specs[pi][0], x_all[:, : m + pi], y_np[:, pi], np.full(n, specs[pi][1]))[1].values())
+                       for _ in range(3))
+            cpu_logpdf += best
+        fit_layers = range(p) if n <= 400 else [p - 1]
+        cpu_fit, cpu_evals = 0.0, 0
+        for pi in fit_layers:
+            _, evals, seconds = tc.layer_fit(specs[pi][0], specs[pi][1], x_all[:, : m + pi], y_np[:, pi], iters=iters)
+            cpu_fit += seconds
+            cpu_evals += evals
+        cpu_scale = 1.0 if n <= 400 else float(p)
+        rows.append({"n": n, "m": m, "p": p, "gpu_logpdf_ms": min(times), "cpu_logpdf_ms": 1e3 * cpu_logpdf,
+                     "gpu_fit_ms": fit_ms, "cpu_fit_ms": 1e3 * cpu_fit * cpu_scale,
+                     "cpu_fit_sample": "every layer" if cpu_scale == 1.0 else f"the last layer x p = {p}",
+                     "cpu_fit_evaluations": int(cpu_evals * cpu_scale)})
+        del x, y
+    return {"rows": rows, "cpu_cores": threads, "fit_iters": iters,
+            "model": "m = 2, p = 4, linear output dependence (C2's model), complete data, normalise_y=False",
+            "cpu_kind": "port: torch-CPU fp64 operators with autograd gradients, scipy L-BFGS-B over log-parameters (oracle/torch_cpu.py)"}
+
+
+def lone_factorisation_leg(eng, sizes=(1024, 2048, 4096, 8192, 16384)):
     """gpar_potrf alone - what every layer of a `fit` and every rank of a layer-parallel evaluation runs - on the augmented
     (n + 1) x (n + 1) matrix of a log marginal likelihood: best of 5, milliseconds per size."""
     import torch
@@ -557,28 +745,6 @@ def lone_factorisation_leg(eng, sizes=(1024, 2048, 4096, 8192)):
         del K0, A, pts
         torch.cuda.empty_cache()
     return out
-
-
-def _leaf_spec(spec):
-    """(leaves, rebuild): the kernel dict's coefficients and length scales as torch leaves for the autograd baseline."""
-    import torch
-
-    leaves = []
-    for term in spec["terms"]:
-        leaves.append(torch.tensor(float(term["coef"]), dtype=torch.float64))
-        for factor in term["factors"]:
-            leaves.append(torch.tensor(list(factor["scales"]), dtype=torch.float64))
-
-    def rebuild(params):
-        it = iter(params)
-        out = {"terms": []}
-        for term in spec["terms"]:
-            coef = next(it)
-            factors = [dict(factor, scales=next(it)) for factor in term["factors"]]
-            out["terms"].append({"coef": coef, "factors": factors})
-        return out
-
-    return leaves, rebuild
 
 
 def cpu_baseline_leg(x_np, y_np, m, p, n_star=2048, num_samples=100, budget_s=30.0):
@@ -659,7 +825,7 @@ def cpu_baseline_leg(x_np, y_np, m, p, n_star=2048, num_samples=100, budget_s=30
                 f"scaled to p={p} layers x {num_samples} samples",
     }
     if per_layer < 8.0:
-        leaves, rebuild = _leaf_spec(spec)
+        leaves, rebuild = tc.leaf_spec(spec)
         leaves.append(torch.tensor(noise, dtype=torch.float64))
         del L, z
         _, _, stages = tc.layer_objective_and_gradient(lambda ps: rebuild(ps[:-1]), leaves, design, y_np[:, p - 1], noise_index=-1)

@@ -51,7 +51,9 @@ def _needs_estimate(gpar, yi, complete):
 def sharded_logpdf(gpar, x, y, w, group=None, timing=None):
     """`GPAR.logpdf(x, y, w)` with the layers divided over the ranks of `group`; every rank returns the total.
     `timing` (a dict, optional) accumulates under "busy_s" the wall-clock this rank spent on its own layers, i.e. up to
-    the collective (what makes a multi-GPU run interpretable: the slowest rank's busy time bounds the step)."""
+    the collective, and under "collective_s" the time in the 8-byte all-reduce - which includes the wait for the slowest rank (what
+    makes a multi-GPU run interpretable without a second one: the slowest rank's busy time bounds the step, a fast rank's
+    collective time is the imbalance)."""
     import time
 
     t_start = time.perf_counter()
@@ -64,12 +66,15 @@ def sharded_logpdf(gpar, x, y, w, group=None, timing=None):
         local, x, x_ind = _sharded_layers(gpar, x, y, w, x_ind, rank, size, group, local)
     if local.is_cuda:
         local = local.cpu()
+    t_busy = time.perf_counter()
     if timing is not None:
-        timing["busy_s"] = timing.get("busy_s", 0.0) + (time.perf_counter() - t_start)
+        timing["busy_s"] = timing.get("busy_s", 0.0) + (t_busy - t_start)
     if size > 1:
         buf = local.detach().to(device=eng.device, dtype=torch.float64).reshape(1).clone()
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         local = buf[0].cpu()
+        if timing is not None:   # (includes the wait for the slowest rank: busy + collective = the step on every rank)
+            timing["collective_s"] = timing.get("collective_s", 0.0) + (time.perf_counter() - t_busy)
     return local
 
 

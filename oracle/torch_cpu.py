@@ -18,7 +18,8 @@ import time
 import numpy as np
 import torch
 
-__all__ = ["set_threads", "cpu_quota", "gram", "layer_logpdf", "layer_objective_and_gradient", "layer_posterior_sample"]
+__all__ = ["set_threads", "cpu_quota", "gram", "layer_logpdf", "layer_vfe_bound", "layer_objective_and_gradient", "layer_posterior_sample",
+           "leaf_spec", "layer_fit"]
 
 EPSILON = 1e-12  # lab's B.epsilon
 
@@ -159,3 +160,88 @@ def layer_posterior_sample(spec, x, L, z, x_star, noise_star, generator=None):
     draw = mean + Ls @ torch.randn(x_star.shape[0], 1, dtype=torch.float64, generator=generator)
     t3 = time.perf_counter()
     return draw, {"gram_s": t1 - t0, "solve_s": t2 - t1, "potrf_s": t3 - t2}
+
+
+def layer_vfe_bound(spec, x, y, noise_diag, z):
+    """Titsias' bound of one layer with inducing inputs z, in the order stheno's PseudoObs evaluates it:
+    L_z = chol(K_zz + eps I), B = L_z^-1 K_zx D^-1/2, A = I + B B^T, c = B D^-1/2 y;  returns (value, seconds per stage)."""
+    x, z = _as_torch(x), _as_torch(z)
+    y, d = _as_torch(y).reshape(-1, 1), _as_torch(noise_diag).reshape(-1)
+    n, M = x.shape[0], z.shape[0]
+    t0 = time.perf_counter()
+    Kzz = gram(spec, z) + EPSILON * torch.eye(M, dtype=torch.float64)
+    Kzx = gram(spec, z, x)
+    # diagonal of K_xx: the kernels here are stationary + linear; evaluated row by row it would be n tiny launches - mlkernels has an
+    # elementwise path for it, restated: sum over terms of coef * prod(factor(x_i, x_i))
+    diag = torch.zeros(n, dtype=torch.float64)
+    for term in spec["terms"]:
+        prod = torch.ones(n, dtype=torch.float64)
+        for factor in term["factors"]:
+            if factor["type"] == "linear":
+                zf = _features(factor, x)
+                prod = prod * torch.sum(zf * zf, dim=1)
+        diag = diag + term["coef"] * prod
+    t1 = time.perf_counter()
+    Lz = torch.linalg.cholesky(Kzz)
+    B = torch.linalg.solve_triangular(Lz, Kzx, upper=False) / torch.sqrt(d)[None, :]
+    t2 = time.perf_counter()
+    A = torch.eye(M, dtype=torch.float64) + B @ B.T
+    c = B @ (y / torch.sqrt(d)[:, None])
+    t3 = time.perf_counter()
+    La = torch.linalg.cholesky(A)
+    v = torch.linalg.solve_triangular(La, c, upper=False)
+    trace = torch.sum(diag / d) - torch.sum(B * B)
+    value = -0.5 * (2.0 * torch.sum(torch.log(torch.diagonal(La))) + torch.sum(torch.log(2.0 * np.pi * d)) + torch.sum(y * y / d[:, None])
+                    - torch.sum(v * v) + trace)
+    t4 = time.perf_counter()
+    return float(value), {"gram_s": t1 - t0, "solve_s": t2 - t1, "product_s": t3 - t2, "potrf_s": t4 - t3}
+
+
+def leaf_spec(spec):
+    """(leaves, rebuild): the kernel dict's coefficients and length scales as torch leaves for autograd."""
+    leaves = []
+    for term in spec["terms"]:
+        leaves.append(torch.tensor(float(term["coef"]), dtype=torch.float64))
+        for factor in term["factors"]:
+            leaves.append(torch.tensor(list(factor["scales"]), dtype=torch.float64))
+
+    def rebuild(params):
+        it = iter(params)
+        out = {"terms": []}
+        for term in spec["terms"]:
+            coef = next(it)
+            factors = [dict(factor, scales=next(it)) for factor in term["factors"]]
+            out["terms"].append({"coef": coef, "factors": factors})
+        return out
+
+    return leaves, rebuild
+
+
+def layer_fit(spec, noise, x, y, iters=20):
+    """`fit` of ONE layer as the reference runs it (regression.py:434-459): scipy's L-BFGS-B (what varz.minimise_l_bfgs_b
+    drives) over the logarithms of the layer's coefficients, length scales and noise, objective and gradient by torch autograd
+    through Gram, Cholesky and solve.  Returns (final objective, evaluations, seconds)."""
+    import scipy.optimize
+
+    leaves, rebuild = leaf_spec(spec)
+    leaves.append(torch.tensor(float(noise), dtype=torch.float64))
+    shapes = [tuple(leaf.shape) for leaf in leaves]
+    x0 = np.concatenate([np.log(np.abs(leaf.numpy().reshape(-1)) + 1e-300) for leaf in leaves])
+    signs = np.concatenate([np.sign(leaf.numpy().reshape(-1)) + (leaf.numpy().reshape(-1) == 0) for leaf in leaves])
+    count = [0]
+
+    def fg(u):
+        count[0] += 1
+        vals = signs * np.exp(u)
+        params, at = [], 0
+        for shape in shapes:
+            size = int(np.prod(shape)) if shape else 1
+            params.append(torch.tensor(vals[at:at + size].reshape(shape), dtype=torch.float64))
+            at += size
+        value, grads, _ = layer_objective_and_gradient(lambda ps: rebuild(ps[:-1]), params, x, y, noise_index=-1)
+        g = np.concatenate([gr.numpy().reshape(-1) for gr in grads]) * vals
+        return value, g
+
+    t0 = time.perf_counter()
+    _, final, _ = scipy.optimize.fmin_l_bfgs_b(fg, x0, maxiter=iters)
+    return float(final), count[0], time.perf_counter() - t0
