@@ -466,7 +466,9 @@ def fit_predict_leg(eng, x_np, y_np, n, m, p, world, fit_iters=20, num_samples=1
            "flops_note": "SURVEY 8(d): training evaluation of a layer = n^3 (n^3/3 factorisation + 2n^3/3 inverse), one evaluation per "
                          "L-BFGS-B function call of each layer's own optimisation; predict = p n^3/3 + p S (n^2 n* + n n*^2 + n*^3/3): the "
                          "REFERENCE's algorithm (a triangular solve of n* columns per layer and sample) - fractions are algorithmic "
-                         "flops / wall-clock / (78.6 TF x GPUs), whatever the implementation shares between samples",
+                         "flops / wall-clock / (78.6 TF x GPUs), whatever the implementation shares between samples: layer 0's inputs are "
+                         "the same for every sample, so ONE solve serves all of them and the work actually done is ~(p - 1) / p of the "
+                         "predict count (0.97 here means ~0.85 of the matrix peak on the solves that run)",
            "predict_ms": 1e3 * (t2 - t1), "num_samples": num_samples, "n_star": n_star,
            "fit_predict_ms": 1e3 * (t2 - t0), "predict_mean_abs": float(np.mean(np.abs(mean))), "n_gpus": world, "fit_parallelism": fit_mode,
            "timing": "barrier-bracketed wall-clock on rank 0; predict = joint ancestral sampling exactly as the reference's "

@@ -238,8 +238,13 @@ def layer_fit(spec, noise, x, y, iters=20):
             size = int(np.prod(shape)) if shape else 1
             params.append(torch.tensor(vals[at:at + size].reshape(shape), dtype=torch.float64))
             at += size
-        value, grads, _ = layer_objective_and_gradient(lambda ps: rebuild(ps[:-1]), params, x, y, noise_index=-1)
+        try:
+            value, grads, _ = layer_objective_and_gradient(lambda ps: rebuild(ps[:-1]), params, x, y, noise_index=-1)
+        except Exception:  # noqa: BLE001 - a trial point of the line search where the Cholesky fails: varz reports NaN there; a
+            return 1e30, np.zeros_like(u)   # large finite value makes scipy's line search back off the same way
         g = np.concatenate([gr.numpy().reshape(-1) for gr in grads]) * vals
+        if not np.isfinite(value) or not np.all(np.isfinite(g)):
+            return 1e30, np.zeros_like(u)
         return value, g
 
     t0 = time.perf_counter()
