@@ -63,7 +63,6 @@ struct GemmArgs {
     long long part_stride;   // elements between consecutive partial slabs of C (split-K)
     long long batch_a, batch_b, batch_c;   // blockIdx.z selects problem z of a batch: operands advance by these many elements
     int nfull, ntail;    // MIXED launches (see gemm_f64_kernel): blocks [0, nfull) take whole tiles, the 2 * ntail blocks behind them half tiles
-    int sblock;          // > 0: the square lower triangle's tiles are enumerated in sblock x sblock super-blocks (see gemm_tile_body)
     long long* stamps;   // dev aid (tools/time_gemm_phases.hip): per-block s_memrealtime stamps + hardware ids, normally null
     long long* stage_stamps;   // dev aid (tools/time_gemm_stages.hip, compiled with GPAR_GEMM_STAGE_STAMPS): 3 stamps per K stage
     const int* pred;     // role-0 launches inside a predicated solve (common.h: GparPredicate): return at once unless (*pred != 0) == pred_sense
@@ -387,31 +386,6 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs& p, double* smem, const 
     }
     if (tm >= 0) {
         // (mapped above)
-    } else if (p.sblock > 0) {
-        // Square lower triangle in S x S super-blocks (super-block rows top to bottom, super-blocks left to right, tiles row-major
-        // inside one) instead of plain row-major.  An XCD works through a contiguous run of this order with ~64 workgroups resident:
-        // they cover ~S row panels and ~S column panels instead of one row panel and 64 column panels, and the K slice of a panel
-        // that one of them fetched is in that XCD's L2 for the others.  Counted fetches of a lone n = 16384 factorisation:
-        // 40.4 -> 26.4 GB (rocprofv3 --pmc FETCH_SIZE, x2; profiles/r03_gemm_tile_order.txt); time: unchanged - the kernel is not
-        // bound by them -, but a third less traffic on the fabric that the co-running panel kernel shares.
-        const int S = p.sblock, T = p.tiles_m;
-        int I = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5) / S;
-        while ((long long)(I + 1) * S * ((long long)(I + 1) * S + 1) / 2 <= idx) ++I;
-        while ((long long)I * S * ((long long)I * S + 1) / 2 > idx) --I;
-        const int rem = idx - (int)((long long)I * S * ((long long)I * S + 1) / 2);
-        const int R = min(S, T - I * S);
-        if (rem < I * R * S) {
-            const int J = rem / (R * S), l = rem - J * R * S;
-            tm = I * S + l / S;
-            tn = J * S + l % S;
-        } else {
-            const int l = rem - I * R * S;
-            int a = (int)((sqrt(8.0 * (double)l + 1.0) - 1.0) * 0.5);
-            while ((a + 1) * (a + 2) / 2 <= l) ++a;
-            while (a * (a + 1) / 2 > l) --a;
-            tm = I * S + a;
-            tn = I * S + l - a * (a + 1) / 2;
-        }
     } else if (p.flags & GPAR_GEMM_C_LOWER) {
         // lower-trapezoid enumeration: rows tm < tiles_n hold tm+1 tiles, the rest hold tiles_n tiles
         const int tri = p.tiles_n * (p.tiles_n + 1) / 2;
@@ -597,15 +571,8 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     p.ksplit = 0;
     p.part_stride = 0;
     const int ntiles = gemm_num_tiles(p.tiles_m, p.tiles_n, flags);
-    // GPAR_GEMM_TILE_BLOCK = S > 0: the trailing update of a square lower triangle enumerates its tiles in S x S super-blocks (see
-    // gemm_tile_body).  OFF by default: counted fetches of the bench command 734 GB row-major, 492 / 487 / 518 / 549 GB for
-    // S = 4 / 6 / 8 / 12 - and the evaluation 0.2 % SLOWER (182.1 -> 182.4 ms, same box, alternating runs), a lone n = 16384
-    // factorisation 0.6 % (26.03 -> 26.20 ms): the update is not bound by its fetches (profiles/r03_gemm_tile_order.txt).
-    static int tile_block = -1;
-    if (tile_block < 0) { const char* e = getenv("GPAR_GEMM_TILE_BLOCK"); tile_block = e ? atoi(e) : 0; }
-    p.sblock = (tile_block > 0 && tile_block <= 64 && role == 1 && !ta && tb && (flags & GPAR_GEMM_C_LOWER) && p.tiles_m == p.tiles_n && ntiles >= 512 &&
-                !(flags & (GPAR_GEMM_A_LOWER | GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_K_TO_COL)))
-                   ? tile_block : 0;
+    // (A super-block tile order for the trailing update - GPAR_GEMM_TILE_BLOCK, rounds 3-4 - cut its counted fetches by a third and
+    // did not make it faster: the update is not bound by them.  Retired in round 5; the record is NOTES.md section 7.)
     for (const void* fn : {reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>),
                            reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>),
                            reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0, 64>),
@@ -672,7 +639,7 @@ static int gemm_splitk_launch(int ta, int tb, int m, int n, int k, double alpha,
     p.fastA = gpar_aligned16(A) && (lda % 2 == 0);
     p.fastB = gpar_aligned16(B) && (ldb % 2 == 0);
     p.fastC = gpar_aligned16(workspace) && (n % 2 == 0) && (((long long)m * n) % 2 == 0);
-    p.stamps = nullptr; p.stage_stamps = nullptr; p.sblock = 0;
+    p.stamps = nullptr; p.stage_stamps = nullptr;
     p.pred = nullptr; p.pred_sense = 0;
     const int len = gpar_ceil_div(gpar_ceil_div(k, splits), GEMM_BK) * GEMM_BK;
     p.ksplit = len;

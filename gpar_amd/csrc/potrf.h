@@ -635,9 +635,8 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // hand-off flags of all panels zeroed once, ahead of the first panel (panel.h)
     const bool prezero = pol.fused && env_int("GPAR_POTRF_PREZERO", 1) && nf >= 128;
     if (prezero) potrf_zero_flags(A, N, lda, stream, batch, batch_a);
-    const int pair_first = env_int("GPAR_POTRF_PAIR_FIRST", 0);
     auto groupable = [&](int k) {
-        return G > 1 && (k > 0 || pair_first) && pol.fused && nbo % 64 == 0 && k + G * nbo <= nf && (N - k) >= pol.pair_rows && (k % 2 == 0) && (lda % 2 == 0) &&
+        return G > 1 && k > 0 && pol.fused && nbo % 64 == 0 && k + G * nbo <= nf && (N - k) >= pol.pair_rows && (k % 2 == 0) && (lda % 2 == 0) &&
                gpar_aligned16(A);
     };
     // Experiment knob, off: the last `tail` columns through ONE panel kernel (up to 16 column blocks).  Measured slower with the
@@ -752,20 +751,18 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             continue;
         }
         // (1) next panel's columns, on the caller's stream; they were last written by the previous side update.
-        // Two round-3 experiment knobs, both OFF by default because neither paid (profiles/r03_exp_potrf_lookahead.txt; same bits):
+        // One round-3 experiment knob is left, OFF by default because it did not pay (profiles/r03_exp_potrf_lookahead.txt; same bits):
         //   GPAR_POTRF_LA_SPLIT=1        when the next step is a GROUP of panels, only its first panel's columns are updated ahead of
         //                                that panel; the other panels' columns go to the head of the side stream and the in-group
         //                                update waits for them there (n = 16384: 25.94 -> 26.12 ms, 12288: 12.74 -> 12.67, 8192: 5.29 -> 5.21)
-        //   GPAR_POTRF_REST_AFTER_LA=r   with fewer than r rows left the big update is released only after the look-ahead update
-        //                                has finished, so that the next panel kernel is dispatched together with the big update's
-        //                                first round instead of queueing behind it (r = 8192 / 10240 / all: 26.36 / 26.85 / 27.52 ms):
-        //                                the chip is work-conserving as it is - what the panel kernel gains the big update loses.
+        // (Releasing the big update only after the look-ahead update - GPAR_POTRF_REST_AFTER_LA / GPAR_POTRF_BATCH_REST_AFTER_LA -
+        // and factoring the very first panel inside a group - GPAR_POTRF_PAIR_FIRST - were measured negative in rounds 3 and 4 and
+        // retired in round 5: NOTES.md section 7.)
         if (trail_done) GPAR_HIP_TRY(hipStreamWaitEvent(stream, trail_done, 0));
         const bool next_grouped = next_end - kend > nbo && groupable(kend);
         const int la_end = (next_grouped && env_int("GPAR_POTRF_LA_SPLIT", 0)) ? kend + nbo : next_end;
-        const bool rest_after_la = (N - kend) < env_int(batch == 1 ? "GPAR_POTRF_REST_AFTER_LA" : "GPAR_POTRF_BATCH_REST_AFTER_LA", 0);
         hipEvent_t panel_done = la_event();
-        if (!rest_after_la) GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
+        GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
         if (potrf_la_is_small(c, k0, kend, la_end)) {
             rc = potrf_la_update(c, k0, kend, la_end, stream);
         } else {
@@ -774,7 +771,6 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             prof_end(stream, pa, N - kend, la_end - kend, (kend - k0) * batch);
         }
         if (rc) return rc;
-        if (rest_after_la) GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
         // (2) everything to the right of the next panel, on the side stream: first the rest of the next group's columns ...
         GPAR_HIP_TRY(hipStreamWaitEvent(side, panel_done, 0));
         mid_done = nullptr;

@@ -222,17 +222,19 @@ class HipEngine:
 
     def logpdf_dense_grad(self, ck, x, y, noise_diag, jitter):
         """One dense layer's objective and the ingredients of its gradient in one library call: (value as a 0-d device tensor,
-        info word, a function returning (1/2 diag(W) on the device, kernel-parameter gradients) once the host needs them)."""
+        info word, a function returning (1/2 diag(W) on the device, kernel-parameter gradients) once the host needs them, the
+        (n + 1) x (n + 1) factor buffer with its log-determinant word - the factor a later posterior mean or conditioning on the
+        same observations would otherwise compute a second time)."""
         safe = getattr(self._tls, "safe", False)
         depth = getattr(self._tls, "pipe_depth", 0)
-        out, half_diag, info, _ = hip.logpdf_dense_grad(ck, self._mat(x), y, noise_diag, jitter, self._periodic(ck),
+        out, half_diag, info, A = hip.logpdf_dense_grad(ck, self._mat(x), y, noise_diag, jitter, self._periodic(ck),
                                                         lookahead=not safe and depth < 3, fused=not safe)
 
         def gradients():
             raw = out[2:].cpu().numpy()   # (the one device-to-host copy of the backward pass)
             return half_diag, self._grads_from_moments(ck, raw, 0.5)
 
-        return out[0], info, gradients
+        return out[0], info, gradients, (A, out[1:2])
 
     def logpdf_lockstep(self, layers, x, y, w, jitter):
         """The whole lock-step evaluation in one library call: (values, their sum in layer order, info words)."""

@@ -627,11 +627,15 @@ class Obs:
                 and isinstance(self.y, torch.Tensor) and self.y.is_cuda)
 
     def _value(self):
-        if getattr(self, "_fuse_grad", False) and self._fac is None:
+        fuse, self._fuse_grad = getattr(self, "_fuse_grad", False), False   # (decided per call by logpdf(): never sticky)
+        if fuse and self._fac is None:
             eng = self.eng
             ck = eng.compile(self.base.kernel, self.fdd.x.shape[1])
-            value, info, self._fused_gradients = eng.logpdf_dense_grad(ck, self.fdd.x.detach(), self.y, self.fdd.noise, eng.epsilon)
+            value, info, self._fused_gradients, (A, logdet) = eng.logpdf_dense_grad(ck, self.fdd.x.detach(), self.y, self.fdd.noise, eng.epsilon)
             eng.check_info(info)
+            # the call leaves the factor behind: a posterior mean / conditioning on these observations (fit(fix=False), replace,
+            # imputation) takes it from here instead of factoring the same matrix again
+            self._fac = _Factor.from_batch(eng, self.fdd.n, A, logdet)
             return value.detach()
         return self.factor().logpdf()
 
@@ -927,6 +931,21 @@ class Obs:
         return out
 
 
+class _LazyV:
+    """v = L_z^-T A^-1 c of an inducing-point observation, computed at first use (on the stream of that use: a later stream-ordered
+    consumer of the factors)."""
+
+    def __init__(self, eng, facA, Lz):
+        self.eng, self.facA, self.Lz, self.value = eng, facA, Lz, None
+
+    def get(self):
+        if self.value is None:
+            v = self.facA.alpha().clone()  # (A^-1 c)^T, 1 x M
+            self.eng.trsm_rln_(self.Lz, v)
+            self.value = v
+        return self.value
+
+
 class PseudoObs:
     """Inducing-point observations (stheno `PseudoObs(f(x_ind), f(x, noise), y)`) of the process `fdd.p` (prior or
     posterior).  `method` selects the approximation, as stheno's `PseudoObsVFE` (the default, Titsias 2009) /
@@ -981,6 +1000,11 @@ class PseudoObs:
         side = eng.side_stream() if hasattr(eng, "side_stream") and not base.is_posterior and n * M >= (1 << 22) else None
         Lz = eng.new_matrix(M, M)   # (allocated on the caller's stream: its lifetime follows that stream, whatever happens on the side)
         ill = None
+        if side is not None:
+            # Lz belongs to the caller's stream's pool but is written on the side stream: tell the allocator, so that an exception
+            # between here and the join (out of memory in the n x M cross-Gram below, say) cannot hand the block to a new tensor
+            # while the side stream's factorisation is still writing it
+            Lz.record_stream(side)
         try:
             with (_on_side(side) if side is not None else contextlib.nullcontext()):
                 mean_z = base._moments_into(pz, Lz, None, eng.epsilon)
@@ -1066,11 +1090,10 @@ class PseudoObs:
 
             facA = _Factor(eng, M, fill, c)
             elbo = -0.5 * (trace_term + torch.sum(torch.log(d)) + n * _LOG_2PI + facA.logdet[0] + yDy - facA.quad)
-        # v = L_z^-T A^-1 c, so that the mean correction at x* is K_*z v
-        v = facA.alpha().clone()  # (A^-1 c)^T, 1 x M
-        eng.trsm_rln_(Lz, v)
+        # v = L_z^-T A^-1 c, so that the mean correction at x* is K_*z v: two single-row backward solves (0.17 ms at M = 1024) that
+        # only a posterior MEAN needs - the value of the bound does not (the last layer of a log marginal likelihood never asks)
         deferring = getattr(eng, "_deferred", None) is not None
-        self._state = {"Lz": Lz, "La": facA.L, "v": v, "elbo": elbo.detach() if deferring else elbo.detach().cpu(),
+        self._state = {"Lz": Lz, "La": facA.L, "v": _LazyV(eng, facA, Lz), "elbo": elbo.detach() if deferring else elbo.detach().cpu(),
                        "Bs": Bs, "G": G, "facA": facA, "kdiag": kdiag, "ys": ys, "d": d, "solved": ill is None,
                        "moves": (excess > 0).to(d.dtype) if self.method == "fitc" else None}
         return self._state
@@ -1205,7 +1228,7 @@ class PseudoObs:
         X, Z = self.fdd.x.detach(), self.u.x.detach()
         n, M = self.fdd.n, self.u.n
         d = st["d"]  # FITC: the effective noise (its own dependence on the kernel is chained in below)
-        v = st["v"].reshape(-1)
+        v = st["v"].get().reshape(-1)
         pxs = self.base._pts(xs)
         Ksz = eng.gram(ck, pxs.z, self.u.pts().z)  # n* x M
         Kxz = eng.gram(ck, self.fdd.pts().z, self.u.pts().z)  # n x M
@@ -1265,7 +1288,7 @@ class PseudoObs:
     def mean_at(self, p):
         st = self._compute()
         Kz = self.base._cross(p, self.u.pts())
-        corr = self.eng.gemm(Kz, st["v"], tb=True)
+        corr = self.eng.gemm(Kz, st["v"].get(), tb=True)
         return corr if not self.base.is_posterior else self.base._mean_at(p) + corr
 
     # kept for callers that use the stheno-like name
@@ -1319,7 +1342,7 @@ class PseudoObs:
         stacked = xs.matrix if isinstance(xs, Stacked) else torch.cat([_as_matrix(eng, x_s) for x_s in xs], dim=0)
         Kz = eng.new_matrix(sum(sizes), self.u.n)
         eng.gram(ck, eng.features(ck, _as_matrix(eng, stacked)), zu, out=Kz)
-        return list(torch.split(eng.gemm(Kz, st["v"], tb=True), sizes, dim=0))
+        return list(torch.split(eng.gemm(Kz, st["v"].get(), tb=True), sizes, dim=0))
 
     def posterior_marginals_batch(self, xs):
         """(means, variances), each n* x S (no noise):  k_aa - |P_a|^2 + |P_a L_A^-T|^2  per point."""
@@ -1332,7 +1355,7 @@ class PseudoObs:
         for s0 in range(0, S, chunk):
             s1 = min(S, s0 + chunk)
             ck, z_all, Kz, P = self._stacked_P(xs[s0:s1])
-            mean[:, s0:s1] = eng.gemm(Kz, st["v"], tb=True).reshape(s1 - s0, ns).T
+            mean[:, s0:s1] = eng.gemm(Kz, st["v"].get(), tb=True).reshape(s1 - s0, ns).T
             kd = eng.gram_diag(ck, z_all) - eng.rownorm2(P)
             eng.trsm_rlt_(st["La"], P)
             var[:, s0:s1] = (kd + eng.rownorm2(P)).reshape(s1 - s0, ns).T
@@ -1356,7 +1379,7 @@ class PseudoObs:
             s1 = min(S, s0 + chunk)
             K = s1 - s0
             ck, z_all, Kz, P = self._stacked_P(xs[s0:s1])
-            means = eng.gemm(Kz, st["v"], tb=True)
+            means = eng.gemm(Kz, st["v"].get(), tb=True)
             batched = K > 1 and hasattr(eng, "potrf_batch_") and ns <= eng.batch_rows() and not getattr(eng._tls, "safe", False)
             if batched:
                 covs = eng.new_matrix(K * ns, ns)
@@ -1385,7 +1408,7 @@ class PseudoObs:
         eng, st = self.eng, self._compute()
         mean = self.base._moments_into(p, block, diag_add, jitter)
         Kz, P = self._P(p)
-        corr = eng.gemm(Kz, st["v"], tb=True)
+        corr = eng.gemm(Kz, st["v"].get(), tb=True)
         eng.gemm(P, P, tb=True, alpha=-1.0, beta=1.0, out=block, c_lower=True)
         eng.trsm_rlt_(st["La"], P)  # Q = P L_A^-T
         eng.gemm(P, P, tb=True, alpha=1.0, beta=1.0, out=block, c_lower=True)

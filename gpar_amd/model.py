@@ -36,21 +36,21 @@ def one_call_enabled():
     return os.environ.get("GPAR_ONE_CALL", "1") != "0"
 
 
-_LAST_PATTERN = []   # [tensor, version, host pattern] of the last device-resident y whose NaN pattern was fetched
-
-
 def _device_nan_pattern(y):
     """NaN pattern of a device tensor as a host array: one small device-to-host copy - a synchronisation - which an evaluation
-    loop over the SAME outputs (an optimiser, a benchmark: `logpdf(x, y)` again and again) would pay every time.  The last
-    tensor is remembered together with its version counter: the same storage, shape and strides at the same version hold the
-    same values (an in-place write moves the counter; the entry keeps the tensor alive, so its memory cannot have been reused)."""
-    if _LAST_PATTERN:
-        ref, version, pattern = _LAST_PATTERN
-        if (ref.data_ptr() == y.data_ptr() and ref.shape == y.shape and ref.stride() == y.stride() and ref.device == y.device
-                and ref._version == version == y._version):
-            return pattern
+    loop over the SAME outputs (an optimiser, a benchmark: `logpdf(x, y)` again and again) would pay every time.  The pattern is
+    remembered ON THE TENSOR OBJECT (attribute `_gpar_nan`, with the version counter it was taken at): it lives and dies with the
+    caller's tensor, nothing global holds on to it (or to the storage behind a view), and threads training different layers never
+    share an entry.  An in-place torch operation moves the version counter and the pattern is fetched again; a write torch does
+    not see (a raw-pointer kernel, `.data`) does not - after such a write, `del y._gpar_nan`."""
+    cached = getattr(y, "_gpar_nan", None)
+    if cached is not None and cached[0] == y._version:
+        return cached[1]
     pattern = torch.isnan(y).cpu().numpy()
-    _LAST_PATTERN[:] = [y, y._version, pattern]
+    try:
+        y._gpar_nan = (y._version, pattern)
+    except (AttributeError, RuntimeError):  # (a tensor subclass without a __dict__: nothing is remembered)
+        pass
     return pattern
 
 

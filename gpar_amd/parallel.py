@@ -345,6 +345,7 @@ def _minimise_sharded(local_objective, vs, patterns, group, iters=1000, f_calls=
         for t in latents:
             t.requires_grad_(True)
             t.grad = None
+        fatal = None
         try:
             value = local_objective(vs)
             if value.requires_grad:
@@ -354,15 +355,24 @@ def _minimise_sharded(local_objective, vs, patterns, group, iters=1000, f_calls=
         except (NotPositiveDefiniteError, ArithmeticError) as e:  # as varz: report NaN and let the line search back off
             logging.getLogger(__name__).warning("objective evaluation failed (%s); returning NaN", e)
             val, grad = np.nan, np.zeros(dim)
+        except Exception as e:  # noqa: BLE001 - anything else (a hand-off timeout re-raised under autograd, out of memory, a failed
+            # point-to-point transfer) must not leave the other ranks waiting in the all-reduce below: this rank takes part in it,
+            # with a failure flag every rank sees, and all of them raise afterwards
+            fatal = e
+            val, grad = np.nan, np.zeros(dim)
         finally:
             for t, r in zip(latents, previous):
                 t.requires_grad_(r)
                 t.grad = None
-        buf = torch.as_tensor(np.concatenate([[val], grad]), dtype=torch.float64).to(eng.device)
+        buf = torch.as_tensor(np.concatenate([[val], grad, [0.0 if fatal is None else 1.0]]), dtype=torch.float64).to(eng.device)
         if size > 1:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         out = buf.cpu().numpy()
-        val, grad = float(out[0]), out[1:].copy()
+        if out[-1] > 0.0:
+            if fatal is not None:
+                raise fatal
+            raise RuntimeError(f"the joint objective failed on {int(out[-1])} other rank(s) (their exception is raised there)")
+        val, grad = float(out[0]), out[1:-1].copy()
         if not np.isfinite(val):
             val, grad = np.nan, np.zeros(dim)   # some rank's share failed: a failed evaluation for everybody
         if trace and rank == 0:
@@ -384,7 +394,7 @@ def _minimise_sharded(local_objective, vs, patterns, group, iters=1000, f_calls=
         announce(0.0, x_opt)
         vs.set_vector(x_opt, names)
         return val
-    val = np.nan
+    val = np.nan   # (never returned as such: scipy's driver evaluates its starting point, so rank 0 announces at least one evaluation)
     while True:
         ctrl = announce(0.0, np.zeros(dim))
         if ctrl[0] == 0.0:

@@ -48,6 +48,42 @@ def test_struct_layouts_and_version_agree():
         assert re.search(rf"#define\s+{macro}\s+{value}\b", text)
 
 
+def test_integration_document_asserts_the_current_abi_version():
+    """INTEGRATION.md shows a maintainer of the reference the ctypes binding, including the version check: the number asserted
+    there is GPAR_ABI_VERSION of the header (it once stayed at 4 while the library had moved to 5)."""
+    text = open(HEADER).read()
+    version = int(re.search(r"#define\s+GPAR_ABI_VERSION\s+(\d+)", text).group(1))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    asserted = [int(v) for v in re.findall(r"gpar_abi_version\(\)\s*==\s*(\d+)", doc)]
+    assert asserted and all(v == version for v in asserted), (asserted, version)
+    from gpar_amd import _lib
+
+    assert _lib.ABI_VERSION == version
+
+
+def test_build_time_kernel_archive_is_tied_to_the_library():
+    """The archive of build-time compiled kernels carries the ABI version and a fingerprint of the library's kernel generators
+    (csrc/jit.h); the library ignores an archive whose header is not its own - file dates decide nothing."""
+    import struct
+
+    from gpar_amd import _lib, aot
+
+    lib = _lib.load()
+    fingerprint = lib.gpar_aot_fingerprint()
+    assert fingerprint != 0 and fingerprint == lib.gpar_aot_fingerprint()
+    if os.path.exists(aot.ARCHIVE):
+        assert aot.read_header() == (lib.gpar_abi_version(), fingerprint)
+        assert aot.is_current()
+    # a header with another fingerprint is not current
+    import tempfile
+
+    with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+        f.write(aot.MAGIC + struct.pack("<IQ", lib.gpar_abi_version(), fingerprint ^ 1) + struct.pack("<I", 6) + b"gfx950" + struct.pack("<I", 0))
+        f.flush()
+        assert not aot.is_current(f.name)
+        assert aot.read_header(f.name) == (lib.gpar_abi_version(), fingerprint ^ 1)
+
+
 def test_no_cpu_fallback_without_a_gpu():
     import torch
 

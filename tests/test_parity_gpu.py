@@ -767,11 +767,12 @@ def test_nan_pattern_of_device_outputs_is_remembered_until_they_change(hip):
     xd, yd = hip.tensor(x), hip.tensor(y)
     reg = GPARRegressor(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False)
     a = float(reg.logpdf(xd, yd))
-    cached = model._LAST_PATTERN[2]
-    assert float(reg.logpdf(xd, yd)) == a and model._LAST_PATTERN[2] is cached
+    cached = yd._gpar_nan[1]   # (kept on the tensor object itself: nothing global holds the tensor or its pattern)
+    assert float(reg.logpdf(xd, yd)) == a and yd._gpar_nan[1] is cached
     yd[5, 1] = float("nan")
     b = float(reg.logpdf(xd, yd))
-    assert model._LAST_PATTERN[2] is not cached and np.isfinite(b) and b != a
+    assert yd._gpar_nan[1] is not cached and np.isfinite(b) and b != a
+    assert not hasattr(model, "_LAST_PATTERN")
     y2 = y.copy()
     y2[5, 1] = np.nan
     assert abs(b - float(reg.logpdf(x, y2))) <= 1e-12 * abs(b)

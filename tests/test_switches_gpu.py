@@ -21,13 +21,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CALL_TIME = [
     ("GPAR_POTRF_NBO", "256"),
     ("GPAR_PANEL_V", "1"),
+    ("GPAR_PANEL_PROGRESSIVE", "0"),
+    ("GPAR_PANEL_SPLIT", "0"),
     ("GPAR_POTRF_FUSED", "0"),
     ("GPAR_POTRF_LOOKAHEAD", "0"),
     ("GPAR_POTRF_LOOKAHEAD", "1"),
     ("GPAR_POTRF_GROUP", "2"),
     ("GPAR_POTRF_GROUP", "1"),
     ("GPAR_POTRF_PAIR_ROWS", "1024"),
-    ("GPAR_POTRF_PAIR_FIRST", "1"),
     ("GPAR_INVERSE_RECURSIVE", "0"),
     ("GPAR_TRSM_FUSED", "0"),
     ("GPAR_TRSV", "0"),
@@ -54,7 +55,6 @@ CALL_TIME = [
     ("GPAR_POTRF_FUSE_MAX", "8"),
     ("GPAR_ONE_CALL", "0"),
     ("GPAR_LOCKSTEP_FUSED_BUILD_ROWS", "0"),
-    ("GPAR_POTRF_BATCH_REST_AFTER_LA", "100000"),
     ("GPAR_VFE_SPREAD_MAX", "1e3"),
     ("GPAR_LINEAR_TAIL", "0"),
     ("GPAR_GEMV", "0"),
@@ -67,8 +67,7 @@ CALL_TIME = [
     ("GPAR_GRAD_JIT_MIN_ENTRIES", "0"),
     ("GPAR_GRAD_JIT_MIN_ENTRIES", "-1"),
 ]
-CACHED = [("GPAR_AOT", "0"), ("GPAR_AOT_MIN_ENTRIES", "0"), ("GPAR_GEMM_HALF_TILES", "0"), ("GPAR_GEMM_HALF_TILES", "100000"), ("GPAR_GEMM_MIXED_TAIL", "0"), ("GPAR_GEMM_TILE_BLOCK", "0"),
-          ("GPAR_GEMM_TILE_BLOCK", "16")]
+CACHED = [("GPAR_AOT", "0"), ("GPAR_AOT_MIN_ENTRIES", "0"), ("GPAR_GEMM_HALF_TILES", "0"), ("GPAR_GEMM_HALF_TILES", "100000"), ("GPAR_GEMM_MIXED_TAIL", "0")]
 
 
 def _evaluate():
