@@ -67,12 +67,12 @@ def structures():
 def jobs():
     """(kind, compiled kernel) for every kernel the archive holds: the Gram build (narrow structures) and the parameter-gradient pass
     for all; rectangular-weight and input-gradient passes where inducing points / joint training are common."""
-    from .engine import GRAM_JIT_MAX_DZ
+    from .engine import GRAM_JIT_WIDE_MAX_DZ
 
     todo = []
     for ck, periodic, sparse in structures().values():
         zd = 20 if periodic else 0
-        if ck.dz <= GRAM_JIT_MAX_DZ:
+        if ck.dz <= GRAM_JIT_WIDE_MAX_DZ:   # (narrow: the strip kernel; wider than GRAM_JIT_MAX_DZ: the 4 x 4 micro-tile form)
             todo.append((0, ck))
         todo.append((1 + zd, ck))
         if sparse:

@@ -468,6 +468,14 @@ unsigned long long gpar::aot_fingerprint() {
         if (jit_request(kind, ks, 6, jkind, extra, entry, source, true)) mix(entry + "\n" + source);
         else mix("-");
     }
+    {   // ... and the wide form of the Gram generator (more than GRAM_JIT_MAX_DZ feature dims): the same factor types over 20 dims
+        gpar_kspec_t wide = ks;
+        wide.factor[0].nd = 8; wide.factor[1].off = 8; wide.factor[1].nd = 7; wide.factor[2].off = 15; wide.factor[2].nd = 5;
+        std::string source, entry;
+        int jkind = 0, extra = 0;
+        if (jit_request(JIT_GRAM, wide, 20, jkind, extra, entry, source, true)) mix(entry + "\n" + source);
+        else mix("-");
+    }
     mix("abi " + std::to_string(GPAR_ABI_VERSION));
     cached = h ? h : 1ull;
     return cached;

@@ -58,7 +58,8 @@ _HW_QUEUES = None
 # for the layer's structure are used, and the widest structure that has a generated Gram kernel
 GRAM_JIT_MIN_ENTRIES = 1 << 26
 GRAD_JIT_MIN_ENTRIES = 1 << 24
-GRAM_JIT_MAX_DZ = 16
+GRAM_JIT_MAX_DZ = 16        # up to here the strip kernel (dim loops unrolled); wider, up to GRAM_JIT_WIDE_MAX_DZ, the 4 x 4 micro-tile form
+GRAM_JIT_WIDE_MAX_DZ = 48
 
 
 def _hardware_queues():
@@ -157,7 +158,7 @@ class HipEngine:
                 (int(f.type), int(f.term), int(f.off), int(f.nd)) for f in ck.kspec.factor[: int(ck.kspec.nfactors)])
             zd = 20 if self._periodic(ck) else 0
             kinds = []
-            if 0 <= gram_min <= entries and ck.dz <= GRAM_JIT_MAX_DZ:
+            if 0 <= gram_min <= entries and ck.dz <= GRAM_JIT_WIDE_MAX_DZ:
                 kinds.append(0)
             if training and 0 <= grad_min <= entries:
                 kinds.append(1 + zd)

@@ -37,21 +37,13 @@ def one_call_enabled():
 
 
 def _device_nan_pattern(y):
-    """NaN pattern of a device tensor as a host array: one small device-to-host copy - a synchronisation - which an evaluation
-    loop over the SAME outputs (an optimiser, a benchmark: `logpdf(x, y)` again and again) would pay every time.  The pattern is
-    remembered ON THE TENSOR OBJECT (attribute `_gpar_nan`, with the version counter it was taken at): it lives and dies with the
-    caller's tensor, nothing global holds on to it (or to the storage behind a view), and threads training different layers never
-    share an entry.  An in-place torch operation moves the version counter and the pattern is fetched again; a write torch does
-    not see (a raw-pointer kernel, `.data`) does not - after such a write, `del y._gpar_nan`."""
-    cached = getattr(y, "_gpar_nan", None)
-    if cached is not None and cached[0] == y._version:
-        return cached[1]
-    pattern = torch.isnan(y).cpu().numpy()
-    try:
-        y._gpar_nan = (y._version, pattern)
-    except (AttributeError, RuntimeError):  # (a tensor subclass without a __dict__: nothing is remembered)
-        pass
-    return pattern
+    """NaN pattern of a device tensor as a host array: one small device-to-host copy, i.e. a synchronisation.  Nothing is
+    remembered here (round 4 kept the last tensor in a process-global: it pinned the tensor - through a view, its whole base
+    storage -, was shared by the training threads without a lock, and could not see writes that do not move torch's version
+    counter).  A caller that evaluates the SAME outputs again and again attaches the pattern to its own tensor object instead
+    (`GPARRegressor.logpdf`: attribute `_gpar_nan` of the tensor the user passed in; `fit`: `_host_nan` of its device copy) and
+    `_prep` takes a pattern that arrives attached."""
+    return torch.isnan(y).cpu().numpy()
 
 
 def _is_torch(a):
@@ -367,7 +359,13 @@ class GPAR:
             # indexing on the device synchronises - about ten times per layer in the dependent regimes, each time draining the
             # previous layer's factorisation before the host may prepare the next (a 4-layer logpdf at n = 2000 with 10 %
             # missing: 4.5 ms of GPU work in 7.1 ms).
-            host_nan = None
+            host_nan, y_given = None, y
+            if _is_torch(y):   # (a pattern attached by the caller, or remembered on this very tensor object: see _device_nan_pattern)
+                host_nan = getattr(y, "_host_nan", None)
+                if host_nan is None:
+                    cached = getattr(y, "_gpar_nan", None)
+                    if cached is not None and cached[0] == y._version and cached[1].shape == tuple(y.shape):
+                        host_nan = cached[1]
             if isinstance(y, np.ndarray):
                 host_nan = np.isnan(y)
             y = eng.tensor(y)
@@ -375,6 +373,11 @@ class GPAR:
             if _is_torch(y) and y.is_cuda and y.dim() == 2 and host_masks():
                 if host_nan is None:
                     host_nan = _device_nan_pattern(y)
+                    if _is_torch(y_given) and y_given.is_cuda:
+                        try:
+                            y_given._gpar_nan = (y_given._version, host_nan)
+                        except (AttributeError, RuntimeError):
+                            pass
                 y._host_nan = host_nan if host_nan.ndim == 2 else None
         return x, y, w
 

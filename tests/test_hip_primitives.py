@@ -841,10 +841,7 @@ def test_generated_gram_kernel_is_bit_identical_to_the_interpreter(case, monkeyp
     got = build()
     after = counts()
     assert after[1] == before[1], "a generated kernel failed to compile"
-    if ck.dz <= 16:
-        assert after[2] >= 1   # at least this structure is cached now
-    else:
-        assert after == before   # a wide structure has no generated Gram kernel: the interpreter served both builds
+    assert after[2] >= 1   # at least this structure is cached now (42 dims: the wide form of round 5, 4 x 4 micro-tile, rolled dim loops)
     for a, b in zip(got, ref):
         assert torch.equal(a, b), name
     # and both agree with the numpy oracle's kernel evaluation
