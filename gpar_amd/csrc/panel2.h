@@ -1137,6 +1137,64 @@ __device__ __forceinline__ pan_d2 p2_load_sc1(const double* __restrict__ src) {
     return pan_d2{__longlong_as_double((long long)a), __longlong_as_double((long long)b)};
 }
 
+// Tile (rb, c) of a BULK row block that is a team row of the NEXT panel of a fused launch (potrf_group_kernel): the same task as
+// p2_team_tile for a row below the diagonal block.  As one workgroup per row block these rows do their left-looking sums column by
+// column and finish ~25 us behind the chain - and the next panel's team is exactly these rows: its chain started ~45 us after the
+// previous one's ended.  By tile, product u runs as soon as X[rb][u] and L[c][u] exist (one per step of the chain) and the row is
+// complete one strip after the last diagonal tile.  The row's progress word keeps its meaning - column blocks published IN
+// ORDER - because a tile announces itself only once its left neighbour has (which, one step of the chain earlier, it has).
+__device__ __forceinline__ void p2_bulk_tile(const PanelArgs& p, int rb, int c, unsigned long long* word, unsigned long long base,
+                                             double* __restrict__ psm) {
+    double* Cs = psm;
+    double* Xs = psm + PNL_TILE;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    double* A = p.A;
+    const int r0 = p.k0 + 64 * rb, l0 = p.k0 + 64 * c;
+    pan_d4 acc[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) acc[mi] = pan_d4{0.0, 0.0, 0.0, 0.0};
+    pan_d2 ct[8];
+    p2_gload(A, p.lda, p.N, r0, l0, t, ct);
+    for (int u = 0; u < c; ++u) {
+        grp_wait(word, base + (unsigned long long)u + 1ull, p.info);                       // X[rb][u]
+        if (p.split) grp_wait(p2_tile_flag(p, c, u), 1ull, p.info);                       // L[c][u] (split team: by tile)
+        else grp_wait(pnl_flag(p, c), 4ull * (unsigned long long)u + 4ull, p.info);       // (one workgroup per team row: in order)
+        pan_d2 xa[8], la[8];
+        p2_gload(A, p.lda, p.N, r0, p.k0 + 64 * u, t, xa);
+        p2_gload(A, p.lda, p.N, l0, p.k0 + 64 * u, t, la);
+        p2_sstore(Cs, t, la);
+        p2_sstore(Xs, t, xa);
+        __syncthreads();
+        p2_chunk(Cs, Xs, acc, w, l15, lk);
+        __syncthreads();
+    }
+    p2_sstore(Xs, t, ct);
+    __syncthreads();
+    pan_d4 T[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) T[mi][v] = Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] - acc[mi][v];
+    grp_wait(pnl_flag(p, c), 4ull * (unsigned long long)c + 4ull, p.info);
+    {
+        pan_d2 lt[8];
+        p2_gload(A, p.lda, p.N, l0, l0, t, lt);
+        p2_sstore(Cs, t, lt);
+    }
+    __syncthreads();
+    p2_strip(Cs, T, l15, lk);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Xs[(16 * w + l15) * PNL_LD + 16 * mi + lk + 4 * v] = T[mi][v];
+    __syncthreads();
+    p2_gstore(A, p.lda, p.N, r0, l0, Xs, t, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (c > 0) grp_wait(word, base + (unsigned long long)c, p.info);   // the left neighbour has announced itself (barrier inside)
+    else __syncthreads();
+    if (t == 0) __hip_atomic_store(word, base + (unsigned long long)c + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One row block of the panel / of a triangular-solve block.
 //   L (ldl, lrows rows): the triangular factor's tiles, read at rows lr0 + 64 c, columns lc0 + 64 u;
 //   B (ldb, brows rows): the right-hand sides / the panel's own rows, read and overwritten at rows r0, columns bc0 + 64 c.
@@ -1792,11 +1850,14 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     int rb, b, tile_c = -1;
     // ---- which segment: panel 0's rows, then per panel q >= 1 (a) diagonal-block tiles, (b) team rows, (c) tiles below, (d) bulk rows
     int q = 0, seg = 0;
-    if (lin >= (R0 - S + NT) * batch) {
-        lin -= (R0 - S + NT) * batch;
+    const int bulk0 = (p.split && g.G > 1) ? S * S + (R0 - 2 * S) : R0 - S;   // panel 0's bulk segment (see (d) below)
+    if (lin >= (NT + bulk0) * batch) {
+        lin -= (NT + bulk0) * batch;
         for (q = 1; q < g.G; ++q) {
             const int Rq = R0 - S * q;
-            const int sizes[4] = {TD * batch, NT * batch, (Rq - S) * S * batch, (Rq - S) * batch};
+            // (d): the rows that form the next panel's team by tile (S * S workgroups), the others one workgroup per row block
+            const int bulk = (p.split && q < g.G - 1) ? S * S + (Rq - 2 * S) : Rq - S;
+            const int sizes[4] = {TD * batch, NT * batch, (Rq - S) * S * batch, bulk * batch};
             for (seg = 1; seg <= 4; ++seg) {
                 if (lin < sizes[seg - 1]) break;
                 lin -= sizes[seg - 1];
@@ -1806,6 +1867,24 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     }
     const int kq = p.k0 + 64 * S * q;
     const bool last = q == g.G - 1;
+    int bulk_c = -1;   // >= 0: this workgroup is tile (rb, bulk_c) of a next-team row block
+    auto bulk_decode = [&](int idx) {
+        if (p.split && !last) {
+            if (idx < S * S * batch) {
+                const int tl = idx / batch;
+                b = idx - tl * batch;
+                rb = S + tl / S;
+                bulk_c = tl - (tl / S) * S;
+                return;
+            }
+            idx -= S * S * batch;
+            rb = 2 * S + idx / batch;
+            b = idx % batch;
+            return;
+        }
+        rb = S + idx / batch;
+        b = idx % batch;
+    };
     if (seg == 0) {
         // teams of all matrices first, as in potrf_panel2_kernel
         if (lin < NT * batch) {
@@ -1813,9 +1892,7 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
             b = lin - rb * batch;
             if (p.split) p2_team_decode(S, rb, rb, tile_c);
         } else {
-            const int idx = lin - NT * batch;
-            rb = S + idx / batch;
-            b = idx % batch;
+            bulk_decode(lin - NT * batch);
         }
     } else if (seg == 1 || seg == 3) {
         rb = lin / batch;   // tile index
@@ -1825,8 +1902,7 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
         b = lin - rb * batch;
         if (p.split) p2_team_decode(S, rb, rb, tile_c);
     } else {
-        rb = S + lin / batch;
-        b = lin % batch;
+        bulk_decode(lin);
     }
     p.A += (size_t)b * p.batch_a;
     if (p.logdet) p.logdet += b;
@@ -1853,6 +1929,11 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
         p.k0 = kq;
         if (tile_c >= 0) p2_team_tile(p, rb, tile_c, psm);
         else p2_row_block<true, true>(p, p.A, p.lda, p.N, kq, kq, p.A, p.lda, p.N, r0, kq, rb, 0, rb, psm);
+    } else if (bulk_c >= 0) {
+        __builtin_amdgcn_s_setprio(1);
+        if (q > 0) grp_wait(grp_word(p.A, p.lda, kq / 64 + rb, 1), counted + (unsigned long long)S, p.info);
+        p.k0 = kq;
+        p2_bulk_tile(p, rb, bulk_c, grp_word(p.A, p.lda, kq / 64 + rb, 0), (unsigned long long)(kq / 64), psm);
     } else {
         if (q > 0) grp_wait(grp_word(p.A, p.lda, kq / 64 + rb, 1), counted + (unsigned long long)S, p.info);
         p.k0 = kq;
@@ -1865,10 +1946,10 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
 static long long potrf_group_workgroups(int N, int k0, int S, int G, int split) {
     const int R0 = (N - k0 + 63) / 64;
     const int NT = split ? S + (S - 1) * (S - 2) / 2 : S;
-    long long per = R0 - S + NT;
+    long long per = NT + ((split && G > 1) ? S * S + (R0 - 2 * S) : R0 - S);
     for (int q = 1; q < G; ++q) {
         const int Rq = R0 - S * q;
-        per += S * (S + 1) / 2 + NT + (long long)(Rq - S) * S + (Rq - S);
+        per += S * (S + 1) / 2 + NT + (long long)(Rq - S) * S + ((split && q < G - 1) ? S * S + (Rq - 2 * S) : Rq - S);
     }
     return per;
 }

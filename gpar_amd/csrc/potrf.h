@@ -653,14 +653,14 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // 0.924 -> 0.866; n = 4600 1.94 / 1.95 / 2.00 / 2.18 ms fused never / from 2560 / 4200 / 5120 rows; n = 16384 inside the noise); a lock-step batch of
     // four gains 1 % on its last pair of panels and loses when more are fused (4 x 4096: 2.74 -> 2.71 / 2.84 ms).  Geometry only, like
     // every other rule here: the same bits with and without look-ahead.
-    const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", 2560) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 6144) / batch;
+    const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", 5200) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 6144) / batch;
     const bool fuse2_on = pol.fused && prezero && !(flags & GPAR_POTRF_UNFUSED) && nbo == 512 && env_int("GPAR_PANEL_V", 2) >= 2 &&
                           env_int("GPAR_PANEL_PAIRS", 1) && (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && fuse2_rows > 0 && tail == 0;
     unsigned long long fuse_counted = 0;   // tiles every row block below the fused launches so far has counted (panel2.h)
     // (more than two panels per launch add little - between panels inside a launch the next team waits ~45 us for the last column
     // blocks of its own rows, which the bulk row blocks of the panel before finish behind the chain - : n = 1536 0.497 -> 0.452 ms with
     // three, n = 2048 0.647 -> 0.637 with four, nothing beyond; 4 measured equal or better than 2 / 3 / 8 at every size)
-    const int fuse_max = env_int("GPAR_POTRF_FUSE_MAX", 4);
+    const int fuse_max = env_int("GPAR_POTRF_FUSE_MAX", 10);
     // panels the step at column k takes in one launch (0: the step is not fused)
     auto fuse_panels = [&](int k) {
         if (!fuse2_on || groupable(k) || k % 64 != 0 || N - k > fuse2_rows) return 0;
