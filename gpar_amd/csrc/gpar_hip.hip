@@ -380,6 +380,7 @@ int gpar_init(void* stream) {
     GPAR_API_GUARD;
     if (!la_init()) return -(int)hipErrorOutOfMemory;
     if (!la_side((hipStream_t)stream)) return -(int)hipErrorOutOfMemory;
+    if (!spin_chain_init()) return -(int)hipErrorOutOfMemory;
     const void* big[] = {reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>),
                          reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>),
                          reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0, 64>),

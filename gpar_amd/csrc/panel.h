@@ -36,6 +36,55 @@ constexpr int PNL_FLAG_SLOTS = 56;                     // usable scratch words p
 constexpr int PNL_MAX_S = 16;                          // S + S^2 <= 8 rows x 56 slots
 constexpr unsigned PNL_SPIN_LIMIT = 1u << 22;
 
+// Kernels whose workgroups WAIT for one another (the three panel kernels) are never in flight together.  A waiting workgroup holds
+// its compute-unit slot, and the chip hands workgroup i of a launch to XCD i % 8: inside ONE launch the lowest unfinished workgroup
+// always runs (every wait targets a lower index, each XCD starts its share in order), but two launches on two streams can fill each
+// other's XCDs with waiters whose producers then find no slot - a cycle that only the bounded spin breaks (-77; three streams at
+// n = 8192 hit it once in two runs when a launch carried thousands of tile workgroups, round 5).  So a launch on a stream other
+// than the previous one's waits for that one (one event per device, re-recorded after every such launch once a second stream has been
+// seen); a process with one stream pays nothing, and the updates - which never wait - still overlap other streams' panels.
+struct SpinChain {
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool any = false;     // a waiting kernel has been launched on this device
+    bool multi = false;   // ... from more than one stream: record after every launch
+};
+static SpinChain g_spin_chain[16];
+static SpinChain& spin_chain() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return g_spin_chain[dev % 16];
+}
+static bool spin_chain_init() {
+    SpinChain& c = spin_chain();
+    return c.ev || hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) == hipSuccess;
+}
+static inline bool spin_chain_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { GPAR_HIP_IGNORE(hipGetLastError()); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+// Callers hold the library mutex.  `enter` before the launch, `leave` after it.
+static int spin_chain_enter(hipStream_t s) {
+    SpinChain& c = spin_chain();
+    if (!c.any || c.last == s) return 0;
+    if (spin_chain_capturing(s)) return 0;   // (a graph being captured is ordered by whoever replays it)
+    if (!spin_chain_init()) return -(int)hipErrorOutOfMemory;
+    if (!c.multi) {
+        // first change of stream: mark the end of what the previous stream holds NOW (a superset of its last waiting kernel)
+        c.multi = true;
+        if (hipEventRecord(c.ev, c.last) != hipSuccess) { GPAR_HIP_IGNORE(hipGetLastError()); return 0; }   // (stream gone: so is its work)
+    }
+    GPAR_HIP_TRY(hipStreamWaitEvent(s, c.ev, 0));
+    return 0;
+}
+static void spin_chain_leave(hipStream_t s) {
+    SpinChain& c = spin_chain();
+    if (c.multi && !spin_chain_capturing(s) && spin_chain_init()) GPAR_HIP_IGNORE(hipEventRecord(c.ev, s));
+    c.last = s;
+    c.any = true;
+}
+
 struct PanelArgs {
     double* A;
     int N, lda, k0, S;   // panel columns [k0, k0 + 64 S)
@@ -439,7 +488,9 @@ static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* l
             GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)(k0 + r) * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream));
     const int R = (N - k0 + 63) / 64;
     int G = R < panel_grid_cap() ? R : panel_grid_cap();
+    if (int rc = spin_chain_enter(stream)) return rc;
     hipLaunchKernelGGL(potrf_panel_kernel, dim3(G), dim3(256), PNL_LDS_BYTES, stream, p);
+    spin_chain_leave(stream);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
