@@ -36,18 +36,32 @@ constexpr int PNL_FLAG_SLOTS = 56;                     // usable scratch words p
 constexpr int PNL_MAX_S = 16;                          // S + S^2 <= 8 rows x 56 slots
 constexpr unsigned PNL_SPIN_LIMIT = 1u << 22;
 
-// Kernels whose workgroups WAIT for one another (the three panel kernels) are never in flight together.  A waiting workgroup holds
-// its compute-unit slot, and the chip hands workgroup i of a launch to XCD i % 8: inside ONE launch the lowest unfinished workgroup
-// always runs (every wait targets a lower index, each XCD starts its share in order), but two launches on two streams can fill each
-// other's XCDs with waiters whose producers then find no slot - a cycle that only the bounded spin breaks (-77; three streams at
-// n = 8192 hit it once in two runs when a launch carried thousands of tile workgroups, round 5).  So a launch on a stream other
-// than the previous one's waits for that one (one event per device, re-recorded after every such launch once a second stream has been
-// seen); a process with one stream pays nothing, and the updates - which never wait - still overlap other streams' panels.
+// Kernels whose workgroups WAIT for one another (the three panel kernels) and the compute-unit slots they hold.  The chip hands
+// workgroup i of a launch to XCD i % 8 and each XCD starts its share in order: inside ONE launch the lowest unfinished workgroup
+// always runs (every wait targets a lower index), but two launches on two streams can fill each other's XCDs with waiters whose
+// producers then find no slot - a cycle that only the bounded spin breaks (-77; three streams at n = 8192 hit it once in two runs
+// when a launch carried thousands of tile workgroups, round 5).  A launch A can be starved only if the OTHER waiting launches in
+// flight fill an XCD by themselves (64 slots: 32 compute units x 2 workgroups of this LDS size; update kernels never wait and always
+// retire).  So:
+//   * BIG launches (more than SPIN_SMALL_WGS workgroups) are never in flight together: one on a stream other than the previous big
+//     one's waits for it (one event, re-recorded after every big launch);
+//   * of SMALL launches at most two are in flight on different streams (2 x 192 / 8 = 48 < 64 slots per XCD beside one big launch):
+//     a ring of two events, a launch waits for the older entry unless its own stream made it.  An inducing-point layer's two small
+//     factorisations (K_zz on a side stream beside the bound's matrix on the caller's) alternate slots and never wait.
+// Nothing is recorded or waited for until a second stream shows up; a process with one stream pays nothing, and the updates still
+// overlap other streams' panels.  GPAR_SPIN_CHAIN=0 switches all of it off (the round-4 behaviour).
+constexpr int SPIN_SMALL_WGS = 192;
 struct SpinChain {
-    hipEvent_t ev = nullptr;
-    hipStream_t last = nullptr;
-    bool any = false;     // a waiting kernel has been launched on this device
-    bool multi = false;   // ... from more than one stream: record after every launch
+    hipEvent_t ev = nullptr;          // the last big launch
+    hipEvent_t sev[2] = {nullptr, nullptr};   // the last two small launches
+    hipStream_t last = nullptr;       // stream of the last big launch
+    hipStream_t sst[2] = {nullptr, nullptr};
+    bool big = false, small[2] = {false, false};   // is there such a launch
+    int snext = 0;
+    hipStream_t seen = nullptr;       // the only stream seen so far (while !multi)
+    bool any = false;
+    bool multi = false;               // waiting kernels come from more than one stream: record after every launch
+    bool created = false;
 };
 static SpinChain g_spin_chain[16];
 static SpinChain& spin_chain() {
@@ -57,32 +71,59 @@ static SpinChain& spin_chain() {
 }
 static bool spin_chain_init() {
     SpinChain& c = spin_chain();
-    return c.ev || hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) == hipSuccess;
+    if (c.created) return true;
+    if (hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c.sev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c.sev[1], hipEventDisableTiming) != hipSuccess)
+        return false;
+    c.created = true;
+    return true;
 }
 static inline bool spin_chain_capturing(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess) { GPAR_HIP_IGNORE(hipGetLastError()); return false; }
     return st != hipStreamCaptureStatusNone;
 }
-// Callers hold the library mutex.  `enter` before the launch, `leave` after it.
-static int spin_chain_enter(hipStream_t s) {
+// Callers hold the library mutex.  `enter` before the launch of `wgs` workgroups, `leave` after it.
+static int spin_chain_enter(hipStream_t s, long long wgs) {
     SpinChain& c = spin_chain();
-    if (!c.any || c.last == s) return 0;
+    if (!c.any || (!c.multi && c.seen == s) || !env_int("GPAR_SPIN_CHAIN", 1)) return 0;
     if (spin_chain_capturing(s)) return 0;   // (a graph being captured is ordered by whoever replays it)
     if (!spin_chain_init()) return -(int)hipErrorOutOfMemory;
     if (!c.multi) {
-        // first change of stream: mark the end of what the previous stream holds NOW (a superset of its last waiting kernel)
+        // a second stream: mark the end of what the first one holds NOW (a superset of its waiting launches) as its last big and
+        // its last small launch
         c.multi = true;
-        if (hipEventRecord(c.ev, c.last) != hipSuccess) { GPAR_HIP_IGNORE(hipGetLastError()); return 0; }   // (stream gone: so is its work)
+        if (hipEventRecord(c.ev, c.seen) == hipSuccess && hipEventRecord(c.sev[0], c.seen) == hipSuccess) {
+            c.big = c.small[0] = true;
+            c.last = c.sst[0] = c.seen;
+            c.snext = 1;
+        } else {
+            GPAR_HIP_IGNORE(hipGetLastError());   // (stream gone: so is its work)
+        }
     }
-    GPAR_HIP_TRY(hipStreamWaitEvent(s, c.ev, 0));
+    if (wgs > SPIN_SMALL_WGS) {
+        if (c.big && c.last != s) GPAR_HIP_TRY(hipStreamWaitEvent(s, c.ev, 0));
+    } else {
+        const int slot = c.snext;   // the older of the two
+        if (c.small[slot] && c.sst[slot] != s) GPAR_HIP_TRY(hipStreamWaitEvent(s, c.sev[slot], 0));
+    }
     return 0;
 }
-static void spin_chain_leave(hipStream_t s) {
+static void spin_chain_leave(hipStream_t s, long long wgs) {
     SpinChain& c = spin_chain();
-    if (c.multi && !spin_chain_capturing(s) && spin_chain_init()) GPAR_HIP_IGNORE(hipEventRecord(c.ev, s));
-    c.last = s;
+    if (!c.any) c.seen = s;
     c.any = true;
+    if (!c.multi || !env_int("GPAR_SPIN_CHAIN", 1) || spin_chain_capturing(s) || !spin_chain_init()) return;
+    if (wgs > SPIN_SMALL_WGS) {
+        GPAR_HIP_IGNORE(hipEventRecord(c.ev, s));
+        c.last = s;
+        c.big = true;
+    } else {
+        GPAR_HIP_IGNORE(hipEventRecord(c.sev[c.snext], s));
+        c.sst[c.snext] = s;
+        c.small[c.snext] = true;
+        c.snext ^= 1;
+    }
 }
 
 struct PanelArgs {
@@ -488,9 +529,9 @@ static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* l
             GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)(k0 + r) * lda + k0 + 8, 0, PNL_FLAG_SLOTS * sizeof(double), stream));
     const int R = (N - k0 + 63) / 64;
     int G = R < panel_grid_cap() ? R : panel_grid_cap();
-    if (int rc = spin_chain_enter(stream)) return rc;
+    if (int rc = spin_chain_enter(stream, G)) return rc;
     hipLaunchKernelGGL(potrf_panel_kernel, dim3(G), dim3(256), PNL_LDS_BYTES, stream, p);
-    spin_chain_leave(stream);
+    spin_chain_leave(stream, G);
     GPAR_LAUNCH_CHECK();
     return 0;
 }

@@ -1741,9 +1741,9 @@ static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* 
                     GPAR_HIP_TRY(hipMemsetAsync(A + (size_t)b * batch_a + (size_t)(k0 + r) * lda + k0 + 9, 0, 23 * sizeof(double), stream));
         }
     const int R = (N - k0 + 63) / 64 - p.S + (p.split ? p.S + (p.S - 1) * (p.S - 2) / 2 : p.S);
-    if (int rc = spin_chain_enter(stream)) return rc;
+    if (int rc = spin_chain_enter(stream, (long long)R * batch)) return rc;
     hipLaunchKernelGGL(potrf_panel2_kernel, dim3(R, batch), dim3(256), P2_LDS_BYTES, stream, p);
-    spin_chain_leave(stream);
+    spin_chain_leave(stream, (long long)R * batch);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
@@ -1967,9 +1967,10 @@ static int potrf_group_fused(double* A, int N, int lda, int k0, int W, int G, do
     g.G = G;
     g.la_base = la_base;
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_group_kernel), P2_LDS_BYTES));
-    if (int rc = spin_chain_enter(stream)) return rc;
-    hipLaunchKernelGGL(potrf_group_kernel, dim3((unsigned)potrf_group_workgroups(N, k0, W / 64, G, g.p.split), batch), dim3(256), P2_LDS_BYTES, stream, g);
-    spin_chain_leave(stream);
+    const long long wgs = potrf_group_workgroups(N, k0, W / 64, G, g.p.split);
+    if (int rc = spin_chain_enter(stream, wgs * batch)) return rc;
+    hipLaunchKernelGGL(potrf_group_kernel, dim3((unsigned)wgs, batch), dim3(256), P2_LDS_BYTES, stream, g);
+    spin_chain_leave(stream, wgs * batch);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
