@@ -653,7 +653,10 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // 0.924 -> 0.866; n = 4600 1.94 / 1.95 / 2.00 / 2.18 ms fused never / from 2560 / 4200 / 5120 rows; n = 16384 inside the noise); a lock-step batch of
     // four gains 1 % on its last pair of panels and loses when more are fused (4 x 4096: 2.74 -> 2.71 / 2.84 ms).  Geometry only, like
     // every other rule here: the same bits with and without look-ahead.
-    const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", 5200) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 6144) / batch;
+    // Round 5 (the next team's rows updated tile by tile, progressive hand-off): a factorisation of up to 5200 rows is ONE launch (n = 4096
+    // 1.56 -> 1.26 ms); a larger one fuses its last eight panels (profiles/r05_exp_fuse_rows.txt: n = 8192 4.77 / 4.72 / 4.60 / 4.71 / 4.66 / 4.79 ms
+    // fused from 5200 / 4700 / 4200 / 3600 / 3100 / 2560 rows; n = 5632 .. 16384 all flat within 2 % between 3600 and 4700).
+    const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", N <= 5200 ? 5200 : 4200) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 6144) / batch;
     const bool fuse2_on = pol.fused && prezero && !(flags & GPAR_POTRF_UNFUSED) && nbo == 512 && env_int("GPAR_PANEL_V", 2) >= 2 &&
                           env_int("GPAR_PANEL_PAIRS", 1) && (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && fuse2_rows > 0 && tail == 0;
     unsigned long long fuse_counted = 0;   // tiles every row block below the fused launches so far has counted (panel2.h)

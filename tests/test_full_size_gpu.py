@@ -266,6 +266,43 @@ def test_concurrent_factorisations_complete_their_handoffs(hip, streams, n):
         assert torch.equal(torch.tril(a), ref)
 
 
+def test_concurrent_factorisations_of_mixed_sizes_complete(hip):
+    """Five streams, small and large factorisations mixed (single panels, fused launches of a few hundred and of thousands of
+    workgroups), three rounds each, everything in flight together: waiting workgroups of one launch must never starve another
+    launch's producers of compute-unit slots (csrc/panel.h: the spin chain).  Every info word 0, every factor the bits of the
+    lone run."""
+    from gpar_amd import hip as H
+
+    dev = hip.device
+    sizes = [1024, 1500, 4096, 6000, 1024]
+    lone, work = [], []
+    for k, n in enumerate(sizes):
+        g = torch.Generator().manual_seed(100 + k)
+        x = torch.rand(n, 3, generator=g, dtype=torch.float64).to(dev)
+        K = torch.exp(-0.5 * torch.cdist(x, x) ** 2 / 0.25)
+        K.diagonal().add_(0.1)
+        a = H.alloc_matrix(n, n, dev)
+        a.copy_(K)
+        _, info = H.potrf_(a)
+        assert int(info.item()) == 0
+        lone.append(torch.tril(a))
+        work.append([H.alloc_matrix(n, n, dev) for _ in range(3)])
+        for w in work[-1]:
+            w.copy_(K)
+    pool = [torch.cuda.Stream(device=dev) for _ in sizes]
+    torch.cuda.synchronize()
+    infos = []
+    for rnd in range(3):
+        for k in range(len(sizes)):
+            with torch.cuda.stream(pool[k]):
+                infos.append(H.potrf_(work[k][rnd])[1])
+    torch.cuda.synchronize()
+    assert [int(i.item()) for i in infos] == [0] * len(infos)
+    for k in range(len(sizes)):
+        for w in work[k]:
+            assert torch.equal(torch.tril(w), lone[k])
+
+
 def test_factorisation_is_repeatable_beside_its_own_trailing_updates(hip):
     """With look-ahead the panel kernel shares compute units with the trailing update, whose waves can hold a panel wave back
     for a whole round of the diagonal-tile factorisation; the waves of a workgroup that do not synchronise inside a round
