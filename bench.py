@@ -28,6 +28,8 @@ import time
 
 import numpy as np
 
+PROCESS_T0 = time.perf_counter()   # wall clock of the whole run, printed as `wall_s` (the driver's own clock also sees interpreter start-up)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -251,7 +253,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
             "traffic": pmc_traffic(n, m, p),
-            "traffic_source": "profiles/r04_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)",
+            "traffic_source": "profiles/r05_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; bytes per launch)",
             "launches": launches.value,
             "flop_per_launch": flops.value / launches.value,
             "avg_launch_ms": ms.value / launches.value,
@@ -299,6 +301,7 @@ def main():
     def emit():
         if rank == 0 and not printed:
             printed.append(True)
+            out["wall_s"] = round(time.perf_counter() - PROCESS_T0, 1)
             print(json.dumps(out), flush=True)
 
     def bail():
@@ -406,7 +409,7 @@ def pmc_traffic(n, m, p):
     workload: counters cannot be collected from inside the timed process) - and null if the kernel's source has changed
     since those passes were taken (tools/refresh_profiles.sh stamps them with a hash of csrc/gemm_f64.h), so that a stale
     figure is never reported beside a new kernel."""
-    path = os.path.join(ROOT, "profiles", "r04_bench_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r05_bench_pmc_traffic.json")
     if (n, m, p) != (16384, 4, 8) or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -684,14 +687,15 @@ def small_n_leg(eng, sizes=(100, 400, 1024, 2048), m=2, p=4, iters=20):
             float(reg.logpdf(x, y))
             torch.cuda.synchronize()
             times.append(1e3 * (time.perf_counter() - t0))
-        fit_ms = None
-        for _ in range(2):   # (the second fit of a size: the first pays first-use costs)
+        fits = []
+        for _ in range(3):   # (best of the second and third fit of a size: the first pays first-use costs)
             trainee = GPARRegressor(**kw)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             trainee.fit(x_np, y_np, iters=iters)
             torch.cuda.synchronize()
-            fit_ms = 1e3 * (time.perf_counter() - t0)
+            fits.append(1e3 * (time.perf_counter() - t0))
+        fit_ms = min(fits[1:])
         specs = layer_specs(kw, m, p)
         x_all = torch.as_tensor(np.concatenate([x_np, y_np], axis=1))
         cpu_logpdf = 0.0
