@@ -1053,6 +1053,38 @@ __device__ __forceinline__ void grp_wait(unsigned long long* word, unsigned long
     __syncthreads();
 }
 
+// all threads; returns once both words are >= need, with the smaller of the two values seen (the same for every thread: through
+// `sh`, an LDS word nobody else writes before the workgroup's next barrier)
+__device__ __forceinline__ unsigned long long grp_wait2(unsigned long long* wi, unsigned long long* wj, unsigned long long need, int* info,
+                                                        unsigned long long* sh) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        unsigned long long a, b;
+        while ((a = __hip_atomic_load(wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > PNL_SPIN_LIMIT) {
+                if (info) atomicCAS(info, 0, -77);
+                a = need;
+                break;
+            }
+        }
+        b = a;
+        if (wj != wi)
+            while ((b = __hip_atomic_load(wj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > PNL_SPIN_LIMIT) {
+                    if (info) atomicCAS(info, 0, -77);
+                    b = need;
+                    break;
+                }
+            }
+        *sh = a < b ? a : b;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    return *sh;
+}
+
 // tile (t, c) of the split team: X[t][c] = (A[t][c] - sum_{u<c} X[t][u] L[c][u]^T) L[c][c]^-T, published
 __device__ __forceinline__ void p2_team_tile(const PanelArgs& p, int trow, int c, double* __restrict__ psm) {
     double* Cs = psm;
@@ -1796,15 +1828,32 @@ __device__ __forceinline__ void grp_la_tile(const PanelArgs& p, int kq, int ti, 
     for (int mi = 0; mi < 4; ++mi) acc[mi] = pan_d4{0.0, 0.0, 0.0, 0.0};
     pan_d2 ct[8];   // the output tile: last written by an earlier launch on the stream
     p2_gload(p.A, p.lda, p.N, r0, c0, t, ct);
+    // Column blocks both rows have published are taken without polling, the next one's operands fetched under the current
+    // product (a tile of a late panel starts with 8 (q - 1) column blocks of earlier panels behind it: at one poll, one
+    // round trip to memory and two barriers per column block - 6 us for 0.9 us of matrix-core work - those outlasted the chain
+    // they should hide behind, and the next team waited for them).  At the frontier - a column block per ~12 us - nothing changes.
+    unsigned long long* seen = reinterpret_cast<unsigned long long*>(psm + 2 * PNL_TILE);
+    int avail = 0;   // column blocks of this launch known to be published by both rows
+    bool loaded = false;
+    pan_d2 xa[8], la[8];
     for (int u = 0; u < nchunks; ++u) {
-        grp_wait(wi, (unsigned long long)(kb0 + u + 1), p.info);
-        if (ti != tj) grp_wait(wj, (unsigned long long)(kb0 + u + 1), p.info);
-        pan_d2 xa[8], la[8];
-        p2_gload(p.A, p.lda, p.N, r0, p.k0 + 64 * u, t, xa);
-        p2_gload(p.A, p.lda, p.N, c0, p.k0 + 64 * u, t, la);
+        if (!loaded) {
+            if (u >= avail) {
+                const unsigned long long m = grp_wait2(wi, wj, (unsigned long long)(kb0 + u + 1), p.info, seen);
+                const long long have = (long long)m - kb0;
+                avail = have > nchunks ? nchunks : (int)have;
+            }
+            p2_gload(p.A, p.lda, p.N, r0, p.k0 + 64 * u, t, xa);
+            p2_gload(p.A, p.lda, p.N, c0, p.k0 + 64 * u, t, la);
+        }
         p2_sstore(Cs, t, la);
         p2_sstore(Xs, t, xa);
         __syncthreads();
+        loaded = u + 1 < avail;   // (avail <= nchunks)
+        if (loaded) {
+            p2_gload(p.A, p.lda, p.N, r0, p.k0 + 64 * (u + 1), t, xa);
+            p2_gload(p.A, p.lda, p.N, c0, p.k0 + 64 * (u + 1), t, la);
+        }
         p2_chunk(Cs, Xs, acc, w, l15, lk);
         __syncthreads();   // the operand reads are done before the next chunk's tiles (or the output tile) land
     }

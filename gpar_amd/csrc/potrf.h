@@ -656,7 +656,11 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // Round 5 (the next team's rows updated tile by tile, progressive hand-off): a factorisation of up to 5200 rows is ONE launch (n = 4096
     // 1.56 -> 1.26 ms); a larger one fuses its last eight panels (profiles/r05_exp_fuse_rows.txt: n = 8192 4.77 / 4.72 / 4.60 / 4.71 / 4.66 / 4.79 ms
     // fused from 5200 / 4700 / 4200 / 3600 / 3100 / 2560 rows; n = 5632 .. 16384 all flat within 2 % between 3600 and 4700).
-    const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", N <= 5200 ? 5200 : 4200) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 6144) / batch;
+    // With the launch's tiles taking published column blocks without polling and fetching the next one under the current product
+    // (grp_la_tile: a tile's share of the earlier panels 6 -> ~3.5 us per column block) a lock-step batch gains from fusing too: four matrices
+    // of 4096 rows in ONE launch 3.55 -> 2.81 ms against 3.05 with their last 1536 rows fused (rows x batch <= 16500: C2, 4 x 3072 1.82 ->
+    // 1.62 ms, 8 x 2048 1.55 -> 1.36; C3 and C5 - the last 2048 / 1024 rows - unchanged; profiles/r05_exp_batch_fuse.txt).
+    const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", N <= 5200 ? 5200 : 4200) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 16500) / batch;
     const bool fuse2_on = pol.fused && prezero && !(flags & GPAR_POTRF_UNFUSED) && nbo == 512 && env_int("GPAR_PANEL_V", 2) >= 2 &&
                           env_int("GPAR_PANEL_PAIRS", 1) && (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && fuse2_rows > 0 && tail == 0;
     unsigned long long fuse_counted = 0;   // tiles every row block below the fused launches so far has counted (panel2.h)
