@@ -2013,6 +2013,15 @@ static int potrf_group_fused(double* A, int N, int lda, int k0, int W, int G, do
     g.p.pairs = 1;
     g.p.progressive = env_int("GPAR_PANEL_PROGRESSIVE", 1);
     g.p.split = g.p.progressive && g.p.S <= 8 && env_int("GPAR_PANEL_SPLIT", 1);
+    // The split team and the next team's rows by tile are latency devices that cost compute-unit slots: per matrix and panel 29 + 64
+    // workgroups that mostly wait, beside its bulk rows.  Where those of all matrices of a lock-step batch no longer fit the chip's 512
+    // slots they crowd out the launch's update tiles, and the launch is bound by those (four matrices of 4096 rows: 2.80 -> 2.67 ms
+    // without, eight of 2048: 1.41 -> 1.34; four of 2048 - 440 such workgroups - 0.97 -> 1.02 the other way; profiles/r05_exp_batch_fuse.txt).
+    if (g.p.split && env_int("GPAR_PANEL_SPLIT", 1) == 1) {
+        const int R0 = (N - k0 + 63) / 64, S = g.p.S;
+        const long long waiting = (long long)batch * (S + (S - 1) * (S - 2) / 2 + S * S + (R0 > 2 * S ? R0 - 2 * S : 0));
+        if (waiting > 512) g.p.split = 0;
+    }
     g.G = G;
     g.la_base = la_base;
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_group_kernel), P2_LDS_BYTES));
