@@ -137,6 +137,7 @@ struct PanelArgs {
     int pairs = 0;           // panel2.h: bulk row blocks take their column blocks in pairs (p2_row_block_pairs)
     int progressive = 0;     // panel2.h: a diagonal tile is handed to the next team row in four block columns while it is being factored (P3Publish)
     int split = 0;           // panel2.h: the team is split by tile (p2_team_tile + chain workgroups); needs progressive, S <= 8
+    int tile_rows = 0;       // panel2.h, fused launches: the rows that form the NEXT team are taken tile by tile (p2_bulk_tile); needs split
 };
 
 __device__ __forceinline__ unsigned long long* pnl_flag(const PanelArgs& p, int f) {

@@ -1901,13 +1901,13 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     int rb, b, tile_c = -1;
     // ---- which segment: panel 0's rows, then per panel q >= 1 (a) diagonal-block tiles, (b) team rows, (c) tiles below, (d) bulk rows
     int q = 0, seg = 0;
-    const int bulk0 = (p.split && g.G > 1) ? S * S + (R0 - 2 * S) : R0 - S;   // panel 0's bulk segment (see (d) below)
+    const int bulk0 = (p.tile_rows && g.G > 1) ? S * S + (R0 - 2 * S) : R0 - S;   // panel 0's bulk segment (see (d) below)
     if (lin >= (NT + bulk0) * batch) {
         lin -= (NT + bulk0) * batch;
         for (q = 1; q < g.G; ++q) {
             const int Rq = R0 - S * q;
             // (d): the rows that form the next panel's team by tile (S * S workgroups), the others one workgroup per row block
-            const int bulk = (p.split && q < g.G - 1) ? S * S + (Rq - 2 * S) : Rq - S;
+            const int bulk = (p.tile_rows && q < g.G - 1) ? S * S + (Rq - 2 * S) : Rq - S;
             const int sizes[4] = {TD * batch, NT * batch, (Rq - S) * S * batch, bulk * batch};
             for (seg = 1; seg <= 4; ++seg) {
                 if (lin < sizes[seg - 1]) break;
@@ -1920,7 +1920,7 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     const bool last = q == g.G - 1;
     int bulk_c = -1;   // >= 0: this workgroup is tile (rb, bulk_c) of a next-team row block
     auto bulk_decode = [&](int idx) {
-        if (p.split && !last) {
+        if (p.tile_rows && !last) {
             if (idx < S * S * batch) {
                 const int tl = idx / batch;
                 b = idx - tl * batch;
@@ -1994,13 +1994,13 @@ __global__ __launch_bounds__(256, 2) void potrf_group_kernel(GroupArgs g) {
     }
 }
 
-static long long potrf_group_workgroups(int N, int k0, int S, int G, int split) {
+static long long potrf_group_workgroups(int N, int k0, int S, int G, int split, int tile_rows) {
     const int R0 = (N - k0 + 63) / 64;
     const int NT = split ? S + (S - 1) * (S - 2) / 2 : S;
-    long long per = NT + ((split && G > 1) ? S * S + (R0 - 2 * S) : R0 - S);
+    long long per = NT + ((tile_rows && G > 1) ? S * S + (R0 - 2 * S) : R0 - S);
     for (int q = 1; q < G; ++q) {
         const int Rq = R0 - S * q;
-        per += S * (S + 1) / 2 + NT + (long long)(Rq - S) * S + ((split && q < G - 1) ? S * S + (Rq - 2 * S) : Rq - S);
+        per += S * (S + 1) / 2 + NT + (long long)(Rq - S) * S + ((tile_rows && q < G - 1) ? S * S + (Rq - 2 * S) : Rq - S);
     }
     return per;
 }
@@ -2022,10 +2022,11 @@ static int potrf_group_fused(double* A, int N, int lda, int k0, int W, int G, do
         const long long waiting = (long long)batch * (S + (S - 1) * (S - 2) / 2 + S * S + (R0 > 2 * S ? R0 - 2 * S : 0));
         if (waiting > 512) g.p.split = 0;
     }
+    g.p.tile_rows = g.p.split && env_int("GPAR_PANEL_TILE_ROWS", 1);
     g.G = G;
     g.la_base = la_base;
     GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_group_kernel), P2_LDS_BYTES));
-    const long long wgs = potrf_group_workgroups(N, k0, W / 64, G, g.p.split);
+    const long long wgs = potrf_group_workgroups(N, k0, W / 64, G, g.p.split, g.p.tile_rows);
     if (int rc = spin_chain_enter(stream, wgs * batch)) return rc;
     hipLaunchKernelGGL(potrf_group_kernel, dim3((unsigned)wgs, batch), dim3(256), P2_LDS_BYTES, stream, g);
     spin_chain_leave(stream, wgs * batch);

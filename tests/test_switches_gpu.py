@@ -23,6 +23,8 @@ CALL_TIME = [
     ("GPAR_PANEL_V", "1"),
     ("GPAR_PANEL_PROGRESSIVE", "0"),
     ("GPAR_PANEL_SPLIT", "0"),
+    ("GPAR_PANEL_SPLIT", "2"),
+    ("GPAR_PANEL_TILE_ROWS", "0"),
     ("GPAR_SPIN_CHAIN", "0"),
     ("GPAR_POTRF_FUSED", "0"),
     ("GPAR_POTRF_LOOKAHEAD", "0"),
