@@ -660,14 +660,16 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // (grp_la_tile: a tile's share of the earlier panels 6 -> ~3.5 us per column block) a lock-step batch gains from fusing too: four matrices
     // of 4096 rows in ONE launch 3.55 -> 2.81 ms against 3.05 with their last 1536 rows fused (rows x batch <= 16500: C2, 4 x 3072 1.82 ->
     // 1.62 ms, 8 x 2048 1.55 -> 1.36; C3 and C5 - the last 2048 / 1024 rows - unchanged; profiles/r05_exp_batch_fuse.txt).
-    const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", N <= 5200 ? 5200 : 4200) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 16500) / batch;
+    const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", N <= 5200 ? 5200 : (N >= 12288 ? 8300 : 4200)) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 16500) / batch;
     const bool fuse2_on = pol.fused && prezero && !(flags & GPAR_POTRF_UNFUSED) && nbo == 512 && env_int("GPAR_PANEL_V", 2) >= 2 &&
                           env_int("GPAR_PANEL_PAIRS", 1) && (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && fuse2_rows > 0 && tail == 0;
     unsigned long long fuse_counted = 0;   // tiles every row block below the fused launches so far has counted (panel2.h)
     // (more than two panels per launch add little - between panels inside a launch the next team waits ~45 us for the last column
     // blocks of its own rows, which the bulk row blocks of the panel before finish behind the chain - : n = 1536 0.497 -> 0.452 ms with
     // three, n = 2048 0.647 -> 0.637 with four, nothing beyond; 4 measured equal or better than 2 / 3 / 8 at every size)
-    const int fuse_max = env_int("GPAR_POTRF_FUSE_MAX", 10);
+    // (from N = 12288 on the last sixteen panels: with the faster update tiles n = 12288 12.0-12.1 -> 11.9 ms, n = 16384 25.4-25.5 -> 25.1-25.2;
+    // n = 8192 4.66-4.70 / 4.59 / 4.74-4.77 ms fused from 4200 / 6200 / 8300 rows: profiles/r05_exp_fuse_rows.txt)
+    const int fuse_max = env_int("GPAR_POTRF_FUSE_MAX", N >= 12288 ? 16 : 10);
     // panels the step at column k takes in one launch (0: the step is not fused)
     auto fuse_panels = [&](int k) {
         if (!fuse2_on || groupable(k) || k % 64 != 0 || N - k > fuse2_rows) return 0;
