@@ -300,9 +300,7 @@ __device__ __forceinline__ void pnl_diag(double* __restrict__ T, int col0, const
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[q] = pan_d2{acc[2 * q], acc[2 * q + 1]};
         } else if (jb > 0) {
-#ifndef GPAR_EXPERIMENT_NO_DIAG_HELPERS
             pnl_rank8(T, T, jb - 1, i, 8 * jb + 8 + (w - 1), 3);
-#endif
         }
         __syncthreads();
     }

@@ -1533,16 +1533,9 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
         pub.base = 4ull * (unsigned long long)trow;
         pub.add = split;
         double* Sd = psm + 2 * PNL_TILE + 16;   // 8 x 8 scratch block behind the progress cache
-#ifdef GPAR_EXPERIMENT_OLD_DIAG
-        pnl_diag(Cs, r0, p, t);
-        __syncthreads();
-        p2_inverse_blocks(Cs, w, lane);
-        __syncthreads();
-#else
         p3_diag(Cs, r0, p, t, nullptr, progressive ? Sd : nullptr, pub, Xs);
         // (every round ends with a barrier: the tile is complete in LDS here, the inverse blocks - those not yet taken out by the
         // publishing wave - transposed in Xs)
-#endif
         P2_STAMP(trow, 2);   // factored
         if (!progressive) {
             p3_extract_inverse(Cs, Xs, w, lane);
@@ -1598,9 +1591,7 @@ __device__ __forceinline__ void p2_row_block(const PanelArgs& p, const double* _
             p2_publish(p, trow, 4ull * (unsigned long long)trow + 4ull);
         }
         P2_STAMP(trow, 4);   // published
-#ifndef GPAR_EXPERIMENT_OLD_DIAG
         p3_diag_logdet(Cs, r0, p, t);
-#endif
     }
 #undef P2_STAMP
 }

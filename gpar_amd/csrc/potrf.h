@@ -607,6 +607,10 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
                      long long batch_a = 0) {
     if (nf > N) return GPAR_ARG_ERROR(1);
     PotrfPolicy pol = potrf_policy(N);
+    // a LONE large factorisation stops grouping earlier (from 7680 rows on the steps are single panels with look-ahead, the last 7680 rows
+    // then one fused launch of fifteen panels): n = 16384 25.10 -> 24.97 ms, n = 12288 11.84 -> 11.79; a lock-step batch keeps 6144 (C3:
+    // 180.2 against 180.7 ms with 7680; profiles/r05_exp_fuse_rows.txt)
+    if (batch == 1 && N >= 12288 && !getenv("GPAR_POTRF_PAIR_ROWS")) pol.pair_rows = 7680;
     // the caller runs several factorisations at once (three or more layer streams): each one's look-ahead side stream would
     // add a queue to an already over-subscribed chip (C5, three streams at n = 8192: 78 -> 72 ms per evaluation without)
     if ((flags & GPAR_POTRF_NO_LOOKAHEAD) && !getenv("GPAR_POTRF_LOOKAHEAD")) pol.lookahead = 0;

@@ -40,4 +40,4 @@ for n, p in cases:
         prof.enable()
         reg.fit(x, y, iters=20)
         prof.disable()
-        pstats.Stats(prof).sort_stats("cumulative").print_stats(40)
+        pstats.Stats(prof).sort_stats(os.environ.get("PROFILE_SORT", "cumulative")).print_stats(45)
