@@ -6,6 +6,7 @@ import torch
 from gpar_amd import hip as H
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4   # matrices in all
 N = n + 1
 g = torch.Generator().manual_seed(1)
 X = torch.rand(n, 4, generator=g, dtype=torch.float64).to(dev)
@@ -23,19 +24,21 @@ def timed(fn, prep):
         e0.record(); fn(); e1.record(); e1.synchronize()
         best = min(best, e0.elapsed_time(e1))
     return best
-A4 = stacked(4)
-t4 = timed(lambda: H.potrf_batch_(A4, 4, nf=n), lambda: [A4[i * N:(i + 1) * N].copy_(K0) for i in range(4)])
-print(f"one batch of 4: {t4:.3f} ms")
+A4 = stacked(B)
+t4 = timed(lambda: H.potrf_batch_(A4, B, nf=n), lambda: [A4[i * N:(i + 1) * N].copy_(K0) for i in range(B)])
+print(f"one batch of {B}: {t4:.3f} ms")
+del A4; torch.cuda.empty_cache()
 pool = [torch.cuda.Stream(device=dev) for _ in range(4)]
-A2 = [stacked(2), stacked(2)]
+A2 = [stacked(B // 2), stacked(B // 2)]
 def two():
     cur = torch.cuda.current_stream()
     for k in range(2):
         pool[k].wait_stream(cur)
-        with torch.cuda.stream(pool[k]): H.potrf_batch_(A2[k], 2, nf=n)
+        with torch.cuda.stream(pool[k]): H.potrf_batch_(A2[k], B // 2, nf=n)
     for k in range(2): cur.wait_stream(pool[k])
-t2 = timed(two, lambda: [A2[k][i * N:(i + 1) * N].copy_(K0) for k in range(2) for i in range(2)])
-print(f"two batches of 2 on two streams: {t2:.3f} ms")
+t2 = timed(two, lambda: [A2[k][i * N:(i + 1) * N].copy_(K0) for k in range(2) for i in range(B // 2)])
+print(f"two batches of {B // 2} on two streams: {t2:.3f} ms")
+if B != 4: sys.exit(0)
 A1 = [stacked(1) for _ in range(4)]
 def four():
     cur = torch.cuda.current_stream()
