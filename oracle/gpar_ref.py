@@ -22,8 +22,9 @@ What each public function pins:
 import numpy as np
 
 from . import gp_ref
+from . import kernels as oracle_kernels
 
-__all__ = ["layer_spec", "gpar_logpdf", "gpar_predict_moments", "fd_gradient", "bounds", "to_unconstrained"]
+__all__ = ["layer_spec", "gpar_logpdf", "gpar_predict_moments", "gpar_sample", "fd_gradient", "bounds", "to_unconstrained"]
 
 
 def _indices(m, pi, markov):
@@ -205,6 +206,66 @@ def gpar_predict_moments(x, y, w, hypers, config, xs, ws=None, latent=False, imp
             x = np.concatenate([x, col[:, None]], axis=1)
             xs = np.concatenate([xs, mean_s[:, None]], axis=1)
     return np.stack(means, axis=1), np.stack(variances, axis=1)
+
+
+def gpar_sample(x, y, w, hypers, config, xs, ws=None, num_samples=1, latent=False, impute=False, replace=False, eps=1e-12,
+                normalise_y=True, seed=0):
+    """`num_samples` ancestral samples (num_samples x n* x p) of a dense GPAR conditioned on (x, y, w), at inputs xs - what
+    `GPARRegressor.sample(xs, ws, posterior=True, num_samples=...)` draws (regression.py:508-564 over model.py:245-277): layer by layer a
+    joint draw of the latent function at the current inputs from the conditioned layer, observation noise noise_i / w*_i on top, and
+    the NOISY draw appended to the inputs of the next layer (with `replace` the posterior mean instead, model.py:291-322 with
+    obs = None); the sample returned is the latent or the noisy draw.  Outputs un-normalised as regression.py:551-552.  Own random
+    numbers (numpy's generator): comparable with the product's samples in distribution only."""
+    rng = np.random.default_rng(seed)
+    x = np.asarray(x, dtype=np.float64)
+    x = x[:, None] if x.ndim == 1 else x
+    xs0 = np.asarray(xs, dtype=np.float64)
+    xs0 = xs0[:, None] if xs0.ndim == 1 else xs0
+    y = np.asarray(y, dtype=np.float64)
+    y = y[:, None] if y.ndim == 1 else y
+    w = np.ones_like(y) if w is None else np.asarray(w, dtype=np.float64)
+    m, p = x.shape[1], y.shape[1]
+    ns = xs0.shape[0]
+    ws = np.ones((ns, p)) if ws is None else np.asarray(ws, dtype=np.float64)
+    offset, scale = _normalisation(y, normalise_y)
+    y = (y - offset) / scale
+    # the conditioning chain (model.py:116-149): per layer the training inputs, the solved weights and the inverse of the noisy Gram
+    available = ~np.isnan(y)
+    layers = []
+    for i in range(p):
+        mask = available[:, i].copy()
+        if impute and i < p - 1:
+            mask |= available[:, i + 1:].any(axis=1)
+        x, yi, wi = x[mask], y[mask, i], w[mask, i]
+        y, w, available = y[mask], w[mask], available[mask]
+        spec, noise = layer_spec(hypers, m, i, config)
+        have = ~np.isnan(yi)
+        S = oracle_kernels.gram(spec, x[have], None, noise_diag=noise / wi[have], jitter=eps)
+        Sinv = np.linalg.inv(S)
+        layers.append((spec, noise, x[have].copy(), Sinv @ yi[have], Sinv))
+        if i < p - 1:
+            col = yi.copy()
+            if impute or replace:
+                mean_x = oracle_kernels.gram(spec, x, x[have]) @ layers[-1][3]
+                if impute:
+                    col[~have] = mean_x[~have]
+                if replace:
+                    col[have] = mean_x[have]
+            x = np.concatenate([x, col[:, None]], axis=1)
+    out = np.empty((num_samples, ns, p))
+    for s_ in range(num_samples):
+        xs = xs0
+        for i, (spec, noise, xt, alpha, Sinv) in enumerate(layers):
+            Ksx = oracle_kernels.gram(spec, xs, xt)
+            mean = Ksx @ alpha
+            cov = oracle_kernels.gram(spec, xs) - Ksx @ Sinv @ Ksx.T
+            cov = 0.5 * (cov + cov.T) + 1e-10 * np.eye(ns)
+            f = mean + np.linalg.cholesky(cov) @ rng.standard_normal(ns)
+            noisy = f + np.sqrt(noise / ws[:, i]) * rng.standard_normal(ns)
+            out[s_, :, i] = (f if latent else noisy) * scale[i] + offset[i]
+            if i < p - 1:
+                xs = np.concatenate([xs, (mean if replace else noisy)[:, None]], axis=1)
+    return out
 
 
 def bounds(name):

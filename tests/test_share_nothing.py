@@ -5,6 +5,9 @@ instead of any factorisation the product composes), beyond the log marginal like
   * conditioning chain + predictive means / variances for `replace=True`, where they exist in closed form
     (reference gpar/model.py:116-149, 245-277, 291-322; gpar/regression.py:339-389, 566-597) - against the product's
     `predict_moments`, and the Monte-Carlo `predict` against both;
+  * the posterior SAMPLES themselves (reference gpar/model.py:245-277: the noisy draw of a layer is the next layer's input) - in
+    distribution, against `gpar_ref.gpar_sample` with its own random numbers: means, spreads and the correlation between consecutive
+    outputs, with the linear-output shortcut, the general path, a Markov window and `replace`;
   * the gradient `fit` needs (reference gpar/regression.py:434-459; autograd there, analytic kernels here) - against central
     finite differences of `gpar_ref.gpar_logpdf` in the hyper-parameter dictionary, mapped to the optimiser's variables.
 
@@ -151,3 +154,43 @@ def test_joint_gradient_matches_share_nothing_finite_differences(engine, name):
     got, want = np.concatenate(got), np.concatenate(want)
     assert np.max(np.abs(want)) > 1e-2
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6 * np.max(np.abs(want)))
+
+
+SAMPLE_CONFIGS = {
+    # the reference's default output dependence (linear only: the product takes its shared-solve shortcut, gp.Obs._sample_batch_linear_tail),
+    # the general path (stacked solves, batched downdates), a Markov window, the chain through replaced means
+    "linear-outputs": (dict(scale=0.5, linear=True, nonlinear=False, noise=0.05), dict()),
+    "nonlinear-outputs": (dict(scale=0.5, linear=True, nonlinear=True, noise=0.05), dict()),
+    "markov1-rq": (dict(scale=0.5, linear=True, nonlinear=True, rq=True, markov=1, noise=0.05), dict()),
+    "replace": (dict(scale=0.5, linear=True, nonlinear=True, noise=0.05, replace=True, impute=True), dict()),
+}
+
+
+@pytest.mark.parametrize("latent", [False, True], ids=["observed", "latent"])
+@pytest.mark.parametrize("name", list(SAMPLE_CONFIGS))
+def test_posterior_samples_have_the_share_nothing_samplers_distribution(engine, name, latent):
+    """`sample(posterior=True)` - joint ancestral sampling, the noisy draw of a layer fed to the next (reference model.py:245-277) -
+    against `gpar_ref.gpar_sample`, a numpy restatement with its own random numbers: per test point and output the means of S = 1500
+    draws agree within 5 standard errors, the standard deviations within 15 %, and so does the correlation between consecutive
+    outputs at a point (within 0.16: four standard errors of a difference of two sample correlations) - what feeding SAMPLES (not means) forward produces.  No shared code, no shared randomness."""
+    from gpar_amd.regression import GPARRegressor
+    from oracle import gpar_ref
+
+    kw, _ = SAMPLE_CONFIGS[name]
+    x, y = _problem(70, 2, 3, seed=len(name) + 71)
+    xs = np.random.default_rng(3).uniform(0, 1, (6, 2))
+    ws = np.random.default_rng(4).uniform(0.5, 2.0, (6, 3))
+    reg = GPARRegressor(**kw)
+    reg.condition(x, y)
+    S = 1500
+    got = np.stack(reg.sample(xs, ws, posterior=True, num_samples=S, latent=latent))
+    want = gpar_ref.gpar_sample(x, y, None, reg.get_variables(), reg.model_config, xs, ws, num_samples=S, latent=latent,
+                                impute=kw.get("impute", False), replace=kw.get("replace", False), seed=9)
+    assert got.shape == want.shape == (S, 6, 3)
+    mg, mw, sg, sw = got.mean(0), want.mean(0), got.std(0), want.std(0)
+    assert np.all(np.abs(mg - mw) <= 5.0 * np.sqrt((sg ** 2 + sw ** 2) / S)), np.max(np.abs(mg - mw) / np.sqrt((sg ** 2 + sw ** 2) / S))
+    np.testing.assert_allclose(sg, sw, rtol=0.15)
+    for i in range(2):
+        cg = [np.corrcoef(got[:, j, i], got[:, j, i + 1])[0, 1] for j in range(6)]
+        cw = [np.corrcoef(want[:, j, i], want[:, j, i + 1])[0, 1] for j in range(6)]
+        np.testing.assert_allclose(cg, cw, atol=0.16)
