@@ -637,7 +637,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // pairing stops once the trailing update is too short to hide it (`pair_rows`).
     const int G = pol.group;
     // hand-off flags of all panels zeroed once, ahead of the first panel (panel.h)
-    const bool prezero = pol.fused && env_int("GPAR_POTRF_PREZERO", 1) && nf >= 128;
+    const bool prezero = pol.fused && env_int("GPAR_POTRF_PREZERO", 1) && nf >= env_int("GPAR_POTRF_LOCKSTEP_MIN", 1);
     if (prezero) potrf_zero_flags(A, N, lda, stream, batch, batch_a);
     auto groupable = [&](int k) {
         return G > 1 && k > 0 && pol.fused && nbo % 64 == 0 && k + G * nbo <= nf && (N - k) >= pol.pair_rows && (k % 2 == 0) && (lda % 2 == 0) &&
@@ -829,7 +829,7 @@ static int potrf_run_batch(double* A, int batch, long long batch_a, int N, int n
     if (nf > N) return GPAR_ARG_ERROR(1);
     const PotrfPolicy pol = potrf_policy(N);
     const bool lockstep = batch > 1 && pol.fused && !(flags & GPAR_POTRF_UNFUSED) && env_int("GPAR_PANEL_V", 2) >= 2 && pol.nbo % 64 == 0 &&
-                          (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && nf >= 128;
+                          (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && nf >= env_int("GPAR_POTRF_LOCKSTEP_MIN", 1);
     if (lockstep) return potrf_run(A, N, nf, lda, logdet, info, stream, flags, batch, batch_a);
     for (int b = 0; b < batch; ++b) {
         const int rc = potrf_run(A + (size_t)b * batch_a, N, nf, lda, logdet + b, info + b, stream, flags);

@@ -54,6 +54,7 @@ CALL_TIME = [
     ("GPAR_POTRF_FUSE2_BATCH_ROWS", "0"),
     ("GPAR_POTRF_FUSE2_BATCH_ROWS", "100000"),
     ("GPAR_POTRF_LA_SMALL_TILES2", "0"),
+    ("GPAR_POTRF_LOCKSTEP_MIN", "2000"),
     ("GPAR_POTRF_FUSE_MAX", "2"),
     ("GPAR_POTRF_FUSE_MAX", "8"),
     ("GPAR_ONE_CALL", "0"),
