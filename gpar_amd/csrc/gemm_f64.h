@@ -581,7 +581,13 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     // half tiles (two workgroups per 128 x 128 tile) while a launch has fewer tiles than the chip has compute units
     static int half_tiles = -1;
     if (half_tiles < 0) { const char* e = getenv("GPAR_GEMM_HALF_TILES"); half_tiles = e ? atoi(e) : 256; }
-    const bool half = !ta && tb && ntiles * batch <= half_tiles && k >= 64 && !(flags & (GPAR_GEMM_A_LOWER | GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_K_TO_COL));
+    // (triangular-aware products included since round 5 - the K range of a tile follows its own first row / last column whatever its height:
+    // the inverse's few-tile products at small n are one K-deep tile each, half as long per workgroup this way: fit(iters=20), one thread,
+    // n = 400 103-120 -> 97-100 ms, n = 1024 136-153 -> 118-121)
+    static int half_flags = -1;
+    if (half_flags < 0) { const char* e = getenv("GPAR_GEMM_HALF_TILES_TRIANGULAR"); half_flags = e ? atoi(e) : 1; }
+    const bool half = !ta && tb && ntiles * batch <= half_tiles && k >= 64 &&
+                      (half_flags || !(flags & (GPAR_GEMM_A_LOWER | GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_K_TO_COL)));
     static int lds_extra = -1;
     if (lds_extra < 0) { const char* e = getenv("GPAR_GEMM_LDS_EXTRA"); lds_extra = e ? atoi(e) : 0; }
     const int GEMM_LDS_REQ = GEMM_LDS_BYTES + lds_extra;   // experiment knob: > 6.2 KB extra forces one workgroup per CU

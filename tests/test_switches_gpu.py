@@ -71,7 +71,8 @@ CALL_TIME = [
     ("GPAR_GRAD_JIT_MIN_ENTRIES", "0"),
     ("GPAR_GRAD_JIT_MIN_ENTRIES", "-1"),
 ]
-CACHED = [("GPAR_AOT", "0"), ("GPAR_AOT_MIN_ENTRIES", "0"), ("GPAR_GEMM_HALF_TILES", "0"), ("GPAR_GEMM_HALF_TILES", "100000"), ("GPAR_GEMM_MIXED_TAIL", "0")]
+CACHED = [("GPAR_AOT", "0"), ("GPAR_AOT_MIN_ENTRIES", "0"), ("GPAR_GEMM_HALF_TILES", "0"), ("GPAR_GEMM_HALF_TILES", "100000"), ("GPAR_GEMM_MIXED_TAIL", "0"),
+          ("GPAR_GEMM_HALF_TILES_TRIANGULAR", "0")]
 
 
 def _evaluate():
