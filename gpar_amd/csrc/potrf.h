@@ -611,6 +611,11 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // then one fused launch of fifteen panels): n = 16384 25.10 -> 24.97 ms, n = 12288 11.84 -> 11.79; a lock-step batch keeps 6144 (C3:
     // 180.2 against 180.7 ms with 7680; profiles/r05_exp_fuse_rows.txt)
     if (batch == 1 && N >= 12288 && !getenv("GPAR_POTRF_PAIR_ROWS")) pol.pair_rows = 7680;
+    // a wide lock-step batch of large matrices groups its panels down to 2560 rows: its rank-1536 updates are `batch` times a lone
+    // matrix's and hide the longer serial stretch, and spare the launch-wide read and write of the trailing matrices two times in three
+    // (C5, 16 x 8193: 55.5 -> 53.7 ms; 12 x 8192 40.8 -> 39.5, 12 x 10240 73.7 -> 72.5; batches of 2-8 and matrices below 8192 rows:
+    // equal or slower, C3 - 8 x 16385 - equal: profiles/r05_exp_batch_pair.txt)
+    if (batch >= 12 && N >= 8192 && !getenv("GPAR_POTRF_PAIR_ROWS")) pol.pair_rows = 2560;
     // the caller runs several factorisations at once (three or more layer streams): each one's look-ahead side stream would
     // add a queue to an already over-subscribed chip (C5, three streams at n = 8192: 78 -> 72 ms per evaluation without)
     if ((flags & GPAR_POTRF_NO_LOOKAHEAD) && !getenv("GPAR_POTRF_LOOKAHEAD")) pol.lookahead = 0;
