@@ -11,6 +11,7 @@
 #pragma once
 #include "common.h"
 #include "gemm_f64.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <utility>
@@ -233,6 +234,7 @@ struct ProfileState {
     double ms_busy = 0.0;    // union of their intervals (launches issued from different streams may overlap)
     static constexpr int MAXEV = 8192;
     hipEvent_t ev[MAXEV][2];
+    int shape[MAXEV][3];     // rows, cols, kb (x batch) of the update behind event pair i (GPAR_PROFILE_DUMP)
     int nev = 0;
     bool created = false;
 };
@@ -249,6 +251,16 @@ static void profile_collect() {
         GPAR_HIP_IGNORE(hipEventElapsedTime(&t1, g_prof.ev[0][0], g_prof.ev[i][1]));
         g_prof.ms_done += t1 - t0;
         iv[i] = {t0, t1};
+    }
+    if (const char* path = getenv("GPAR_PROFILE_DUMP")) {
+        // development aid (tools/r06_launch_table.py): one line per counted update launch - start and end in ms since the first
+        // one, rows, cols, K x batch - appended to the named file
+        if (FILE* f = fopen(path, "a")) {
+            for (int i = 0; i < g_prof.nev; ++i)
+                fprintf(f, "%.6f %.6f %d %d %d\n", iv[i].first, iv[i].second, g_prof.shape[i][0], g_prof.shape[i][1], g_prof.shape[i][2]);
+            fprintf(f, "#\n");
+            fclose(f);
+        }
     }
     std::sort(iv.begin(), iv.end());
     float cs = iv[0].first, ce = iv[0].second;
@@ -580,8 +592,11 @@ static hipStream_t la_side(hipStream_t caller) {
     return s;
 }
 
-static void prof_begin(hipStream_t s, bool& active) {
-    active = g_prof.on && g_prof.nev < ProfileState::MAXEV;
+// (`rows`: the rows of the update about to be launched.  An update of at most POTRF_SMALL_ROWS rows - the augmented row once the last
+// panel is next - is the one-wave kernel, not the matrix-core update: it is not counted, so that `launches` equals the dispatches of
+// gemm_f64_kernel<false, true, 1, *> a kernel trace of the same evaluation shows.)
+static void prof_begin(hipStream_t s, bool& active, int rows) {
+    active = g_prof.on && g_prof.nev < ProfileState::MAXEV && !(rows <= POTRF_SMALL_ROWS && env_int("GPAR_POTRF_SMALL_UPDATE", 1));
     if (!active) return;
     if (!g_prof.created) {
         for (int i = 0; i < ProfileState::MAXEV; ++i)
@@ -594,6 +609,7 @@ static void prof_begin(hipStream_t s, bool& active) {
 static void prof_end(hipStream_t s, bool active, int rows, int cols, int kb) {
     if (!active) return;
     GPAR_HIP_IGNORE(hipEventRecord(g_prof.ev[g_prof.nev][1], s));
+    g_prof.shape[g_prof.nev][0] = rows; g_prof.shape[g_prof.nev][1] = cols; g_prof.shape[g_prof.nev][2] = kb;
     g_prof.nev++;
     g_prof.launches++;
     // algorithmic flops of the lower-trapezoid rank-kb update: 2 * kb per stored element
@@ -701,7 +717,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
                     // (they must have received the previous step's update first: it runs at the head of the side stream)
                     if (mid_done) { GPAR_HIP_TRY(hipStreamWaitEvent(stream, mid_done, 0)); mid_done = nullptr; }
                     bool pb;
-                    prof_begin(stream, pb);
+                    prof_begin(stream, pb, N - ks);
                     rc = potrf_gemm_update(c, k0, ks, ks + nbo, stream, 1);
                     prof_end(stream, pb, N - ks, nbo, (ks - k0) * batch);
                 }
@@ -740,7 +756,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
                 // small kernel, everything to their right by the GEMM)
                 rc = potrf_la_update(c, k0, kend, next_end, stream);
                 if (!rc) {
-                    prof_begin(stream, pa);
+                    prof_begin(stream, pa, N - next_end);
                     rc = potrf_rest_update(c, k0, kend, next_end, stream);
                     prof_end(stream, pa, N - next_end, N - next_end, (kend - k0) * batch);
                 }
@@ -751,18 +767,18 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
                 // (the same two launches as the look-ahead schedule below - the next step's columns, then everything to their right:
                 // the update kernel picks its tile shape by the size of the launch, and a tile that preloads C rounds differently
                 // from one that adds it at the end, so ONE launch over everything would not return the look-ahead schedule's bits)
-                prof_begin(stream, pa);
+                prof_begin(stream, pa, N - kend);
                 rc = potrf_gemm_update(c, k0, kend, next_end, stream, 1);
                 prof_end(stream, pa, N - kend, next_end - kend, (kend - k0) * batch);
                 if (!rc) {
-                    prof_begin(stream, pa);
+                    prof_begin(stream, pa, N - next_end);
                     rc = potrf_rest_update(c, k0, kend, next_end, stream);
                     prof_end(stream, pa, N - next_end, N - next_end, (kend - k0) * batch);
                 }
                 if (rc) return rc;
                 continue;
             }
-            prof_begin(stream, pa);
+            prof_begin(stream, pa, N - kend);
             rc = potrf_gemm_update(c, k0, kend, N, stream, 1);
             prof_end(stream, pa, N - kend, N - kend, (kend - k0) * batch);
             if (rc) return rc;
@@ -784,7 +800,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         if (potrf_la_is_small(c, k0, kend, la_end)) {
             rc = potrf_la_update(c, k0, kend, la_end, stream);
         } else {
-            prof_begin(stream, pa);
+            prof_begin(stream, pa, N - kend);
             rc = potrf_gemm_update(c, k0, kend, la_end, stream, 1);   // same kernel symbol: it is part of the trailing update
             prof_end(stream, pa, N - kend, la_end - kend, (kend - k0) * batch);
         }
@@ -795,7 +811,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         if (la_end < next_end) {
             const int rows = N - la_end, cols = next_end - la_end;
             const double* P = A + (size_t)la_end * lda + k0;
-            prof_begin(side, pa);
+            prof_begin(side, pa, rows);
             rc = gemm_launch(0, 1, rows, cols, kend - k0, -1.0, P, lda, P, lda, 1.0, A + (size_t)la_end * lda + la_end, lda,
                              GPAR_GEMM_C_LOWER, side, 1, batch, batch_a, batch_a, batch_a);
             prof_end(side, pa, rows, cols, (kend - k0) * batch);
@@ -807,7 +823,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         {
             const int rows = N - next_end, cols = N - next_end;
             if (rows > 0) {
-                prof_begin(side, pa);
+                prof_begin(side, pa, rows);
                 rc = potrf_rest_update(c, k0, kend, next_end, side);
                 prof_end(side, pa, rows, cols, (kend - k0) * batch);
                 if (rc) return rc;

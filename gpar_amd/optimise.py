@@ -24,11 +24,26 @@ def evaluation_count():
     return _evaluations
 
 
+def count_evaluation():
+    """One more objective + gradient evaluation (several host threads may train layers at once: a statistic, not a synchronised counter)."""
+    global _evaluations
+    _evaluations += 1
+
+
 def minimise_l_bfgs_b(f, vs, names=None, iters=1000, f_calls=10000, trace=False):
     """Minimise `f(vs)` over the variables whose names match `names` (globs allowed; default: all).
 
     Returns the final objective value; the optimum is written back into `vs`.
     """
+    fg, names, x0 = objective_and_gradient(f, vs, names, trace=trace)
+    x_opt, val, _ = scipy.optimize.fmin_l_bfgs_b(fg, x0, maxiter=iters, maxfun=f_calls)
+    vs.set_vector(x_opt, names)
+    return val
+
+
+def objective_and_gradient(f, vs, names=None, trace=False):
+    """(fg, names, x0): `fg(x)` -> (value, gradient) of `f(vs)` at the latent vector x of the variables matching `names` - the
+    function scipy's L-BFGS-B calls - by back-propagation; the resolved names; the current latent vector."""
     patterns = names
 
     def select():
@@ -49,8 +64,7 @@ def minimise_l_bfgs_b(f, vs, names=None, iters=1000, f_calls=10000, trace=False)
     x0 = vs.get_vector(names)
 
     def fg(x):
-        global _evaluations
-        _evaluations += 1  # (several host threads may train layers at once: a statistic, not a synchronised counter)
+        count_evaluation()
         vs.set_vector(x, names)
         previous = [t.requires_grad for t in latents]
         for t in latents:
@@ -74,6 +88,4 @@ def minimise_l_bfgs_b(f, vs, names=None, iters=1000, f_calls=10000, trace=False)
             print(f"  objective {val:.6e}  |grad| {np.linalg.norm(grad):.3e}")
         return val, grad
 
-    x_opt, val, _ = scipy.optimize.fmin_l_bfgs_b(fg, x0, maxiter=iters, maxfun=f_calls)
-    vs.set_vector(x_opt, names)
-    return val
+    return fg, names, x0

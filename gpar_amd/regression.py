@@ -196,6 +196,10 @@ class GPARRegressor:
     """GPAR regressor.  See the reference docstring (regression.py:200-262) for the meaning of every keyword;
     signature and defaults are identical."""
 
+    #: `fit(fix=True)` trains dense layers through the prepared objective of gpar_amd/fastfit.py (same device launches, no
+    #: autograd, no per-evaluation model objects); False keeps the general route for every layer (tests compare the two).
+    fast_fit = True
+
     def __init__(self, replace=False, impute=True, scale=1.0, scale_tie=False, per=False, per_period=1.0,
                  per_scale=1.0, per_decay=10.0, input_linear=False, input_linear_scale=100.0, linear=True,
                  linear_scale=100.0, nonlinear=False, nonlinear_scale=1.0, rq=False, markov=None, noise=0.1,
@@ -282,9 +286,11 @@ class GPARRegressor:
         finals = {}
         eng = get_engine()
         x_dev, y_dev, w_dev = eng.tensor(self.x), eng.tensor(self.y), eng.tensor(self.w)
-        if y_dev.is_cuda and host_masks():
+        if host_masks():
             # self.y is a host tensor (condition): its NaN pattern costs nothing here, and per_output then plans the masks on the
-            # host - index tensors, no synchronisation per layer and evaluation
+            # host - index tensors, no synchronisation per layer and evaluation (on any engine: the CPU tests walk the same route)
+            if y_dev is self.y:
+                y_dev = y_dev.view(y_dev.shape)   # (never hang the plan on the regressor's own attribute)
             y_dev._host_nan = torch.isnan(self.y).numpy()
         y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
         self._prepare_kernels(self.m, self.p, self.n, training=True, inputs=not fix or bool(optimise_x_ind))
@@ -308,13 +314,39 @@ class GPARRegressor:
             names = [f"{pi}/*"] if fix else [f"{i}/*" for i in range(pi + 1)]
             if optimise_x_ind:
                 names = names + ["x_ind"]
-            finals[pi] = minimise_l_bfgs_b(objective, self.vs, names=names, **kw_args)
+            fast = None
+            if fix and not optimise_x_ind and self.fast_fit:
+                # a dense layer with fixed inputs: the objective prepared once, an evaluation = one library call + the chain rule
+                # in numpy (gpar_amd/fastfit.py); None where that route does not apply
+                from . import fastfit
+                from .optimise import objective_and_gradient
+
+                general = []
+
+                def general_fg(x):   # (a failed factorisation goes through the general route's evaluation: unfused retry, NaN)
+                    if not general:
+                        general.append(objective_and_gradient(objective, self.vs, names, trace=kw_args.get("trace", False))[0])
+                    return general[0](x)
+
+                fast = fastfit.build(self, eng, self.vs, pi, names, fixed_x, y_cached[bool(self.impute)][pi], general_fg=general_fg)
+            if fast is not None:
+                finals[pi] = fast.minimise(**kw_args)
+            else:
+                finals[pi] = minimise_l_bfgs_b(objective, self.vs, names=names, **kw_args)
             if optimise_x_ind and "x_ind" in self.vs:
                 self.x_ind = self.vs["x_ind"].detach().clone()
 
         from .parallel import layers_train_independently
 
-        streams = eng.worker_streams(rows=self.n) if hasattr(eng, "worker_streams") else []
+        depth = None
+        if fix and not optimise_x_ind and self.fast_fit and not self.sparse and os.environ.get("GPAR_FIT_THREADS") is None:
+            from .gp import one_call_grad_rows
+
+            if 0 < self.n <= one_call_grad_rows():
+                # the prepared objective leaves ~0.1 ms of interpreter time per evaluation: four drivers no longer contend for it
+                # (fit(iters=20), four layers, 2 -> 4 threads: n = 100 21 -> 15 ms, 400 35 -> 29, 1024 43 -> 30; profiles/r06_small_fit.txt)
+                depth = 4
+        streams = eng.worker_streams(depth=depth, rows=self.n) if hasattr(eng, "worker_streams") else []
         if concurrent and fix and len(layers) > 1 and len(streams) > 1 and layers_train_independently(self, y_dev):
             # Layers whose inputs are data and whose hyper-parameters are their own train independently of one another:
             # two host threads, each on its own stream, keep two L-BFGS-B drivers in flight so that one layer's

@@ -194,7 +194,28 @@ def layer_vfe_bound(spec, x, y, noise_diag, z):
     value = -0.5 * (2.0 * torch.sum(torch.log(torch.diagonal(La))) + torch.sum(torch.log(2.0 * np.pi * d)) + torch.sum(y * y / d[:, None])
                     - torch.sum(v * v) + trace)
     t4 = time.perf_counter()
+    layer_vfe_bound.last_factors = (Lz, La, v)   # (for layer_vfe_posterior_sample: what conditioning on the same data would hold)
     return float(value), {"gram_s": t1 - t0, "solve_s": t2 - t1, "product_s": t3 - t2, "potrf_s": t4 - t3}
+
+
+def layer_vfe_posterior_sample(spec, z, Lz, La, v, x_star, noise_star, generator=None):
+    """One posterior draw of one inducing-point layer at x_star (stheno's PseudoObs posterior; reference
+    gpar/model.py:286-287 then :264-270): with P = K(x*, Z) L_z^-T and Q = P L_A^-T,
+    mean = Q (L_A^-1 c) (`v`), cov = K** - P P^T + Q Q^T, sample = mean + chol(cov + noise + eps) randn.  Returns (draw, seconds per stage)."""
+    z, x_star = _as_torch(z), _as_torch(x_star)
+    t0 = time.perf_counter()
+    Ksz = gram(spec, x_star, z)
+    Kss = gram(spec, x_star)
+    t1 = time.perf_counter()
+    P = torch.linalg.solve_triangular(Lz, Ksz.T, upper=False).T
+    Q = torch.linalg.solve_triangular(La, P.T, upper=False).T
+    mean = Q @ v
+    cov = Kss - P @ P.T + Q @ Q.T + torch.diag(_as_torch(noise_star).reshape(-1) + EPSILON)
+    t2 = time.perf_counter()
+    Ls = torch.linalg.cholesky(cov)
+    draw = mean + Ls @ torch.randn(x_star.shape[0], 1, dtype=torch.float64, generator=generator)
+    t3 = time.perf_counter()
+    return draw, {"gram_s": t1 - t0, "solve_s": t2 - t1, "potrf_s": t3 - t2}
 
 
 def leaf_spec(spec):

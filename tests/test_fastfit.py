@@ -1,0 +1,210 @@
+"""The prepared training objective of a dense layer (gpar_amd/fastfit.py; reference gpar/regression.py:418-459, the objective
+`minimise_l_bfgs_b` is handed per layer with fix=True).
+
+CPU part: the HOST logic - the kernel expression traced over value holders, the bounded transforms, the mapping of the device
+pass's per-position gradients to the store's variables, the chain rule in numpy - against the general route (torch autograd
+through `GPAR.logpdf`) on the numpy engine, with the device side of the objective replaced by a dense numpy computation.
+GPU part (`-m gpu`): the real thing through libgpar_hip.so - value to the bit, gradient to rounding, trained hyper-parameters
+of `fit` equal on both routes."""
+import numpy as np
+import pytest
+import torch
+
+from gpar_amd import fastfit
+from gpar_amd.engine import set_engine
+from gpar_amd.model import per_output
+from gpar_amd.optimise import objective_and_gradient
+from gpar_amd.regression import GPARRegressor, _construct_gpar
+
+from .conftest import make_engine
+
+_LOG_2PI = float(np.log(2.0 * np.pi))
+
+
+class NumpyObjective(fastfit.DenseLayerObjective):
+    """DenseLayerObjective with its device side restated densely in numpy (test infrastructure: oracle kernels)."""
+
+    def _allocate(self, ck):
+        pass
+
+    def _device_eval(self, ck, noise):
+        from oracle import kernels as ok
+
+        spec = ok.spec_to_dict(self.kernel.resolve(self.width))
+        X, y, w = self.X.numpy(), self.y.numpy(), self.w.numpy()
+        n = X.shape[0]
+        K = ok.gram(spec, X, None, noise_diag=noise / w, jitter=self.eng.epsilon)
+        try:
+            L = np.linalg.cholesky(K)
+        except np.linalg.LinAlgError:
+            return None
+        alpha = np.linalg.solve(K, y)
+        value = -0.5 * (2.0 * np.sum(np.log(np.diag(L))) + n * _LOG_2PI + float(y @ alpha))
+        W = np.outer(alpha, alpha) - np.linalg.inv(K)
+        return value, ok.kernel_grads(spec, X, W), 0.5 * np.diag(W).copy()
+
+
+CONFIGS = {
+    "default": dict(scale=0.5, linear=True, nonlinear=False, noise=0.1),
+    "nonlinear": dict(scale=0.5, linear=True, nonlinear=True, noise=0.1),
+    "rq": dict(scale=0.7, linear=True, nonlinear=True, rq=True, noise=0.05),
+    "periodic": dict(scale=0.5, per=True, per_period=0.8, linear=True, nonlinear=True, noise=0.1),
+    "input_linear": dict(scale=0.5, input_linear=True, linear=False, nonlinear=True, noise=0.1),
+    "tied_markov": dict(scale=0.5, scale_tie=True, linear=True, nonlinear=True, markov=1, noise=0.1),
+}
+
+
+def _data(n=40, m=2, p=3, seed=0, missing=0.0, weights=False):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 1, (n, m))
+    cols = []
+    for i in range(p):
+        f = np.sin(4.0 * x @ rng.uniform(0.5, 1.5, m) + i) + (0.5 * cols[-1] if cols else 0.0)
+        cols.append(f + 0.1 * rng.standard_normal(n))
+    y = np.stack(cols, axis=1)
+    if missing:
+        y[rng.random(y.shape) < missing] = np.nan
+        y[0] = 0.3   # (one complete row)
+    w = rng.uniform(0.5, 2.0, y.shape) if weights else None
+    return x, y, w
+
+
+def _layer_objectives(reg, eng, pi, cls):
+    """(fast objective, general fg, x0) of layer pi of the conditioned regressor, both over the store reg.vs."""
+    x_t, y_t, w_t = eng.tensor(reg.x), eng.tensor(reg.y), eng.tensor(reg.w)
+    if y_t is reg.y:
+        y_t = y_t.view(y_t.shape)
+    y_t._host_nan = torch.isnan(reg.y).numpy()
+    y_cached = {k: list(per_output(y_t, w_t, keep=k)) for k in [True, False]}
+    gpar = _construct_gpar(reg, reg.vs, reg.m, pi + 1)
+    fixed_x, fixed_x_ind = gpar.logpdf(x_t, y_cached, None, only_last_layer=True, outputs=list(range(pi)), return_inputs=True)
+
+    def objective(vs):
+        g = _construct_gpar(reg, vs, reg.m, pi + 1)
+        return -g.logpdf(fixed_x, y_cached, None, only_last_layer=True, outputs=[pi], x_ind=fixed_x_ind)
+
+    names = [f"{pi}/*"]
+    fg, resolved, x0 = objective_and_gradient(objective, reg.vs, names)
+    fast = fastfit.build(reg, eng, reg.vs, pi, names, fixed_x, y_cached[bool(reg.impute)][pi], cls=cls)
+    assert fast is not None and fast.names == resolved
+    return fast, fg, x0
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("variant", ["plain", "weights", "missing", "missing_replace"])
+def test_prepared_objective_equals_the_autograd_route_on_the_host_side(oracle_engine, name, variant):
+    x, y, w = _data(missing=0.2 if variant.startswith("missing") else 0.0, weights=variant == "weights")
+    reg = GPARRegressor(normalise_y=variant != "plain", replace=variant == "missing_replace", **CONFIGS[name])
+    reg.condition(x, y, w)
+    for pi in range(reg.p):
+        fast, fg, x0 = _layer_objectives(reg, oracle_engine, pi, NumpyObjective)
+        rng = np.random.default_rng(pi)
+        for trial in range(3):
+            xv = x0 + (0.0 if trial == 0 else 0.3 * rng.standard_normal(x0.shape))
+            v_fast, g_fast = fast.fg(xv)
+            v_ref, g_ref = fg(xv)
+            assert abs(v_fast - v_ref) <= 1e-9 * max(1.0, abs(v_ref)), (name, variant, pi, v_fast, v_ref)
+            np.testing.assert_allclose(g_fast, g_ref, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(g_ref).max()))
+        reg.vs.set_vector(x0, fast.names)
+
+
+def test_prepared_objective_leaves_unread_variables_alone_and_reports_failures(oracle_engine):
+    x, y, w = _data()
+    reg = GPARRegressor(scale=0.5, scale_tie=True, linear=True, nonlinear=True, noise=0.1, normalise_y=False)
+    reg.condition(x, y, w)
+    fast, fg, x0 = _layer_objectives(reg, oracle_engine, 1, NumpyObjective)
+    # layer 1 reads "0/input/scales" (tied) but trains "1/*" only: the tied scales are not among its variables
+    assert all(n.startswith("1/") for n in fast.names) and "0/input/scales" in fast.holders
+
+    class Failing(NumpyObjective):
+        def _device_eval(self, ck, noise):
+            return None
+
+    seen = []
+    failing = Failing(fast.eng, fast.vs, fast.names, fast.kernel, fast.noise, fast.holders, fast.X, fast.y, fast.w,
+                      general_fg=lambda xv: (seen.append(1), fg(xv))[1])
+    v, g = failing.fg(x0)
+    v_ref, g_ref = fg(x0)
+    assert seen and v == v_ref and np.array_equal(g, g_ref) and failing.fallbacks == 1
+    lone = Failing(fast.eng, fast.vs, fast.names, fast.kernel, fast.noise, fast.holders, fast.X, fast.y, fast.w)
+    v, g = lone.fg(x0)
+    assert np.isnan(v) and not g.any()
+
+
+def test_fit_takes_the_prepared_objective_where_it_applies_and_trains_the_same_model(oracle_engine, monkeypatch):
+    x, y, w = _data(n=30, missing=0.1)
+    built = []
+    real_build = fastfit.build
+
+    def build(*args, **kwargs):
+        obj = real_build(*args, cls=NumpyObjective, **kwargs)
+        built.append(obj)
+        return obj
+
+    monkeypatch.setattr(fastfit, "build", build)
+    kw = dict(scale=0.5, linear=True, nonlinear=True, noise=0.1)
+    fast = GPARRegressor(**kw)
+    fast.fit(x, y, w, iters=6)
+    assert len(built) == 3 and all(b is not None and b.evaluations > 0 for b in built)
+    slow = GPARRegressor(**kw)
+    slow.fast_fit = False
+    slow.fit(x, y, w, iters=6)
+    assert len(built) == 3
+    a, b = fast.get_variables(), slow.get_variables()
+    assert sorted(a) == sorted(b)
+    for k in a:
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-9, err_msg=k)
+    # inducing points: the prepared objective does not apply, the general route trains
+    sparse = GPARRegressor(x_ind=np.linspace(0, 1, 8)[:, None] * np.ones((1, 2)), **kw)
+    before = len(built)
+    sparse.fit(x, y, w, iters=2)
+    assert all(b is None for b in built[before:])
+
+
+# ---- through libgpar_hip.so --------------------------------------------------------------------------------------------------
+
+@pytest.fixture
+def hip_engine():
+    eng = make_engine("hip")
+    previous = set_engine(eng)
+    yield eng
+    set_engine(previous)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("variant,n", [("plain", 100), ("weights", 257), ("missing", 400), ("plain", 1100)])
+def test_prepared_objective_on_the_device_same_value_bits_and_gradient(hip_engine, name, variant, n):
+    x, y, w = _data(n=n, missing=0.15 if variant == "missing" else 0.0, weights=variant == "weights", seed=n)
+    reg = GPARRegressor(normalise_y=False, **CONFIGS[name])
+    reg.condition(x, y, w)
+    for pi in range(reg.p):
+        fast, fg, x0 = _layer_objectives(reg, hip_engine, pi, None)
+        rng = np.random.default_rng(pi)
+        for trial in range(2):
+            xv = x0 + (0.0 if trial == 0 else 0.2 * rng.standard_normal(x0.shape))
+            v_fast, g_fast = fast.fg(xv)
+            v_ref, g_ref = fg(xv)
+            assert v_fast == v_ref, (name, variant, pi, v_fast, v_ref)   # the same launches on the same inputs
+            np.testing.assert_allclose(g_fast, g_ref, rtol=1e-11, atol=1e-12 * max(1.0, np.abs(g_ref).max()))
+        assert fast.fallbacks == 0
+        reg.vs.set_vector(x0, fast.names)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [100, 400, 1024])
+def test_fit_trains_the_same_hyperparameters_on_both_routes(hip_engine, n):
+    """the same trained hyper-parameters as the general route.  Every evaluation returns the same VALUE to
+    the bit and the same gradient up to the summation order of one sum (the noise variance's: n terms added by numpy here, by a
+    device reduction there - a relative 1e-16); twenty L-BFGS-B iterations carry that to 1e-9 .. 2e-8 of a trained value."""
+    x, y, _ = _data(n=n, m=2, p=4, seed=3)
+    kw = dict(scale=0.5, linear=True, nonlinear=False, noise=0.1, normalise_y=False)
+    fast = GPARRegressor(**kw)
+    fast.fit(x, y, iters=20)
+    slow = GPARRegressor(**kw)
+    slow.fast_fit = False
+    slow.fit(x, y, iters=20)
+    a, b = fast.get_variables(), slow.get_variables()
+    assert sorted(a) == sorted(b)
+    for k in a:
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-7, atol=1e-10, err_msg=k)

@@ -233,6 +233,71 @@ def test_c4_full_size_inducing_point_bound_against_the_dense_nystrom_route(hip):
     want = dense - 0.5 * trace
     assert abs(elbo - want) <= 1e-9 * abs(want), (elbo, want)
 
+    # ---- the POSTERIOR through the same observations (reference gpar/model.py:286-287 -> f | obs, :298-301 the mean fed forward): its
+    # mean at the inducing inputs and at held-out inputs against the dense Nystrom route, mean(x*) = Q_*x (Q + D)^-1 y with
+    # Q_*x = K_*z K_zz^-1 K_zx = P_* Bt^T (P_* = K_*z L_z^-T), from the 65537 x 65537 factor above
+    alpha = A[n : n + 1, :n].clone()
+    H.trsm_rln_(A[:n, :n], alpha)           # alpha^T = (L^-1 y)^T L^-1 = y^T (Q + D)^-1
+    del A
+    r = H.gemv_t(Bt, alpha.reshape(-1))      # Bt^T alpha  (M)
+    post = f | obs
+    xs = torch.cat([hip.tensor(np.random.default_rng(5).uniform(0, 1, (300, m))),
+                    torch.randn(300, p - 1, dtype=torch.float64, generator=torch.Generator().manual_seed(3)).to(hip.device)], dim=1)
+    for pts in (zd, xs):
+        got = post.mean(pts).reshape(-1)
+        _, P = obs._P(post._pts(pts))
+        want_mean = (P @ r.reshape(-1, 1)).reshape(-1)
+        assert float((got - want_mean).abs().max()) <= 1e-7 * float(want_mean.abs().max()), float((got - want_mean).abs().max())
+    # ... and its variance at held-out inputs against the same route: k** - P P^T + P (I + Bs^T Bs)^-1 P^T, the middle matrix from
+    # torch's own Cholesky of the product torch formed (nothing of the product's M x M factor enters)
+    var = post.marginal_moments(xs)[1].reshape(-1)
+    _, P = obs._P(post._pts(xs))
+    Ad = Bs.T @ Bs + torch.eye(M, dtype=torch.float64, device=hip.device)
+    Qs = torch.linalg.solve_triangular(torch.linalg.cholesky(Ad), P.T, upper=False)
+    want_var = hip.gram_diag(post._pts(xs).ck, post._pts(xs).z).reshape(-1) - (P * P).sum(1) + (Qs * Qs).sum(0)
+    assert float((var - want_var).abs().max()) <= 1e-8 * float(want_var.abs().max())
+    assert float(var.min()) > 0.0
+
+
+def test_c4_full_size_condition_and_predict_through_the_inducing_points(hip):
+    """BASELINE.md section 4, C4's other two legs at full size (n = 65536, M = 1024, p = 4): `condition` + `predict` - every layer's
+    posterior through PseudoObs, `x_ind` gaining a column per layer (reference gpar/model.py:286-287, 298-305) - exercised through
+    the public API: the closed-form predictive moments of the `replace=True` model against the Monte-Carlo `predict` of the same
+    model (mean within 5 standard errors, spread within 25 %), and C4's own sampler (`replace=False`): finite, ordered bounds that
+    contain the Monte-Carlo mean, a fresh `logpdf` under the posterior that beats the prior's on held-in data."""
+    from gpar_amd.regression import GPARRegressor
+
+    n, m, p, M, ns, S = 65536, 8, 4, 1024, 512, 50
+    x, y = _data(n, m, p)
+    z = np.random.default_rng(3).uniform(0, 1, (M, m))
+    xs = np.random.default_rng(6).uniform(0, 1, (ns, m))
+    kw = dict(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False, x_ind=z)
+
+    rep = GPARRegressor(replace=True, **kw)
+    rep.condition(x, y)
+    mean_cf, var_cf = rep.predict_moments(xs)
+    assert np.isfinite(mean_cf).all() and np.isfinite(var_cf).all() and (var_cf > 0).all()
+    hip.seed(21)
+    samples = np.stack(rep.sample(xs, posterior=True, num_samples=S))
+    mc_mean, mc_sd = samples.mean(0), samples.std(0, ddof=1)
+    se = np.sqrt(var_cf / S)
+    assert np.all(np.abs(mc_mean - mean_cf) <= 5.0 * se + 1e-9), float(np.max(np.abs(mc_mean - mean_cf) / se))
+    ratio = mc_sd.mean(0) / np.sqrt(var_cf).mean(0)
+    assert np.all(np.abs(ratio - 1.0) <= 0.25), ratio
+    # conditioning moved the model towards its training outputs: posterior means at 2000 training inputs are closer to y than the
+    # prior mean (0) is (1024 inducing inputs in eight dimensions at the initial length scales explain little: 0.92 against 0.98)
+    fit_mean, _ = rep.predict_moments(x[:2000])
+    assert np.mean((fit_mean - y[:2000]) ** 2) < 0.97 * np.mean(y[:2000] ** 2)
+
+    reg = GPARRegressor(**kw)   # C4 as BASELINE names it: sampled values fed forward
+    reg.condition(x, y)
+    hip.seed(22)
+    mean, lo, hi = reg.predict(xs, num_samples=S, credible_bounds=True)
+    assert np.isfinite(mean).all() and np.isfinite(lo).all() and np.isfinite(hi).all()
+    assert np.all(lo <= mean) and np.all(mean <= hi) and np.all(hi - lo > 0)
+    # layer 0 sees the same inputs under both models: its predictive mean is the closed form's
+    np.testing.assert_allclose(mean[:, 0], mean_cf[:, 0], atol=5.0 * float(np.sqrt(var_cf[:, 0] / S).max()))
+
 
 @pytest.mark.parametrize("streams,n", [(3, 8192), (4, 4096)])
 def test_concurrent_factorisations_complete_their_handoffs(hip, streams, n):

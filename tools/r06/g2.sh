@@ -1,0 +1,8 @@
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r6b; mkdir -p $O
+for n in 400 2048; do
+  rocprofv3 --kernel-trace --stats -f csv -d $O/kt_$n -o kt -- python tools/r06/one_fit.py $n 1 1 2 > $O/kt_$n.log 2>&1
+  python tools/kernel_table.py $O/kt_$n "one_fit $n 1" > $O/kstats_$n.txt 2>&1
+  rm -rf $O/kt_$n
+done
+head -40 $O/kstats_400.txt; head -40 $O/kstats_2048.txt
