@@ -588,9 +588,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     if (half_flags < 0) { const char* e = getenv("GPAR_GEMM_HALF_TILES_TRIANGULAR"); half_flags = e ? atoi(e) : 1; }
     const bool half = !ta && tb && ntiles * batch <= half_tiles && k >= 64 &&
                       (half_flags || !(flags & (GPAR_GEMM_A_LOWER | GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_K_TO_COL)));
-    static int lds_extra = -1;
-    if (lds_extra < 0) { const char* e = getenv("GPAR_GEMM_LDS_EXTRA"); lds_extra = e ? atoi(e) : 0; }
-    const int GEMM_LDS_REQ = GEMM_LDS_BYTES + lds_extra;   // experiment knob: > 6.2 KB extra forces one workgroup per CU
+    const int GEMM_LDS_REQ = GEMM_LDS_BYTES;   // (padding the request so that ONE workgroup fits a compute unit - a hole for a panel workgroup on every unit - changed nothing: lesson 34)
     // whole tiles, except for a last round that would be at most half full (MIXED, see the kernel): the trailing update alone
     p.nfull = ntiles; p.ntail = 0;
     static int mixed_tail = -1;

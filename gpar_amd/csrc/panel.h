@@ -48,19 +48,21 @@ constexpr unsigned PNL_SPIN_LIMIT = 1u << 22;
 //   * of SMALL launches at most two are in flight on different streams (2 x 192 / 8 = 48 < 64 slots per XCD beside one big launch):
 //     a ring of two events, a launch waits for the older entry unless its own stream made it.  An inducing-point layer's two small
 //     factorisations (K_zz on a side stream beside the bound's matrix on the caller's) alternate slots and never wait.
-// Nothing is recorded or waited for until a second stream shows up; a process with one stream pays nothing, and the updates still
-// overlap other streams' panels.  GPAR_SPIN_CHAIN=0 switches all of it off (the round-4 behaviour).
+// Every waiting launch records its end on ITS OWN stream (one hipEventRecord per panel launch, ~1 us of host time): the chain never
+// touches a stream handle it merely remembers - a caller may have destroyed it - and needs no "second stream seen" state that would
+// have to decay (round 5 recorded nothing while one stream was in use and marked the first stream's tail when a second showed up).
+// A launch on the stream that made the entry it would wait for does not wait (stream order already holds); waiting for an event
+// whose launch has long finished costs the device nothing.  GPAR_SPIN_CHAIN=0 switches all of it off (the round-4 behaviour).
+// The state is PER PROCESS (and per device): two processes sharing one GPU are ordered by nothing - there the bounded spin, the -77
+// status and the caller's unfused retry are what remains.
 constexpr int SPIN_SMALL_WGS = 192;
 struct SpinChain {
     hipEvent_t ev = nullptr;          // the last big launch
     hipEvent_t sev[2] = {nullptr, nullptr};   // the last two small launches
-    hipStream_t last = nullptr;       // stream of the last big launch
+    hipStream_t last = nullptr;       // stream of the last big launch (compared, never used)
     hipStream_t sst[2] = {nullptr, nullptr};
     bool big = false, small[2] = {false, false};   // is there such a launch
     int snext = 0;
-    hipStream_t seen = nullptr;       // the only stream seen so far (while !multi)
-    bool any = false;
-    bool multi = false;               // waiting kernels come from more than one stream: record after every launch
     bool created = false;
 };
 static SpinChain g_spin_chain[16];
@@ -86,21 +88,8 @@ static inline bool spin_chain_capturing(hipStream_t s) {
 // Callers hold the library mutex.  `enter` before the launch of `wgs` workgroups, `leave` after it.
 static int spin_chain_enter(hipStream_t s, long long wgs) {
     SpinChain& c = spin_chain();
-    if (!c.any || (!c.multi && c.seen == s) || !env_int("GPAR_SPIN_CHAIN", 1)) return 0;
+    if (!(c.big || c.small[0] || c.small[1]) || !env_int("GPAR_SPIN_CHAIN", 1)) return 0;
     if (spin_chain_capturing(s)) return 0;   // (a graph being captured is ordered by whoever replays it)
-    if (!spin_chain_init()) return -(int)hipErrorOutOfMemory;
-    if (!c.multi) {
-        // a second stream: mark the end of what the first one holds NOW (a superset of its waiting launches) as its last big and
-        // its last small launch
-        c.multi = true;
-        if (hipEventRecord(c.ev, c.seen) == hipSuccess && hipEventRecord(c.sev[0], c.seen) == hipSuccess) {
-            c.big = c.small[0] = true;
-            c.last = c.sst[0] = c.seen;
-            c.snext = 1;
-        } else {
-            GPAR_HIP_IGNORE(hipGetLastError());   // (stream gone: so is its work)
-        }
-    }
     if (wgs > SPIN_SMALL_WGS) {
         if (c.big && c.last != s) GPAR_HIP_TRY(hipStreamWaitEvent(s, c.ev, 0));
     } else {
@@ -111,15 +100,13 @@ static int spin_chain_enter(hipStream_t s, long long wgs) {
 }
 static void spin_chain_leave(hipStream_t s, long long wgs) {
     SpinChain& c = spin_chain();
-    if (!c.any) c.seen = s;
-    c.any = true;
-    if (!c.multi || !env_int("GPAR_SPIN_CHAIN", 1) || spin_chain_capturing(s) || !spin_chain_init()) return;
+    if (!env_int("GPAR_SPIN_CHAIN", 1) || spin_chain_capturing(s) || !spin_chain_init()) return;
     if (wgs > SPIN_SMALL_WGS) {
-        GPAR_HIP_IGNORE(hipEventRecord(c.ev, s));
+        if (hipEventRecord(c.ev, s) != hipSuccess) { GPAR_HIP_IGNORE(hipGetLastError()); return; }
         c.last = s;
         c.big = true;
     } else {
-        GPAR_HIP_IGNORE(hipEventRecord(c.sev[c.snext], s));
+        if (hipEventRecord(c.sev[c.snext], s) != hipSuccess) { GPAR_HIP_IGNORE(hipGetLastError()); return; }
         c.sst[c.snext] = s;
         c.small[c.snext] = true;
         c.snext ^= 1;

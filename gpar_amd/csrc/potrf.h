@@ -506,14 +506,8 @@ static int trsm_block_back_fused2(const double* L, int n, int ldl, double* B, in
 static inline int potrf_panel_any(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed,
                                   int batch = 1, long long batch_a = 0) {
     if (env_int("GPAR_PANEL_V", 2) >= 2) {
-        // Experiment knob (default off): with at least this many rows left the panel is split into a chain-only launch (the W / 64
-        // team workgroups factor the diagonal block) and the fused triangular-solve block kernel for the rows below.
-        const int split_rows = batch == 1 ? env_int("GPAR_POTRF_PANEL_SPLIT_ROWS", 1 << 30) : (1 << 30);
-        if (N - k0 >= split_rows && N - k0 > W) {
-            int rc = potrf_panel_fused2(A, k0 + W, lda, k0, W, logdet, info, stream, prezeroed, 1, 0);
-            if (rc) return rc;
-            return trsm_block_fused2(A + (size_t)k0 * lda + k0, W, lda, A + (size_t)(k0 + W) * lda + k0, N - k0 - W, lda, 0, W / 64, 0, stream);
-        }
+        // (a chain-only launch followed by the solve block kernel for the rows below - GPAR_POTRF_PANEL_SPLIT_ROWS, round 2 - was
+        // slower at every size and is retired: NOTES.md section 7, lesson 34)
         return potrf_panel_fused2(A, N, lda, k0, W, logdet, info, stream, prezeroed, batch, batch_a);
     }
     for (int b = 0; b < batch; ++b) {   // (the first-generation kernel takes one matrix per launch)
@@ -622,6 +616,11 @@ static void prof_end(hipStream_t s, bool active, int rows, int cols, int kb) {
 static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* info, hipStream_t stream, int flags = 0, int batch = 1,
                      long long batch_a = 0) {
     if (nf > N) return GPAR_ARG_ERROR(1);
+    // The schedule below - panel widths, which steps are grouped, which are fused into one launch, the tile form of every update -
+    // is a function of the SHAPE (N, nf, lda alignment) AND OF `batch`, and of nothing else: the same bits with and without
+    // look-ahead, alone or beside other work, on any stream.  A matrix factored inside a lock-step batch takes another summation
+    // order than the same matrix alone (pair_rows, fuse2_rows and the half-tile rule of the updates all look at the batch): equal
+    // to rounding, not to the bit (tests/test_full_size_gpu.py::test_batch_geometry_changes_the_summation_order_not_the_factor).
     PotrfPolicy pol = potrf_policy(N);
     // a LONE large factorisation stops grouping earlier (from 7680 rows on the steps are single panels with look-ahead, the last 7680 rows
     // then one fused launch of fifteen panels): n = 16384 25.10 -> 24.97 ms, n = 12288 11.84 -> 11.79; a lock-step batch keeps 6144 (C3:
@@ -650,7 +649,6 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     hipStream_t side = (pol.lookahead && nf > nbo && la_init()) ? la_side(stream) : nullptr;
     const bool la = side != nullptr;
     hipEvent_t trail_done = nullptr;   // completion of the side-stream update issued in the previous step
-    hipEvent_t mid_done = nullptr;     // completion of the side-stream update of the current group's 2nd .. last panels' columns
     // Early in the factorisation two panels are factored back to back (the second after a narrow update of its own
     // columns by the first) and the rest of the matrix then receives ONE rank-2*nbo update: the trailing update reads and
     // writes every remaining element once per 1024 columns instead of once per 512, and a K = 1024 SYRK runs ~8 % faster
@@ -664,11 +662,8 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         return G > 1 && k > 0 && pol.fused && nbo % 64 == 0 && k + G * nbo <= nf && (N - k) >= pol.pair_rows && (k % 2 == 0) && (lda % 2 == 0) &&
                gpar_aligned16(A);
     };
-    // Experiment knob, off: the last `tail` columns through ONE panel kernel (up to 16 column blocks).  Measured slower with the
-    // left-looking kernel too - n = 1024 as one 16-block panel 0.43 ms against 0.33 ms as two panels + a tiny update, C4
-    // 18.1 -> 19.7 ms: a team row's products for column block c (c chunks of 0.55 us) run while row c factors its
-    // diagonal tile (5 us), and from c ~ 10 on they outlast it and join the chain.
-    const int tail = pol.fused ? env_int("GPAR_POTRF_TAIL", 0) : 0;
+    // (The last columns through ONE panel kernel of up to 16 column blocks - GPAR_POTRF_TAIL, round 3 - measured slower: n = 1024 0.43
+    // against 0.33 ms, C4 18.1 -> 19.7 ms; retired in round 6.)
     // Two or more panels in ONE launch (potrf_group_kernel, panel2.h; at most GPAR_POTRF_FUSE_MAX) once the rows that are left make a step latency-bound: at most
     // GPAR_POTRF_FUSE2_ROWS rows from the step's first column on (a lock-step batch: GPAR_POTRF_FUSE2_BATCH_ROWS over the batch - it
     // fills the chip sooner).  Measured (tools/exp_potrf_fuse2.py, profiles/r04_exp_potrf_fuse2.txt): lone n = 1024 / 2048 / 3072 /
@@ -687,7 +682,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // 1.62 ms, 8 x 2048 1.55 -> 1.36; C3 and C5 - the last 2048 / 1024 rows - unchanged; profiles/r05_exp_batch_fuse.txt).
     const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", N <= 5200 ? 5200 : (N >= 12288 ? 8300 : 4200)) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 16500) / batch;
     const bool fuse2_on = pol.fused && prezero && !(flags & GPAR_POTRF_UNFUSED) && nbo == 512 && env_int("GPAR_PANEL_V", 2) >= 2 &&
-                          env_int("GPAR_PANEL_PAIRS", 1) && (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && fuse2_rows > 0 && tail == 0;
+                          env_int("GPAR_PANEL_PAIRS", 1) && (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && fuse2_rows > 0;
     unsigned long long fuse_counted = 0;   // tiles every row block below the fused launches so far has counted (panel2.h)
     // (more than two panels per launch add little - between panels inside a launch the next team waits ~45 us for the last column
     // blocks of its own rows, which the bulk row blocks of the panel before finish behind the chain - : n = 1536 0.497 -> 0.452 ms with
@@ -703,7 +698,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
         return G >= 2 ? G : 0;
     };
     auto fusable2 = [&](int k) { return fuse_panels(k) > 0; };
-    auto panel_end = [&](int k) { return fusable2(k) ? k + fuse_panels(k) * nbo : ((nf - k <= tail || k + nbo >= nf) ? nf : k + nbo); };
+    auto panel_end = [&](int k) { return fusable2(k) ? k + fuse_panels(k) * nbo : (k + nbo >= nf ? nf : k + nbo); };
     for (int k0 = 0, knext = 0; k0 < nf; k0 = knext) {
         int kend = panel_end(k0);
         // a ragged tail (nf not a multiple of 64) becomes its own narrow panel so the wide part stays fusable
@@ -714,8 +709,6 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             for (int i = 0; i < G && !rc; ++i) {
                 const int ks = k0 + i * nbo;
                 if (i > 0) {   // this panel's columns: one update by the i panels of the group factored so far
-                    // (they must have received the previous step's update first: it runs at the head of the side stream)
-                    if (mid_done) { GPAR_HIP_TRY(hipStreamWaitEvent(stream, mid_done, 0)); mid_done = nullptr; }
                     bool pb;
                     prof_begin(stream, pb, N - ks);
                     rc = potrf_gemm_update(c, k0, ks, ks + nbo, stream, 1);
@@ -785,16 +778,12 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             continue;
         }
         // (1) next panel's columns, on the caller's stream; they were last written by the previous side update.
-        // One round-3 experiment knob is left, OFF by default because it did not pay (profiles/r03_exp_potrf_lookahead.txt; same bits):
-        //   GPAR_POTRF_LA_SPLIT=1        when the next step is a GROUP of panels, only its first panel's columns are updated ahead of
-        //                                that panel; the other panels' columns go to the head of the side stream and the in-group
-        //                                update waits for them there (n = 16384: 25.94 -> 26.12 ms, 12288: 12.74 -> 12.67, 8192: 5.29 -> 5.21)
-        // (Releasing the big update only after the look-ahead update - GPAR_POTRF_REST_AFTER_LA / GPAR_POTRF_BATCH_REST_AFTER_LA -
-        // and factoring the very first panel inside a group - GPAR_POTRF_PAIR_FIRST - were measured negative in rounds 3 and 4 and
-        // retired in round 5: NOTES.md section 7.)
+        // (Measured negative and retired - NOTES.md section 7 and R5.11: updating only the first panel's columns of a following GROUP
+        // ahead of it, GPAR_POTRF_LA_SPLIT (n = 16384 25.94 -> 26.12 ms, C3 180.5 -> 182.0); releasing the big update only after the
+        // look-ahead update, GPAR_POTRF_REST_AFTER_LA / GPAR_POTRF_BATCH_REST_AFTER_LA; factoring the very first panel inside a group,
+        // GPAR_POTRF_PAIR_FIRST.)
         if (trail_done) GPAR_HIP_TRY(hipStreamWaitEvent(stream, trail_done, 0));
-        const bool next_grouped = next_end - kend > nbo && groupable(kend);
-        const int la_end = (next_grouped && env_int("GPAR_POTRF_LA_SPLIT", 0)) ? kend + nbo : next_end;
+        const int la_end = next_end;
         hipEvent_t panel_done = la_event();
         GPAR_HIP_TRY(hipEventRecord(panel_done, stream));
         if (potrf_la_is_small(c, k0, kend, la_end)) {
@@ -805,21 +794,8 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
             prof_end(stream, pa, N - kend, la_end - kend, (kend - k0) * batch);
         }
         if (rc) return rc;
-        // (2) everything to the right of the next panel, on the side stream: first the rest of the next group's columns ...
+        // (2) everything to the right of the next step's columns, on the side stream
         GPAR_HIP_TRY(hipStreamWaitEvent(side, panel_done, 0));
-        mid_done = nullptr;
-        if (la_end < next_end) {
-            const int rows = N - la_end, cols = next_end - la_end;
-            const double* P = A + (size_t)la_end * lda + k0;
-            prof_begin(side, pa, rows);
-            rc = gemm_launch(0, 1, rows, cols, kend - k0, -1.0, P, lda, P, lda, 1.0, A + (size_t)la_end * lda + la_end, lda,
-                             GPAR_GEMM_C_LOWER, side, 1, batch, batch_a, batch_a, batch_a);
-            prof_end(side, pa, rows, cols, (kend - k0) * batch);
-            if (rc) return rc;
-            mid_done = la_event();
-            GPAR_HIP_TRY(hipEventRecord(mid_done, side));
-        }
-        // ... then everything beyond the next step's columns
         {
             const int rows = N - next_end, cols = N - next_end;
             if (rows > 0) {

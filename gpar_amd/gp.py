@@ -932,17 +932,28 @@ class Obs:
 
 
 class _LazyV:
-    """v = L_z^-T A^-1 c of an inducing-point observation, computed at first use (on the stream of that use: a later stream-ordered
-    consumer of the factors)."""
+    """v = L_z^-T A^-1 c of an inducing-point observation, computed at first use on the stream of that use.  The producing
+    stream and an event behind the solve are kept: a later consumer on ANOTHER stream (a posterior shared between worker streams)
+    waits for that event instead of reading v unordered."""
 
     def __init__(self, eng, facA, Lz):
         self.eng, self.facA, self.Lz, self.value = eng, facA, Lz, None
+        self._stream = self._ready = None
 
     def get(self):
         if self.value is None:
             v = self.facA.alpha().clone()  # (A^-1 c)^T, 1 x M
             self.eng.trsm_rln_(self.Lz, v)
             self.value = v
+            if v.is_cuda:
+                self._stream = torch.cuda.current_stream(v.device)
+                self._ready = torch.cuda.Event()
+                self._ready.record(self._stream)
+        elif self._ready is not None:
+            here = torch.cuda.current_stream(self.value.device)
+            if here != self._stream:
+                here.wait_event(self._ready)
+                self.value.record_stream(here)
         return self.value
 
 

@@ -46,6 +46,16 @@ def _device_nan_pattern(y):
     return torch.isnan(y).cpu().numpy()
 
 
+def _attached_nan_pattern(y):
+    """The NaN pattern a caller attached to the tensor (`_host_nan`), if the tensor has not been written in place since
+    (`_host_nan_version`: the version counter it was taken at; a pattern attached without one is taken as is - test code)."""
+    pattern = getattr(y, "_host_nan", None)
+    if pattern is None:
+        return None
+    version = getattr(y, "_host_nan_version", None)
+    return pattern if version is None or version == y._version else None
+
+
 def _is_torch(a):
     return isinstance(a, torch.Tensor)
 
@@ -177,7 +187,7 @@ def per_output(y, w=None, keep=False):
         yield from y[keep]
         return
     p = y.shape[1]
-    host_nan = getattr(y, "_host_nan", None) if _is_torch(y) else None
+    host_nan = _attached_nan_pattern(y) if _is_torch(y) else None
     if host_nan is not None and host_nan.shape == tuple(y.shape):
         yield from _per_output_planned(y, w, ~host_nan, keep)
         return
@@ -361,7 +371,7 @@ class GPAR:
             # missing: 4.5 ms of GPU work in 7.1 ms).
             host_nan, y_given = None, y
             if _is_torch(y):   # (a pattern attached by the caller, or remembered on this very tensor object: see _device_nan_pattern)
-                host_nan = getattr(y, "_host_nan", None)
+                host_nan = _attached_nan_pattern(y)
                 if host_nan is None:
                     cached = getattr(y, "_gpar_nan", None)
                     if cached is not None and cached[0] == y._version and cached[1].shape == tuple(y.shape):
@@ -378,7 +388,7 @@ class GPAR:
                             y_given._gpar_nan = (y_given._version, host_nan)
                         except (AttributeError, RuntimeError):
                             pass
-                y._host_nan = host_nan if host_nan.ndim == 2 else None
+                y._host_nan, y._host_nan_version = (host_nan if host_nan.ndim == 2 else None), y._version
         return x, y, w
 
     def _prep_ind(self, x_ind):

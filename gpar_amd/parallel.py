@@ -253,7 +253,7 @@ def inputs_are_data(reg, y):
 def _tag_host_nan(reg, y_dev):
     """The NaN pattern of the (host-resident) training outputs, attached for per_output: masks planned on the host (GPAR._prep)."""
     if y_dev.is_cuda and host_masks():
-        y_dev._host_nan = torch.isnan(reg.y).numpy()
+        y_dev._host_nan, y_dev._host_nan_version = torch.isnan(reg.y).numpy(), y_dev._version
 
 
 def sharded_fit(reg, x, y, w=None, group=None, fix=True, **kw_args):

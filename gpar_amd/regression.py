@@ -200,6 +200,12 @@ class GPARRegressor:
     #: autograd, no per-evaluation model objects); False keeps the general route for every layer (tests compare the two).
     fast_fit = True
 
+    #: `logpdf` on device-resident outputs remembers their NaN pattern ON THE CALLER'S TENSOR (attribute `_gpar_nan`, with the tensor's
+    #: version counter) so that a loop over the same outputs pays the device-to-host synchronisation once.  Writes torch cannot see
+    #: - a raw-pointer kernel, another library, `.data` writes, a DLPack alias - do not move the counter: after one, `del y._gpar_nan`,
+    #: or set this attribute False (per regressor, or on the class) and the pattern is read from the device at every call.
+    nan_pattern_cache = True
+
     def __init__(self, replace=False, impute=True, scale=1.0, scale_tie=False, per=False, per_period=1.0,
                  per_scale=1.0, per_decay=10.0, input_linear=False, input_linear_scale=100.0, linear=True,
                  linear_scale=100.0, nonlinear=False, nonlinear_scale=1.0, rq=False, markov=None, noise=0.1,
@@ -291,7 +297,7 @@ class GPARRegressor:
             # host - index tensors, no synchronisation per layer and evaluation (on any engine: the CPU tests walk the same route)
             if y_dev is self.y:
                 y_dev = y_dev.view(y_dev.shape)   # (never hang the plan on the regressor's own attribute)
-            y_dev._host_nan = torch.isnan(self.y).numpy()
+            y_dev._host_nan, y_dev._host_nan_version = torch.isnan(self.y).numpy(), y_dev._version
         y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
         self._prepare_kernels(self.m, self.p, self.n, training=True, inputs=not fix or bool(optimise_x_ind))
 
@@ -404,8 +410,15 @@ class GPARRegressor:
             else:
                 for c in remaining:
                     trial(c)
-            # (ties - identical columns - go to the lower column index: the order of `remaining`)
-            best = max(remaining, key=lambda c: (results[c][0], -c))
+            # (ties - identical columns - go to the lower column index: the order of `remaining`; a trial whose optimisation ended on
+            # a failed evaluation carries NaN, which would make the comparisons order-dependent: it ranks below every finite value)
+            def rank(c):
+                value = results[c][0]
+                return (value if np.isfinite(value) else -np.inf, -c)
+
+            if not any(np.isfinite(results[c][0]) for c in remaining):
+                raise ArithmeticError(f"greedy_order: every candidate for position {k} ended on a failed evaluation")
+            best = max(remaining, key=rank)
             order.append(best)
             values.append(results[best][0])
             chain_vs = results[best][1]
@@ -438,16 +451,17 @@ class GPARRegressor:
             # tensor): their NaN pattern decides every mask of the evaluation and costs a device-to-host synchronisation, which a
             # loop over the same outputs (an optimiser, a benchmark) would pay every time.  It is kept ON THE CALLER'S TENSOR OBJECT
             # together with the version counter it was taken at - it lives and dies with that object, nothing global holds the
-            # tensor, and an in-place torch operation is seen.  (A write torch cannot see - a raw-pointer kernel - is not:
-            # `del y._gpar_nan` after one.)
-            cached = getattr(y_given, "_gpar_nan", None)
+            # tensor, and an in-place torch operation is seen.  (A write torch cannot see - a raw-pointer kernel, `.data`, a DLPack
+            # alias - is not: `del y._gpar_nan` after one, or switch the cache off with `nan_pattern_cache = False`.)
+            cached = getattr(y_given, "_gpar_nan", None) if self.nan_pattern_cache else None
             if cached is None or cached[0] != y_given._version or cached[1].shape != tuple(y.shape):
                 cached = (y_given._version, torch.isnan(y).cpu().numpy())
-                try:
-                    y_given._gpar_nan = cached
-                except (AttributeError, RuntimeError):
-                    pass
-            y._host_nan = cached[1]
+                if self.nan_pattern_cache:
+                    try:
+                        y_given._gpar_nan = cached
+                    except (AttributeError, RuntimeError):
+                        pass
+            y._host_nan, y._host_nan_version = cached[1], y._version
         w = _init_weights(w, y)
         m, p = x.shape[1], y.shape[1]
         if posterior and not self.is_conditioned:

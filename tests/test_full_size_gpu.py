@@ -299,6 +299,42 @@ def test_c4_full_size_condition_and_predict_through_the_inducing_points(hip):
     np.testing.assert_allclose(mean[:, 0], mean_cf[:, 0], atol=5.0 * float(np.sqrt(var_cf[:, 0] / S).max()))
 
 
+@pytest.mark.parametrize("N,batch", [(8193, 12), (6500, 2), (7681, 2)])
+def test_batch_geometry_changes_the_summation_order_not_the_factor(hip, N, batch):
+    """The grouping / fusing geometry of gpar_potrf is a function of (N, batch) (csrc/potrf.h: `pair_rows` 2560 for twelve or more
+    matrices of at least 8192 rows, fused launches while rows x batch <= 16500): a matrix factored inside a lock-step batch takes
+    another summation order than the same matrix alone - bit-identity holds within ONE (N, batch) geometry (with and without
+    look-ahead, alone or beside other work), not across them.  What must hold across them is the factor itself: lock-step against
+    one-at-a-time to 1e-12 of the matrix scale, at the sizes where the geometries differ most (a wide batch of large matrices; two
+    matrices of 6000-8000 rows: two successive fused launches, the second with tiles counted by the first)."""
+    from gpar_amd import hip as H
+
+    dev = hip.device
+    nf = N - 1
+    g = torch.Generator().manual_seed(N + batch)
+    pts = torch.rand(N, 3, generator=g, dtype=torch.float64).to(dev)
+    base = torch.exp(-0.5 * torch.cdist(pts, pts) ** 2 / 0.25)
+    stacked = H.alloc_matrix(batch * N, N, dev)
+    for b in range(batch):
+        blk = stacked[b * N:(b + 1) * N]
+        blk.copy_(base)
+        blk.diagonal().add_(0.05 + 0.01 * b)
+    del base
+    singles = []
+    for b in (0, batch - 1):
+        one = stacked[b * N:(b + 1) * N].clone()
+        ld, info = H.potrf_(one, nf)
+        assert int(info.item()) == 0
+        singles.append((b, one, float(ld)))
+    logdet, info = H.potrf_batch_(stacked, batch, nf)
+    assert info.cpu().tolist() == [0] * batch
+    for b, one, ld in singles:
+        blk = stacked[b * N:(b + 1) * N]
+        diff = (torch.tril(blk) - torch.tril(one)).abs().max()
+        assert float(diff) <= 1e-12 * float(torch.tril(one).abs().max()), (b, float(diff))
+        assert abs(float(logdet[b]) - ld) <= 1e-12 * abs(ld)
+
+
 @pytest.mark.parametrize("streams,n", [(3, 8192), (4, 4096)])
 def test_concurrent_factorisations_complete_their_handoffs(hip, streams, n):
     """The persistent panel kernel hands tiles between co-resident workgroups; the product runs up to three or four

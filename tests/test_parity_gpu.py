@@ -802,6 +802,8 @@ def test_one_call_objective_and_gradient_return_the_same_bits(monkeypatch, kw, n
             value.backward()
             out[mode] = (float(value), {k: v.grad.clone().numpy() for k, v in zip(reg.vs.names, reg.vs.get_vars())})
             reg2 = GPARRegressor(scale=0.5, noise=0.1, **kw)
+            reg2.fast_fit = False   # (the general route on both sides: this test compares the one-call and the two-step DEVICE routes;
+            #                          the prepared objective against the general route is tests/test_fastfit.py)
             reg2.fit(x, y, w, iters=3)
             out[mode + "fit"] = reg2.get_variables()
         monkeypatch.delenv("GPAR_ONE_CALL_GRAD_ROWS")
