@@ -333,7 +333,7 @@ def main():
         # the other BASELINE.json configurations on the same GPU, in the same run (parity-test cases, not the headline)
         del x, y, w
         try:
-            out["config_grid"] = config_grid_leg(eng, cpu=not args.no_cpu)
+            out["config_grid"] = config_grid_leg(eng, cpu=False)
         except Exception as exc:
             out["config_grid"] = {"error": f"{type(exc).__name__}: {exc}"}
         try:
@@ -344,6 +344,8 @@ def main():
             out["small_n"] = small_n_leg(eng) if not args.no_cpu else None
         except Exception as exc:
             out["small_n"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if not args.no_cpu and "error" not in out["config_grid"]:
+            config_grid_cpu_legs(out["config_grid"])   # (every GPU leg of the line has run by now)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_leg(x_np, y_np, m, p, budget_s=args.cpu_budget)
     emit()
@@ -634,14 +636,18 @@ def config_grid_leg(eng, evals=5, warmup=2, cpu=True):
             rec["predict_finite"] = bool(np.isfinite(mean).all())
             # training at this size: layer by layer, L-BFGS-B, analytic gradient (second fit of the process: the first one pays the
             # allocator's first big blocks)
+            from gpar_amd import optimise
+
             fits = []
             for rep in range(4):   # (best of three after a first fit that pays first-use costs; four host threads: +-8 % run to run)
                 trainee = GPARRegressor(**kw)
+                before = optimise.evaluation_count()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 trainee.fit(x_np, y_np, iters=20)
                 torch.cuda.synchronize()
                 fits.append(1e3 * (time.perf_counter() - t0))
+                rec["fit_evaluations"] = optimise.evaluation_count() - before
             rec["fit_20_iters_ms"] = min(fits[1:])
             rec["fit_20_iters_ms_all"] = [round(t, 1) for t in fits]
             rec["fit_finite"] = bool(all(np.all(np.isfinite(v)) for v in trainee.get_variables().values()))
@@ -656,16 +662,30 @@ def config_grid_leg(eng, evals=5, warmup=2, cpu=True):
             rec["predict_200_samples_ms"] = 1e3 * (time.perf_counter() - t0)
             rec["predict_n_star"] = 2048
             rec["predict_finite"] = bool(np.isfinite(mean).all() and np.isfinite(lo).all() and np.isfinite(hi).all())
-        if cpu:
-            try:
-                rec["cpu_baseline"] = cpu_config_leg(name, cfg, x_np, y_np, kw)
-            except Exception as exc:  # noqa: BLE001 - the GPU numbers must survive a failure of the baseline
-                rec["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
         grid[name] = rec
         del x, y, reg
         torch.cuda.empty_cache()
     grid["lone_factorisation_ms"] = lone_factorisation_leg(eng)
+    if cpu:
+        config_grid_cpu_legs(grid)
     return grid
+
+
+def config_grid_cpu_legs(grid):
+    """The torch-CPU baseline of every configuration of `grid` (after the GPU legs: see below)."""
+    if True:
+        # the CPU baselines AFTER every GPU leg: the torch-CPU operators leave an OpenMP team spinning for a while after each parallel
+        # region, and in a container with a CPU quota that team competes with the product's own host threads (fit drives up to four)
+        for name, cfg in GRID.items():
+            n, m, p = cfg["n"], cfg["m"], cfg["p"]
+            x_np, y_np = paper_synthetic() if name == "C1" else synthetic(n, m, p)
+            kw = dict(cfg["kw"], normalise_y=False)
+            if "M" in cfg:
+                kw["x_ind"] = np.random.default_rng(3).uniform(0, 1, (cfg["M"], m))
+            try:
+                grid[name]["cpu_baseline"] = cpu_config_leg(name, cfg, x_np, y_np, kw)
+            except Exception as exc:  # noqa: BLE001 - the GPU numbers must survive a failure of the baseline
+                grid[name]["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def paper_synthetic(seed=1, n=200, noise=0.1):
@@ -761,6 +781,27 @@ def cpu_config_leg(name, cfg, x_np, y_np, kw):
         extra = {"condition_ms": 1e3 * total * scale, "predict_ms": 1e3 * (total * scale + p * 100 * draw_s), "per_layer_per_sample_ms": 1e3 * draw_s,
                  "condition_predict_sample": "condition = the bound's factors (one layer x p); predict = that + p x 100 x one timed posterior "
                                              "draw of the last layer at n* = 2048 (cross-Gram, two solves against the M x M factors, n* x n* Cholesky)"}
+    if name in ("C2", "C5"):
+        # per-unit costs of the other legs on the CPU port, the last (widest) layer: one posterior draw at n* = 2048 (predict = p
+        # conditionings + p x S draws) and, for C2, one objective + autograd-gradient evaluation (fit(iters=20) = that x the number of
+        # evaluations the GPU's L-BFGS-B made: `fit_evaluations`)
+        spec, noise = specs[p - 1]
+        design = x_all[:, : m + p - 1]
+        _, _, L = tc.layer_logpdf(spec, design, y_np[:, p - 1], np.full(n, noise))
+        zz = torch.linalg.solve_triangular(L, torch.as_tensor(y_np[:, p - 1]).reshape(-1, 1), upper=False)
+        star = torch.as_tensor(np.random.default_rng(2).uniform(0, 1, (2048, m + p - 1)))
+        _, st = tc.layer_posterior_sample(spec, design, L, zz, star, np.full(2048, noise))
+        draw_s = sum(st.values())
+        S = 100 if name == "C2" else 200
+        extra = {"predict_ms": 1e3 * (total * scale + p * S * draw_s), "per_layer_per_sample_ms": 1e3 * draw_s, "predict_num_samples": S,
+                 "predict_sample": f"p conditionings (the logpdf figure) + p x {S} x one timed posterior draw of the last layer at n* = 2048"}
+        if name == "C2":
+            del L, zz
+            leaves, rebuild = tc.leaf_spec(spec)
+            leaves.append(torch.tensor(noise, dtype=torch.float64))
+            _, _, stg = tc.layer_objective_and_gradient(lambda ps: rebuild(ps[:-1]), leaves, design, y_np[:, p - 1], noise_index=-1)
+            extra["fit_evaluation_ms"] = 1e3 * (stg["forward_s"] + stg["backward_s"])
+            extra["fit_sample"] = "one objective + autograd gradient of the last layer; fit(iters=20) = this x the GPU run's evaluation count"
     return {"logpdf_ms": 1e3 * total * scale, "cores": threads, "kind": "port", **extra,
             "sample": ("every layer, full size" if scale == 1.0 else f"the last (widest) layer at full size x p = {p}"
                        + ("; inducing inputs of that layer: the given ones extended by zero columns" if "M" in cfg else "")),
@@ -769,15 +810,15 @@ def cpu_config_leg(name, cfg, x_np, y_np, kw):
 
 def small_n_leg(eng, sizes=(100, 400, 1024, 2048), m=2, p=4, iters=20):
     """The small-problem regime (where GPAR is used most: tens to a few thousand observations): logpdf and fit(iters=20) on the
-    GPU and with the torch-CPU port, same data and initial hyper-parameters (C2's model: linear output dependence)."""
+    GPU and with the torch-CPU port, same data and initial hyper-parameters (C2's model: linear output dependence).  Every GPU leg
+    first, then the CPU legs (their OpenMP teams keep spinning after a parallel region and would compete with fit's host threads)."""
     import torch
 
     from gpar_amd.regression import GPARRegressor
     from oracle import torch_cpu as tc
 
     kw = dict(scale=0.5, linear=True, nonlinear=False, noise=0.1, normalise_y=False)
-    rows = []
-    threads = tc.set_threads()
+    gpu = {}
     for n in sizes:
         x_np, y_np = synthetic(n, m, p)
         x, y = eng.tensor(x_np), eng.tensor(y_np)
@@ -792,14 +833,19 @@ def small_n_leg(eng, sizes=(100, 400, 1024, 2048), m=2, p=4, iters=20):
             torch.cuda.synchronize()
             times.append(1e3 * (time.perf_counter() - t0))
         fits = []
-        for _ in range(3):   # (best of the second and third fit of a size: the first pays first-use costs)
+        for _ in range(4):   # (best of the second to fourth fit of a size: the first pays first-use costs)
             trainee = GPARRegressor(**kw)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             trainee.fit(x_np, y_np, iters=iters)
             torch.cuda.synchronize()
             fits.append(1e3 * (time.perf_counter() - t0))
-        fit_ms = min(fits[1:])
+        gpu[n] = (min(times), min(fits[1:]), [round(t, 1) for t in fits])
+        del x, y
+    rows = []
+    threads = tc.set_threads()
+    for n in sizes:
+        x_np, y_np = synthetic(n, m, p)
         specs = layer_specs(kw, m, p)
         x_all = torch.as_tensor(np.concatenate([x_np, y_np], axis=1))
         cpu_logpdf = 0.0
@@ -814,11 +860,10 @@ def small_n_leg(eng, sizes=(100, 400, 1024, 2048), m=2, p=4, iters=20):
             cpu_fit += seconds
             cpu_evals += evals
         cpu_scale = 1.0 if n <= 400 else float(p)
-        rows.append({"n": n, "m": m, "p": p, "gpu_logpdf_ms": min(times), "cpu_logpdf_ms": 1e3 * cpu_logpdf,
-                     "gpu_fit_ms": fit_ms, "cpu_fit_ms": 1e3 * cpu_fit * cpu_scale,
+        rows.append({"n": n, "m": m, "p": p, "gpu_logpdf_ms": gpu[n][0], "cpu_logpdf_ms": 1e3 * cpu_logpdf,
+                     "gpu_fit_ms": gpu[n][1], "gpu_fit_ms_all": gpu[n][2], "cpu_fit_ms": 1e3 * cpu_fit * cpu_scale,
                      "cpu_fit_sample": "every layer" if cpu_scale == 1.0 else f"the last layer x p = {p}",
                      "cpu_fit_evaluations": int(cpu_evals * cpu_scale)})
-        del x, y
     return {"rows": rows, "cpu_cores": threads, "fit_iters": iters,
             "model": "m = 2, p = 4, linear output dependence (C2's model), complete data, normalise_y=False",
             "cpu_kind": "port: torch-CPU fp64 operators with autograd gradients, scipy L-BFGS-B over log-parameters (oracle/torch_cpu.py)"}

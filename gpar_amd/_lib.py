@@ -24,7 +24,7 @@ POTRF_UNFUSED = 2
 WS_GEMM_SPLITK, WS_GEMV_T, WS_GRAM_GRAD, WS_CHOL_INVERSE, WS_INPUT_GRAD = 1, 2, 3, 4, 5
 GRAD_NACC = GPAR_MAX_TERMS + GPAR_MAX_FACTORS + 2 * GPAR_MAX_DIMS
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 LIB_NAME = "libgpar_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -124,6 +124,11 @@ SIGNATURES = {
         _c_int,
         [ctypes.POINTER(FSpec), ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, ctypes.c_long, _ptr, _c_dbl, _ptr, _ptr, _c_int, _ptr, _c_int,
          _ptr, _c_int, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _ptr],
+    ),
+    "gpar_logpdf_dense_grad_finish": (
+        _c_int,
+        [ctypes.POINTER(FSpec), ctypes.POINTER(KSpec), _ptr, _c_int, _c_int, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _ptr, _c_int,
+         _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr],
     ),
     "gpar_logpdf_dense_build": (
         _c_int,

@@ -762,29 +762,18 @@ int gpar_gram_grad_cross(const gpar_kspec_t* ks, const double* z1, const double*
     return gram_grad_launch(ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2, dz, W, ldw, mode, workspace, nblocks, out, stream);
 }
 
-int gpar_logpdf_dense_grad(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, const double* y, long incy,
-                           const double* noise_diag, double jitter, double* z, double* zd, int ldz, double* A, int lda, double* X, int ldxw,
-                           double* W, int ldw, double* alpha, double* workspace, int nblocks, double* out, double* half_diag, int* info,
-                           int potrf_flags, void* stream) {
-    GPAR_API_GUARD;
-    if (!fs || !ks || !x || !y || !z || !A || !X || !W || !alpha || !workspace || !out || !half_diag || !info || n <= 0 || nblocks <= 0)
-        return GPAR_ARG_ERROR(1);
+// Everything of gpar_logpdf_dense_grad behind the factorisation: value, K^-1 from L, alpha^T = (L^-1 y)^T L^-1, W = alpha alpha^T - K^-1,
+// the fused weighted-sum pass, 1/2 diag W.  `logdet`: the word the factorisation left (out + 1 itself in the one-call form).
+static int logpdf_grad_finish_run(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, double* z, double* zd,
+                                  int ldz, double* A, int lda, const double* logdet, double* X, int ldxw, double* W, int ldw, double* alpha,
+                                  double* workspace, int nblocks, double* out, double* half_diag, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    // ---- value: what gpar_logpdf_dense does
-    int rc = featurize_launch(fs, x, n, ldx, z, ldz, st);
-    if (!rc && zd && fs->dz > 0) {
+    if (zd && fs->dz > 0) {
         const long total = (long)n * fs->dz;
         hipLaunchKernelGGL(featurize_dfreq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *fs, x, n, ldx, zd, ldz);
     }
-    if (!rc) rc = gram_launch(ks, z, n, ldz, z, n, ldz, fs->dz, A, lda, GPAR_GRAM_LOWER, noise_diag, jitter, nullptr, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(logpdf_prepare_kernel, dim3(gpar_ceil_div(n + 1, 256)), dim3(256), 0, st, y, incy, n, A, lda, out + 1, info);
-    rc = potrf_run(A, n + 1, n, lda, out + 1, info, st, potrf_flags);
-    if (rc) return rc;
-    hipLaunchKernelGGL(logpdf_value_kernel, dim3(1), dim3(1), 0, st, (const double*)A, lda, n, (double)n * 1.8378770664093453,
-                       (const double*)(out + 1), out);
-    // ---- gradient ingredients: K^-1 from L, alpha^T = (L^-1 y)^T L^-1, W = alpha alpha^T - K^-1, the fused weighted-sum pass
-    rc = chol_inverse_run(A, n, lda, X, ldxw, W, ldw, st);
+    hipLaunchKernelGGL(logpdf_value_kernel, dim3(1), dim3(1), 0, st, (const double*)A, lda, n, (double)n * 1.8378770664093453, logdet, out);
+    int rc = chol_inverse_run(A, n, lda, X, ldxw, W, ldw, st);
     if (rc) return rc;
     hipLaunchKernelGGL(copy_row_kernel, dim3(gpar_ceil_div(n, 256)), dim3(256), 0, st, (const double*)(A + (size_t)n * lda), alpha, n);
     rc = trsm_rln_run(A, n, lda, alpha, 1, n, st);
@@ -794,6 +783,37 @@ int gpar_logpdf_dense_grad(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const
     hipLaunchKernelGGL(half_diag_kernel, dim3(gpar_ceil_div(n, 256)), dim3(256), 0, st, (const double*)W, ldw, n, half_diag);
     GPAR_LAUNCH_CHECK();
     return 0;
+}
+
+int gpar_logpdf_dense_grad(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, const double* y, long incy,
+                           const double* noise_diag, double jitter, double* z, double* zd, int ldz, double* A, int lda, double* X, int ldxw,
+                           double* W, int ldw, double* alpha, double* workspace, int nblocks, double* out, double* half_diag, int* info,
+                           int potrf_flags, void* stream) {
+    GPAR_API_GUARD;
+    if (!fs || !ks || !x || !y || !z || !A || !X || !W || !alpha || !workspace || !out || !half_diag || !info || n <= 0 || nblocks <= 0)
+        return GPAR_ARG_ERROR(1);
+    hipStream_t st = (hipStream_t)stream;
+    // ---- value: what gpar_logpdf_dense does (features, Gram, observations, the augmented factorisation)
+    int rc = featurize_launch(fs, x, n, ldx, z, ldz, st);
+    if (!rc) rc = gram_launch(ks, z, n, ldz, z, n, ldz, fs->dz, A, lda, GPAR_GRAM_LOWER, noise_diag, jitter, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(logpdf_prepare_kernel, dim3(gpar_ceil_div(n + 1, 256)), dim3(256), 0, st, y, incy, n, A, lda, out + 1, info);
+    rc = potrf_run(A, n + 1, n, lda, out + 1, info, st, potrf_flags);
+    if (rc) return rc;
+    // ---- value and gradient ingredients from the factor
+    return logpdf_grad_finish_run(fs, ks, x, n, ldx, z, zd, ldz, A, lda, out + 1, X, ldxw, W, ldw, alpha, workspace, nblocks, out, half_diag, stream);
+}
+
+int gpar_logpdf_dense_grad_finish(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, double* z, double* zd,
+                                  int ldz, double* A, int lda, const double* logdet, const int* info, double* X, int ldxw, double* W, int ldw,
+                                  double* alpha, double* workspace, int nblocks, double* out, double* half_diag, int* info_out, void* stream) {
+    GPAR_API_GUARD;
+    if (!fs || !ks || !x || !z || !A || !logdet || !X || !W || !alpha || !workspace || !out || !half_diag || n <= 0 || nblocks <= 0)
+        return GPAR_ARG_ERROR(1);
+    hipStream_t st = (hipStream_t)stream;
+    GPAR_HIP_TRY(hipMemcpyAsync(out + 1, logdet, sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (info && info_out) GPAR_HIP_TRY(hipMemcpyAsync(info_out, info, sizeof(int), hipMemcpyDeviceToDevice, st));
+    return logpdf_grad_finish_run(fs, ks, x, n, ldx, z, zd, ldz, A, lda, logdet, X, ldxw, W, ldw, alpha, workspace, nblocks, out, half_diag, stream);
 }
 
 int gpar_gram_input_grad(const gpar_kspec_t* ks, const double* z1, int n1, int ldz1, const double* z2, int n2, int ldz2, int dz,

@@ -23,6 +23,8 @@ the unfused retry (`model._retry_unfused`).
 """
 import ctypes
 import logging
+import os
+import threading
 
 import numpy as np
 import scipy.optimize
@@ -31,7 +33,7 @@ import torch
 from . import _lib, hip, optimise
 from .kernels import Kernel, compile_kernel
 
-__all__ = ["build", "DenseLayerObjective"]
+__all__ = ["build", "DenseLayerObjective", "LockstepFactor", "lockstep_rows"]
 
 log = logging.getLogger(__name__)
 
@@ -114,13 +116,157 @@ def _slots(kernel):
     return out
 
 
+def lockstep_rows():
+    """(min, max) rows between which concurrently trained layers factor their matrices TOGETHER (LockstepFactor).  Measured
+    (profiles/r06_lockstep_fit.txt; fit(iters=20), four layers, rendezvous off -> on): n = 1024 37 -> 38 ms, 1536 52 -> 68, 2048
+    61 -> 71, 3072 121 -> 119, 4096 220 -> 210: a round costs every lane the slowest lane's evaluation plus two thread hand-offs, and
+    below ~3000 rows that is more than the queueing of the lone factorisations behind one another costs - so the default starts
+    at 3072 rows; above `gp.one_call_grad_rows()` the prepared objective does not apply.  GPAR_FIT_LOCKSTEP_ROWS=lo[:hi] overrides
+    (0 = never)."""
+    from .gp import one_call_grad_rows
+
+    env = os.environ.get("GPAR_FIT_LOCKSTEP_ROWS")
+    lo, hi = 3072, one_call_grad_rows()
+    if env is not None:
+        parts = env.split(":")
+        lo = int(parts[0])
+        if lo <= 0:
+            return (1, 0)
+        if len(parts) > 1:
+            hi = min(hi, int(parts[1]))
+    return lo, hi
+
+
+class LockstepFactor:
+    """The lock-step training rendezvous: the layers `fit(fix=True)` trains independently of one another (reference
+    gpar/regression.py:418-446 runs their optimisations one after the other) evaluate their objectives in ROUNDS, and the
+    factorisations of a round are ONE gpar_potrf_batch.
+
+    Why: from ~1000 rows on a factorisation is one launch of hundreds of workgroups that wait for one another, and such launches
+    of different streams must not be in flight together (csrc/panel.h: the spin chain) - four training threads queue their
+    factorisations one behind the other (n = 4096: 4 x 1.2 ms per round of evaluations), while the same four matrices factored
+    in lock-step take 2.7 ms.  Everything else of an evaluation (Gram build before, inverse / weights / gradient pass after) stays
+    on the member's own stream and overlaps with the other members'.  What it costs: the lanes now move in step - a round lasts as
+    long as its slowest evaluation plus two thread hand-offs - where free-running lanes hide one lane's factorisation under the
+    others' inverses; it pays from ~3000 rows (`lockstep_rows`).
+
+    Protocol (deterministic: the composition of a round depends on the members' evaluation counts, never on timing).  Every lane
+    (host thread + stream) owns one slot of a shared (lanes (n + 1)) x (n + 1) buffer.  Per evaluation a lane enqueues its build into
+    its slot, records an event and ARRIVES; when every active lane has arrived, the last one makes its stream wait for the others'
+    events, enqueues gpar_potrf_batch over each run of consecutive arrived slots, records an event behind it and wakes the others,
+    which make their streams wait for that event and go on with gpar_logpdf_dense_grad_finish.  A lane LEAVES when its last layer is
+    trained (or when it falls back to the general route for good); leaving may complete a round the others were waiting for.
+    The factor of a matrix inside a batch of k equals the factor of the matrix alone to rounding, not to the bit (csrc/potrf.h: the
+    schedule is a function of the shape AND the batch), so a concurrently trained model equals the serially trained one to the
+    optimiser's amplification of that (1e-8 .. 1e-6 relative after 20 iterations), not bit for bit."""
+
+    def __init__(self, eng, n, lanes):
+        self.n, self.lanes = int(n), int(lanes)
+        self.cond = threading.Condition()
+        self.active = set(range(self.lanes))
+        self.arrived = {}          # lane -> event behind its build
+        self.generation = 0
+        self.done = None           # event behind the batch of the generation that completed last
+        self.error = None
+        self.rounds = 0
+        self.batches = 0
+        self.history = []          # (lanes of the round), for tests: the composition of every round
+        self._allocate(eng)
+
+    # ---- the device side (replaced by the CPU tests of the protocol: tests/test_fastfit.py) -----------------------------------
+    def _allocate(self, eng):
+        dev = eng.device
+        self.lib = _lib.load()
+        self.A = hip.alloc_matrix(self.lanes * (self.n + 1), self.n + 1, dev)
+        self.lda = hip._ld(self.A)
+        self.stride = (self.n + 1) * self.lda            # elements between consecutive slots
+        self.logdet = torch.zeros(self.lanes, dtype=torch.float64, device=dev)
+        self.info = torch.zeros(self.lanes, dtype=torch.int32, device=dev)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.A.device)
+
+    def _record(self, stream):
+        event = torch.cuda.Event()
+        event.record(stream)
+        return event
+
+    def _wait(self, stream, event):
+        stream.wait_event(event)
+
+    def _potrf(self, stream, first, count):
+        a, ld, info = self.slot(first)
+        rc = self.lib.gpar_potrf_batch(a, count, self.stride, self.n + 1, self.n, self.lda, ld, info, 0, stream.cuda_stream)
+        _lib.check(rc, "gpar_potrf_batch")
+
+    # pointers of a lane's slot
+    def slot(self, lane):
+        return (self.A.data_ptr() + 8 * lane * self.stride, self.logdet.data_ptr() + 8 * lane, self.info.data_ptr() + 4 * lane)
+
+    # ---- the protocol --------------------------------------------------------------------------------------------------------
+    def _launch(self):
+        """(lock held, every active lane has arrived) one gpar_potrf_batch per run of consecutive slots, on the caller's stream."""
+        lanes = sorted(self.arrived)
+        try:
+            stream = self._stream()
+            for lane in lanes:
+                self._wait(stream, self.arrived[lane])
+            i = 0
+            while i < len(lanes):
+                j = i
+                while j + 1 < len(lanes) and lanes[j + 1] == lanes[j] + 1:
+                    j += 1
+                self._potrf(stream, lanes[i], j - i + 1)
+                self.batches += 1
+                i = j + 1
+            self.done = self._record(stream)
+        except BaseException as exc:  # noqa: BLE001 - every waiting lane must hear of it
+            self.error = exc
+        self.history.append(tuple(lanes))
+        self.arrived = {}
+        self.generation += 1
+        self.rounds += 1
+        self.cond.notify_all()
+
+    def factor(self, lane):
+        """The lane's build is enqueued on the current stream: factor its slot with the round; on return the current stream is
+        ordered behind the factorisation."""
+        stream = self._stream()
+        mine = self._record(stream)
+        with self.cond:
+            if lane not in self.active:
+                raise RuntimeError("lane is not a member of the rendezvous")
+            self.arrived[lane] = mine
+            gen = self.generation
+            if set(self.arrived) >= self.active:
+                self._launch()
+            else:
+                while self.generation == gen:
+                    self.cond.wait()
+            if self.error is not None:
+                raise self.error
+            done = self.done
+        self._wait(stream, done)
+
+    def leave(self, lane):
+        """The lane takes no further part (idempotent)."""
+        with self.cond:
+            if lane not in self.active:
+                return
+            self.active.discard(lane)
+            self.arrived.pop(lane, None)
+            if self.active and set(self.arrived) >= self.active:
+                self._launch()
+
+
 class DenseLayerObjective:
     """-log N(y; 0, K_theta(X) + noise / w + eps I) of layer `pi` and its gradient with respect to the latent (unconstrained)
     variables `names` of `vs`, evaluated as described in the module docstring.  X (n x width), y, w (n) are device tensors that do
     not change during the optimisation."""
 
-    def __init__(self, eng, vs, names, kernel, noise_holder, holders, X, y, w, general_fg=None):
+    def __init__(self, eng, vs, names, kernel, noise_holder, holders, X, y, w, general_fg=None, group=None, lane=None):
         self.eng, self.vs, self.names = eng, vs, list(names)
+        self.group, self.lane = group, lane   # a LockstepFactor and this objective's slot in it, or None
         self.kernel, self.noise, self.holders = kernel, noise_holder, holders
         self.general_fg = general_fg
         self.X = X if X.stride(-1) == 1 else X.contiguous()
@@ -153,7 +299,9 @@ class DenseLayerObjective:
         dz = max(ck.dz, 1)
         self.z = hip.alloc_matrix(n, dz, dev)
         self.zd = hip.alloc_matrix(n, dz, dev, zero=True) if self.periodic else None
-        self.A = hip.alloc_matrix(n + 1, n + 1, dev)
+        if self.group is not None and self.group.n != n:
+            raise ValueError("the rendezvous was made for another number of rows")
+        self.A = hip.alloc_matrix(n + 1, n + 1, dev) if self.group is None else None   # (a member's factor lives in its slot of the group's buffer)
         self.Xw = hip.alloc_matrix(n, n, dev)
         self.W = hip.alloc_matrix(n, n, dev)
         nt = (n + 63) // 64
@@ -170,7 +318,8 @@ class DenseLayerObjective:
         self.flags = 0
         self._ptrs = dict(
             x=self.X.data_ptr(), ldx=hip._ld(self.X), y=self.y.data_ptr(), incy=int(self.y.stride(0)), noise=self.noise_vec.data_ptr(),
-            z=self.z.data_ptr(), zd=None if self.zd is None else self.zd.data_ptr(), ldz=hip._ld(self.z), A=self.A.data_ptr(), lda=hip._ld(self.A),
+            z=self.z.data_ptr(), zd=None if self.zd is None else self.zd.data_ptr(), ldz=hip._ld(self.z),
+            A=None if self.A is None else self.A.data_ptr(), lda=None if self.A is None else hip._ld(self.A),
             X=self.Xw.data_ptr(), ldxw=hip._ld(self.Xw), W=self.W.data_ptr(), ldw=hip._ld(self.W),
             alpha=self.work[self.nblocks * nacc:].data_ptr(), work=self.work.data_ptr(), out=self.res.data_ptr(),
             half=self.res[2 + nacc:].data_ptr(), info=self.res[2 + nacc + n:].data_ptr(),
@@ -187,11 +336,25 @@ class DenseLayerObjective:
             # the correctly rounded quotient of two tensors, as model.GPAR._noise_over forms it
             torch.true_divide(self.noise_num.fill_(noise), self.w, out=self.noise_vec)
         p = self._ptrs
-        rc = self.lib.gpar_logpdf_dense_grad(
-            ctypes.byref(ck.fspec), ctypes.byref(ck.kspec), p["x"], self.n, p["ldx"], p["y"], p["incy"], p["noise"], float(self.eng.epsilon),
-            p["z"], p["zd"], p["ldz"], p["A"], p["lda"], p["X"], p["ldxw"], p["W"], p["ldw"], p["alpha"], p["work"], self.nblocks, p["out"],
-            p["half"], p["info"], self.flags, stream.cuda_stream)
-        _lib.check(rc, "gpar_logpdf_dense_grad")
+        if self.group is None:
+            rc = self.lib.gpar_logpdf_dense_grad(
+                ctypes.byref(ck.fspec), ctypes.byref(ck.kspec), p["x"], self.n, p["ldx"], p["y"], p["incy"], p["noise"], float(self.eng.epsilon),
+                p["z"], p["zd"], p["ldz"], p["A"], p["lda"], p["X"], p["ldxw"], p["W"], p["ldw"], p["alpha"], p["work"], self.nblocks, p["out"],
+                p["half"], p["info"], self.flags, stream.cuda_stream)
+            _lib.check(rc, "gpar_logpdf_dense_grad")
+        else:
+            # build into this lane's slot, factor with the round, finish on this stream (LockstepFactor)
+            g = self.group
+            a, ld, info = g.slot(self.lane)
+            rc = self.lib.gpar_logpdf_dense_build(
+                ctypes.byref(ck.fspec), ctypes.byref(ck.kspec), p["x"], self.n, p["ldx"], p["y"], p["incy"], p["noise"], float(self.eng.epsilon),
+                p["z"], p["ldz"], a, g.lda, ld, info, stream.cuda_stream)
+            _lib.check(rc, "gpar_logpdf_dense_build")
+            g.factor(self.lane)
+            rc = self.lib.gpar_logpdf_dense_grad_finish(
+                ctypes.byref(ck.fspec), ctypes.byref(ck.kspec), p["x"], self.n, p["ldx"], p["z"], p["zd"], p["ldz"], a, g.lda, ld, info,
+                p["X"], p["ldxw"], p["W"], p["ldw"], p["alpha"], p["work"], self.nblocks, p["out"], p["half"], p["info"], stream.cuda_stream)
+            _lib.check(rc, "gpar_logpdf_dense_grad_finish")
         self.res_host.copy_(self.res, non_blocking=True)
         stream.synchronize()
         if int(self.info_np[0]) != 0:
@@ -276,7 +439,7 @@ class DenseLayerObjective:
         return val
 
 
-def build(reg, eng, vs, pi, names, fixed_x, item, general_fg=None, cls=None):
+def build(reg, eng, vs, pi, names, fixed_x, item, general_fg=None, cls=None, group=None, lane=None):
     """The fast objective of layer `pi` of regressor `reg` with fixed design matrix `fixed_x`, or None when this route does not
     apply.  `item` = (y_i, w_i, mask) as `model.per_output` yields it for output pi; `names` the variable names being optimised."""
     from .gp import one_call_grad_rows
@@ -314,4 +477,7 @@ def build(reg, eng, vs, pi, names, fixed_x, item, general_fg=None, cls=None):
     names = vs.match(names)   # (globs; resolved now that the layer's variables exist)
     if not names:
         return None
-    return cls(eng, vs, names, kernel, noise, tracer.holders, X, yi, wi.reshape(-1), general_fg=general_fg)
+    if group is not None and (group.n != n or not on_device):
+        group = None
+    return cls(eng, vs, names, kernel, noise, tracer.holders, X, yi, wi.reshape(-1), general_fg=general_fg, group=group,
+               lane=lane if group is not None else None)

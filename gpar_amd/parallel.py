@@ -303,8 +303,9 @@ def sharded_fit(reg, x, y, w=None, group=None, fix=True, **kw_args):
 
             _minimise_sharded(local_objective, reg.vs, [f"{i}/*" for i in range(pi + 1)], group, **kw_args)
         return "joint-sharded"
-    for pi in fixed:
-        minimise_l_bfgs_b(lambda vs, pi=pi: term(vs, pi), reg.vs, names=[f"{pi}/*"], **kw_args)
+    # this rank's layers through the regressor's own layer-wise training: the prepared objective (gpar_amd/fastfit.py) and the
+    # worker streams where they apply, the general route otherwise - what the single-process `fit` runs for the same layers
+    reg._train(sorted(fixed), fix=True, **kw_args)
     if size > 1:
         for pi in range(reg.p):
             names = reg.vs.match([f"{pi}/*"])

@@ -163,25 +163,30 @@ def _init_weights(w, y, attribute=False):
     return _uprank(_to_torch(w))
 
 
-def _run_on_streams(eng, streams, shares, fn):
-    """fn(item) for every item of shares[k] on stream k, one host thread per stream; exceptions re-raised here."""
+def _run_on_streams(eng, streams, shares, fn, on_exit=None):
+    """fn(item) for every item of shares[k] on stream k, one host thread per stream; exceptions re-raised here.  `on_exit(k)`: called
+    by thread k when it is done with its share, whatever happened (a lane of a lock-step rendezvous leaves it there)."""
     import threading
 
     main = torch.cuda.current_stream(eng.device)
     errors = []
 
-    def work(stream, items):
+    def work(k, stream, items):
         try:
             with torch.cuda.device(eng.device), torch.cuda.stream(stream):
-                for item in items:
-                    fn(item)
+                try:
+                    for item in items:
+                        fn(item)
+                finally:
+                    if on_exit is not None:
+                        on_exit(k)
         except BaseException as exc:  # noqa: BLE001 - handed to the caller's thread
             errors.append(exc)
 
     threads = []
-    for stream, items in zip(streams, shares):
+    for k, (stream, items) in enumerate(zip(streams, shares)):
         stream.wait_stream(main)
-        threads.append(threading.Thread(target=work, args=(stream, items), daemon=True))
+        threads.append(threading.Thread(target=work, args=(k, stream, items), daemon=True))
     for t in threads:
         t.start()
     for t in threads:
@@ -301,7 +306,7 @@ class GPARRegressor:
         y_cached = {k: list(per_output(y_dev, w_dev, keep=k)) for k in [True, False]}
         self._prepare_kernels(self.m, self.p, self.n, training=True, inputs=not fix or bool(optimise_x_ind))
 
-        def train_layer(pi):
+        def train_layer(pi, group=None, lane=None):
             if fix:
                 gpar = _construct_gpar(self, self.vs, self.m, pi + 1)
                 fixed_x, fixed_x_ind = gpar.logpdf(
@@ -334,7 +339,10 @@ class GPARRegressor:
                         general.append(objective_and_gradient(objective, self.vs, names, trace=kw_args.get("trace", False))[0])
                     return general[0](x)
 
-                fast = fastfit.build(self, eng, self.vs, pi, names, fixed_x, y_cached[bool(self.impute)][pi], general_fg=general_fg)
+                fast = fastfit.build(self, eng, self.vs, pi, names, fixed_x, y_cached[bool(self.impute)][pi], general_fg=general_fg,
+                                     group=group, lane=lane)
+            if group is not None and (fast is None or fast.group is None):
+                group.leave(lane)   # (this lane trains through the general route from here on: the others must not wait for it)
             if fast is not None:
                 finals[pi] = fast.minimise(**kw_args)
             else:
@@ -344,11 +352,12 @@ class GPARRegressor:
 
         from .parallel import layers_train_independently
 
-        depth = None
-        if fix and not optimise_x_ind and self.fast_fit and not self.sparse and os.environ.get("GPAR_FIT_THREADS") is None:
+        depth, prepared = None, False
+        if fix and not optimise_x_ind and self.fast_fit and not self.sparse:
             from .gp import one_call_grad_rows
 
-            if 0 < self.n <= one_call_grad_rows():
+            prepared = 0 < self.n <= one_call_grad_rows()   # every layer goes through the prepared objective (fastfit.py)
+            if prepared and os.environ.get("GPAR_FIT_THREADS") is None:
                 # the prepared objective leaves ~0.1 ms of interpreter time per evaluation: four drivers no longer contend for it
                 # (fit(iters=20), four layers, 2 -> 4 threads: n = 100 21 -> 15 ms, 400 35 -> 29, 1024 43 -> 30; profiles/r06_small_fit.txt)
                 depth = 4
@@ -360,7 +369,23 @@ class GPARRegressor:
             # is the serial one: every evaluation is the same deterministic device computation.
             with torch.no_grad():  # lazily created variables must all exist before the store is shared between threads
                 _construct_gpar(self, self.vs, self.m, self.p).logpdf(x_dev[:2], y_dev[:2], w_dev[:2])
-            _run_on_streams(eng, streams, [layers[k::len(streams)] for k in range(len(streams))], train_layer)
+            lanes = min(len(streams), len(layers))
+            shares = [layers[k::lanes] for k in range(lanes)]
+            group = None
+            if prepared and lanes > 1 and all(isinstance(item[2], slice) for item in y_cached[bool(self.impute)]):
+                # every layer goes through the prepared objective on the same number of rows: from ~1000 rows on their
+                # factorisations are taken in lock-step, one gpar_potrf_batch per round of evaluations (fastfit.LockstepFactor)
+                from . import fastfit
+
+                lo, hi = fastfit.lockstep_rows()
+                if lo <= self.n <= hi and hasattr(eng, "_grads_from_moments"):
+                    group = fastfit.LockstepFactor(eng, self.n, lanes)
+            if group is None:
+                _run_on_streams(eng, streams[:lanes], shares, train_layer)
+            else:
+                tagged = [[(pi, k) for pi in share] for k, share in enumerate(shares)]
+                _run_on_streams(eng, streams[:lanes], tagged, lambda item: train_layer(item[0], group, item[1]), on_exit=group.leave)
+                self._lockstep_rounds = (group.rounds, group.batches)
         else:
             for pi in layers:
                 train_layer(pi)

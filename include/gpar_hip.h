@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define GPAR_ABI_VERSION 6
+#define GPAR_ABI_VERSION 7
 
 /* ---- kernel specification -------------------------------------------------------------------
  * A GPAR layer kernel (gpar/regression.py:92-180) is a sum of products of elementary kernels applied
@@ -200,6 +200,18 @@ int gpar_logpdf_dense_grad(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const
                            const double* noise_diag, double jitter, double* z, double* zd, int ldz, double* A, int lda, double* X, int ldxw,
                            double* W, int ldw, double* alpha, double* workspace, int nblocks, double* out, double* half_diag, int* info,
                            int potrf_flags, void* stream);
+/* The same evaluation for a factor that ALREADY EXISTS (ABI v7) - the second half of gpar_logpdf_dense_grad: the value from the corner
+ * of A and `logdet`, K^-1 from L, alpha, W, the weighted-sum pass, 1/2 diag W (gpar_featurize_dfreq first when zd is non-null).  For
+ * callers that factor several layers' matrices TOGETHER: gpar_logpdf_dense_build per layer into the slots of one buffer, ONE
+ * gpar_potrf_batch over the slots, then this call per layer on a stream of its own (the lock-step training rendezvous of
+ * gpar_amd/fastfit.py: the p independent layer optimisations of fit(fix=True), gpar/regression.py:418-446, evaluate in rounds).
+ * `logdet` / `info`: the layer's words of the batch (device); out[1] <- logdet[0], info_out[0] <- info[0] (either of the last two may
+ * be NULL), so that one device-to-host copy of `out` .. `info_out` carries everything the host reads.  A failed factorisation
+ * (info != 0) leaves garbage in out / half_diag, as gpar_logpdf_dense_grad does.
+ * [objective + gradient of one layer inside varz.minimise_l_bfgs_b, gpar/regression.py:434-459] */
+int gpar_logpdf_dense_grad_finish(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, double* z, double* zd,
+                                  int ldz, double* A, int lda, const double* logdet, const int* info, double* X, int ldxw, double* W, int ldw,
+                                  double* alpha, double* workspace, int nblocks, double* out, double* half_diag, int* info_out, void* stream);
 
 /* The same moment sums of  sum W dK/dtheta  for the other weight shapes the inducing-point (VFE) bound needs
  * [gradient of the PseudoObs elbo, gpar/model.py:226,286-287 under varz's optimiser]:

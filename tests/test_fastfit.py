@@ -161,6 +161,108 @@ def test_fit_takes_the_prepared_objective_where_it_applies_and_trains_the_same_m
     assert all(b is None for b in built[before:])
 
 
+class _FakeRendezvous(fastfit.LockstepFactor):
+    """The protocol of the lock-step rendezvous with its device side replaced by a log (no GPU: threads, a condition, counters)."""
+
+    def _allocate(self, eng):
+        self.log = []
+
+    def _stream(self):
+        import threading
+
+        return threading.get_ident()
+
+    def _record(self, stream):
+        return ("event", stream, len(self.log))
+
+    def _wait(self, stream, event):
+        pass
+
+    def _potrf(self, stream, first, count):
+        self.log.append((first, count))
+
+
+def test_lockstep_rendezvous_rounds_are_a_function_of_the_evaluation_counts_only():
+    """LockstepFactor: lanes that make different numbers of evaluations (L-BFGS-B line searches differ per layer), train several
+    layers one after the other and finish at different times - every round holds exactly the lanes that still have evaluations to
+    make, consecutive slots are one batch, nobody deadlocks, and the composition of the rounds is the same whatever the timing."""
+    import random
+    import threading
+    import time
+
+    counts = [[5, 3], [2], [7, 1, 2], [4]]   # evaluations per layer, per lane
+
+    def run(seed):
+        rv = _FakeRendezvous(None, 10, len(counts))
+        rng = random.Random(seed)
+        delays = [[rng.random() * 2e-3 for _ in range(sum(c))] for c in counts]
+
+        def lane(k):
+            try:
+                it = iter(delays[k])
+                for evaluations in counts[k]:
+                    for _ in range(evaluations):
+                        time.sleep(next(it))
+                        rv.factor(k)
+            finally:
+                rv.leave(k)
+
+        threads = [threading.Thread(target=lane, args=(k,), daemon=True) for k in range(len(counts))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=20)
+            assert not t.is_alive(), "a lane is stuck in the rendezvous"
+        return rv.history, rv.log
+
+    totals = [sum(c) for c in counts]
+    expected = [tuple(k for k in range(len(counts)) if totals[k] > r) for r in range(max(totals))]
+    first = run(0)
+    assert first[0] == expected
+    assert all(run(seed) == first for seed in (1, 2, 3))
+    # runs of consecutive slots are one batch each: round 0 = lanes 0-3 in one call, a round of lanes (0, 2) two calls
+    assert first[1][0] == (0, 4) and (0, 1) in first[1] and (2, 1) in first[1]
+
+
+def test_lockstep_rendezvous_passes_a_failure_to_every_lane_and_a_leaving_lane_completes_the_round():
+    import threading
+
+    class Broken(_FakeRendezvous):
+        def _potrf(self, stream, first, count):
+            raise RuntimeError("launch failed")
+
+    rv = Broken(None, 10, 2)
+    seen = []
+
+    def lane(k):
+        try:
+            rv.factor(k)
+        except RuntimeError as exc:
+            seen.append((k, str(exc)))
+        finally:
+            rv.leave(k)
+
+    threads = [threading.Thread(target=lane, args=(k,), daemon=True) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=10)
+        assert not t.is_alive()
+    assert sorted(seen) == [(0, "launch failed"), (1, "launch failed")]
+    # a lane that leaves while the other waits completes the round for it
+    rv = _FakeRendezvous(None, 10, 2)
+    waiter = threading.Thread(target=lambda: rv.factor(0), daemon=True)
+    waiter.start()
+    import time
+
+    time.sleep(0.05)
+    rv.leave(1)
+    waiter.join(timeout=10)
+    assert not waiter.is_alive() and rv.history == [(0,)]
+    with pytest.raises(RuntimeError):
+        rv.factor(1)   # (not a member any more)
+
+
 # ---- through libgpar_hip.so --------------------------------------------------------------------------------------------------
 
 @pytest.fixture
@@ -208,3 +310,40 @@ def test_fit_trains_the_same_hyperparameters_on_both_routes(hip_engine, n):
     assert sorted(a) == sorted(b)
     for k in a:
         np.testing.assert_allclose(a[k], b[k], rtol=1e-7, atol=1e-10, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(1100, 4), (1500, 6), (2048, 3)])
+def test_lockstep_rendezvous_trains_the_model_of_the_serial_loop(hip_engine, monkeypatch, n, p):
+    """fit(fix=True) above ~1000 rows: the lanes' factorisations of a round are ONE gpar_potrf_batch (fastfit.LockstepFactor).  The
+    factor of a matrix inside a batch equals the lone factor to rounding (not to the bit), so the trained hyper-parameters are those
+    of the serial loop to the optimiser's amplification of rounding; with more layers than lanes a lane trains several layers one
+    after the other, and the rendezvous reports as many rounds as the busiest lane made evaluations."""
+    from gpar_amd import optimise
+
+    x, y, _ = _data(n=n, m=2, p=p, seed=n)
+    kw = dict(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False)
+    monkeypatch.delenv("GPAR_FIT_THREADS", raising=False)
+    monkeypatch.setenv("GPAR_FIT_LOCKSTEP_ROWS", "1000")   # (the default starts at 3072 rows: see fastfit.lockstep_rows)
+    before = optimise.evaluation_count()
+    together = GPARRegressor(**kw)
+    together.fit(x, y, iters=10)
+    evaluations = optimise.evaluation_count() - before
+    rounds, batches = together._lockstep_rounds
+    assert 0 < rounds <= evaluations and batches >= rounds
+    assert rounds < evaluations   # (several lanes per round)
+    monkeypatch.setenv("GPAR_FIT_THREADS", "1")
+    serial = GPARRegressor(**kw)
+    serial.fit(x, y, iters=10)
+    a, b = together.get_variables(), serial.get_variables()
+    assert sorted(a) == sorted(b)
+    for k in a:
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=1e-8, err_msg=k)
+    # off by the switch: the lanes factor on their own, bit for bit the serial model
+    monkeypatch.delenv("GPAR_FIT_THREADS")
+    monkeypatch.setenv("GPAR_FIT_LOCKSTEP_ROWS", "0")
+    apart = GPARRegressor(**kw)
+    apart.fit(x, y, iters=10)
+    assert not hasattr(apart, "_lockstep_rounds")
+    for k, v in apart.get_variables().items():
+        assert np.array_equal(v, b[k]), k
