@@ -65,6 +65,7 @@ CALL_TIME = [
     ("GPAR_VFE_FUSED_SCALARS", "0"),
     ("GPAR_ONE_CALL_GRAD_ROWS", "0"),
     ("GPAR_FIT_THREADS", "1"),
+    ("GPAR_FIT_LOCKSTEP_ROWS", "1000"),   # (what it changes - concurrent fits - is tests/test_fastfit.py::test_lockstep_rendezvous_*)
     ("GPAR_NOTPD_RETRY", "0"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "0"),
     ("GPAR_GRAM_JIT_MIN_ENTRIES", "-1"),
