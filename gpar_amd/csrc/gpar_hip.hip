@@ -387,8 +387,6 @@ int gpar_init(void* stream) {
                          reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1, 64>), reinterpret_cast<const void*>(&gram_grad_kernel),
                          reinterpret_cast<const void*>(&gram_input_grad_kernel)};
     for (const void* fn : big) GPAR_HIP_TRY(gpar_set_max_lds(fn, 160 * 1024));
-    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&potrf_panel_kernel), PNL_LDS_BYTES));
-    GPAR_HIP_TRY(gpar_set_max_lds(reinterpret_cast<const void*>(&trsm_block_kernel), PNL_LDS_BYTES));
     const void* p2[] = {reinterpret_cast<const void*>(&potrf_panel2_kernel), reinterpret_cast<const void*>(&trsm_block2_kernel),
                         reinterpret_cast<const void*>(&trsm_block2_back_kernel), reinterpret_cast<const void*>(&trinv_blocks2_kernel)};
     for (const void* fn : p2) GPAR_HIP_TRY(gpar_set_max_lds(fn, P2_LDS_BYTES));

@@ -415,7 +415,6 @@ static bool potrf_la_is_small(const PotrfCtx& c, int k0, int kend, int la_end) {
     const int cols = la_end - kend, K = kend - k0;
     if (cols <= 0 || cols % 64 != 0 || K <= 0 || K % 64 != 0 || (c.lda & 1) || !gpar_aligned16(c.A) || (c.batch_a & 1) || (k0 & 1) || c.N - kend <= POTRF_SMALL_ROWS)
         return false;
-    if (env_int("GPAR_PANEL_V", 2) < 2) return false;
     const int nc = cols / 64, tr = (c.N - kend + 63) / 64;
     if (tr < nc) return false;
     const long long tiles = ((long long)nc * (nc + 1) / 2 + (long long)(tr - nc) * nc) * c.batch;
@@ -486,12 +485,9 @@ static int potrf_panel_split(const PotrfCtx& c, int k0, int kend, int nb, hipStr
 }
 
 // defined in panel.h (one launch per 64-row block of B for up to 8 column steps)
-static int trsm_block_fused(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
-                            hipStream_t stream);
 // defined in panel.h (one persistent launch per panel)
-static int potrf_panel_fused(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed);
 static void potrf_zero_flags(double* A, int N, int lda, hipStream_t stream, int batch, long long batch_a);
-// second generation (panel2.h): left-looking row-block tasks, strips on the matrix cores.  GPAR_PANEL_V=1 selects the first.
+// the fused panel kernels (panel2.h): left-looking row-block tasks, strips on the matrix cores
 static int potrf_panel_fused2(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed,
                               int batch = 1, long long batch_a = 0);
 static int trsm_block_fused2(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
@@ -505,21 +501,13 @@ static int trsm_block_back_fused2(const double* L, int n, int ldl, double* B, in
 
 static inline int potrf_panel_any(double* A, int N, int lda, int k0, int W, double* logdet, int* info, hipStream_t stream, bool prezeroed,
                                   int batch = 1, long long batch_a = 0) {
-    if (env_int("GPAR_PANEL_V", 2) >= 2) {
-        // (a chain-only launch followed by the solve block kernel for the rows below - GPAR_POTRF_PANEL_SPLIT_ROWS, round 2 - was
-        // slower at every size and is retired: NOTES.md section 7, lesson 34)
-        return potrf_panel_fused2(A, N, lda, k0, W, logdet, info, stream, prezeroed, batch, batch_a);
-    }
-    for (int b = 0; b < batch; ++b) {   // (the first-generation kernel takes one matrix per launch)
-        const int rc = potrf_panel_fused(A + (size_t)b * batch_a, N, lda, k0, W, logdet ? logdet + b : nullptr, info ? info + b : nullptr, stream, prezeroed);
-        if (rc) return rc;
-    }
-    return 0;
+    // (a chain-only launch followed by the solve block kernel for the rows below - GPAR_POTRF_PANEL_SPLIT_ROWS, round 2 - was slower at
+    // every size and is retired: NOTES.md section 7, lesson 34)
+    return potrf_panel_fused2(A, N, lda, k0, W, logdet, info, stream, prezeroed, batch, batch_a);
 }
 static inline int trsm_block_any(const double* L, int n, int ldl, double* B, int nrows, int ldb, int c0, int S, int upper_tri,
                                  hipStream_t stream) {
-    return env_int("GPAR_PANEL_V", 2) >= 2 ? trsm_block_fused2(L, n, ldl, B, nrows, ldb, c0, S, upper_tri, stream)
-                                           : trsm_block_fused(L, n, ldl, B, nrows, ldb, c0, S, upper_tri, stream);
+    return trsm_block_fused2(L, n, ldl, B, nrows, ldb, c0, S, upper_tri, stream);
 }
 
 struct LookaheadState {
@@ -681,7 +669,7 @@ static int potrf_run(double* A, int N, int nf, int lda, double* logdet, int* inf
     // of 4096 rows in ONE launch 3.55 -> 2.81 ms against 3.05 with their last 1536 rows fused (rows x batch <= 16500: C2, 4 x 3072 1.82 ->
     // 1.62 ms, 8 x 2048 1.55 -> 1.36; C3 and C5 - the last 2048 / 1024 rows - unchanged; profiles/r05_exp_batch_fuse.txt).
     const int fuse2_rows = batch == 1 ? env_int("GPAR_POTRF_FUSE2_ROWS", N <= 5200 ? 5200 : (N >= 12288 ? 8300 : 4200)) : env_int("GPAR_POTRF_FUSE2_BATCH_ROWS", 16500) / batch;
-    const bool fuse2_on = pol.fused && prezero && !(flags & GPAR_POTRF_UNFUSED) && nbo == 512 && env_int("GPAR_PANEL_V", 2) >= 2 &&
+    const bool fuse2_on = pol.fused && prezero && !(flags & GPAR_POTRF_UNFUSED) && nbo == 512 &&
                           env_int("GPAR_PANEL_PAIRS", 1) && (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && fuse2_rows > 0;
     unsigned long long fuse_counted = 0;   // tiles every row block below the fused launches so far has counted (panel2.h)
     // (more than two panels per launch add little - between panels inside a launch the next team waits ~45 us for the last column
@@ -825,7 +813,7 @@ static int potrf_run_batch(double* A, int batch, long long batch_a, int N, int n
     if (batch <= 0) return 0;
     if (nf > N) return GPAR_ARG_ERROR(1);
     const PotrfPolicy pol = potrf_policy(N);
-    const bool lockstep = batch > 1 && pol.fused && !(flags & GPAR_POTRF_UNFUSED) && env_int("GPAR_PANEL_V", 2) >= 2 && pol.nbo % 64 == 0 &&
+    const bool lockstep = batch > 1 && pol.fused && !(flags & GPAR_POTRF_UNFUSED) && pol.nbo % 64 == 0 &&
                           (lda % 2 == 0) && (batch_a % 2 == 0) && gpar_aligned16(A) && nf >= env_int("GPAR_POTRF_LOCKSTEP_MIN", 1);
     if (lockstep) return potrf_run(A, N, nf, lda, logdet, info, stream, flags, batch, batch_a);
     for (int b = 0; b < batch; ++b) {
@@ -958,7 +946,7 @@ __global__ __launch_bounds__(256) void set_block_identity_kernel(double* __restr
 
 static int chol_inverse_run(const double* L, int n, int ldl, double* X, int ldx, double* Kinv, int ldk, hipStream_t stream) {
     if (n <= 0) return 0;
-    const bool recursive = env_int("GPAR_INVERSE_RECURSIVE", 1) && env_int("GPAR_PANEL_V", 2) >= 2 && n >= 1024 && n % 512 == 0 && gpar_aligned16(L) &&
+    const bool recursive = env_int("GPAR_INVERSE_RECURSIVE", 1) && n >= 1024 && n % 512 == 0 && gpar_aligned16(L) &&
                            gpar_aligned16(X) && gpar_aligned16(Kinv) && ldl % 2 == 0 && ldx % 2 == 0 && ldk % 2 == 0;
     if (recursive) hipLaunchKernelGGL(set_block_identity_kernel, dim3(2, n), dim3(256), 0, stream, X, n, ldx, 512);
     else hipLaunchKernelGGL(set_identity_kernel, dim3(gpar_ceil_div(n, 256), n), dim3(256), 0, stream, X, n, ldx);
@@ -1176,7 +1164,7 @@ static int trsm_rln_run(const double* L, int n, int ldl, double* B, int nrows, i
     // (panel2.h) and followed by ONE K = 512 NN update of everything to its left - instead of 64-column strips with a K = 64
     // update each (16 + 16 launches per 1024 columns, the updates at a fifth of the rate).  A ragged tail (n not a multiple of
     // 64) goes first, by the strip path.
-    const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && env_int("GPAR_PANEL_V", 2) >= 2 && n >= env_int("GPAR_TRSM_BACK_FUSED_MIN", 128) && nrows >= 2 &&
+    const bool fusable = env_int("GPAR_TRSM_FUSED", 1) && n >= 128 && nrows >= 2 &&
                          gpar_aligned16(L) && gpar_aligned16(B) && (ldl % 2 == 0) && (ldb % 2 == 0);
     int ntop = n;   // columns [0, ntop) still to be solved
     if (fusable) {

@@ -20,7 +20,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CALL_TIME = [
     ("GPAR_POTRF_NBO", "256"),
-    ("GPAR_PANEL_V", "1"),
     ("GPAR_PANEL_PROGRESSIVE", "0"),
     ("GPAR_PANEL_SPLIT", "0"),
     ("GPAR_PANEL_SPLIT", "2"),
