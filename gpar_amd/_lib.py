@@ -173,6 +173,7 @@ SIGNATURES = {
     "gpar_workspace_doubles": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
     "gpar_randn": (_c_int, [_u64, _u64, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "gpar_trmv_lower": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr]),
+    "gpar_trmv_upper": (_c_int, [_ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr]),
     "gpar_gemv": (_c_int, [_ptr, _c_int, _c_int, _c_int, _ptr, _c_int, _c_dbl, _ptr, _c_int, _ptr]),
     "gpar_trmv_lower_batch": (
         _c_int,

@@ -576,7 +576,7 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     for (const void* fn : {reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0>),
                            reinterpret_cast<const void*>(&gemm_f64_kernel<true, false, 0>), reinterpret_cast<const void*>(&gemm_f64_kernel<true, true, 0>),
                            reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 0, 64>),
-                           reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1, 64>)})
+                           reinterpret_cast<const void*>(&gemm_f64_kernel<false, true, 1, 64>), reinterpret_cast<const void*>(&gemm_f64_kernel<false, false, 0, 64>)})
         GPAR_HIP_TRY(gpar_set_max_lds(fn, 160 * 1024));
     // half tiles (two workgroups per 128 x 128 tile) while a launch has fewer tiles than the chip has compute units
     static int half_tiles = -1;
@@ -586,7 +586,9 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     // n = 400 103-120 -> 97-100 ms, n = 1024 136-153 -> 118-121)
     static int half_flags = -1;
     if (half_flags < 0) { const char* e = getenv("GPAR_GEMM_HALF_TILES_TRIANGULAR"); half_flags = e ? atoi(e) : 1; }
-    const bool half = !ta && tb && ntiles * batch <= half_tiles && k >= 64 &&
+    // (round 6: the NN form too - the second product of every level of the recursive inversion, X12 = -T X22, is a few-tile launch
+    // with K up to the block size: n = 2048 / 4096 ... us per evaluation of a training objective)
+    const bool half = !ta && ntiles * batch <= half_tiles && k >= 64 &&
                       (half_flags || !(flags & (GPAR_GEMM_A_LOWER | GPAR_GEMM_K_FROM_ROW | GPAR_GEMM_K_TO_COL)));
     const int GEMM_LDS_REQ = GEMM_LDS_BYTES;   // (padding the request so that ONE workgroup fits a compute unit - a hole for a panel workgroup on every unit - changed nothing: lesson 34)
     // whole tiles, except for a last round that would be at most half full (MIXED, see the kernel): the trailing update alone
@@ -600,7 +602,8 @@ static int gemm_launch(int ta, int tb, int m, int n, int k, double alpha, const 
     }
     dim3 grid(half ? 2 * ntiles : p.nfull + 2 * p.ntail, 1, batch), block(256);
     if (half && role == 1) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1, 64>), grid, block, GEMM_LDS_REQ, stream, p);
-    else if (half) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0, 64>), grid, block, GEMM_LDS_REQ, stream, p);
+    else if (half && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0, 64>), grid, block, GEMM_LDS_REQ, stream, p);
+    else if (half) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0, 64>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (role == 1 && !ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, GEMM_LDS_REQ, stream, p);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, GEMM_LDS_REQ, stream, p);

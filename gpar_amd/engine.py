@@ -307,6 +307,14 @@ class HipEngine:
     def chol_inverse(self, L):
         return hip.chol_inverse(L)
 
+    def chol_inverse_x(self, L):
+        """(lower triangle of (L L^T)^-1, X = L^-T in the upper triangle of the call's workspace)."""
+        return hip.chol_inverse(L, with_x=True)
+
+    def trmv_upper(self, U, x):
+        """U x for an upper-triangular U and one vector (n entries), as a 1 x n row."""
+        return hip.trmv_upper(self._mat(U), x).reshape(1, -1)
+
     def gemv_t(self, A, v):
         """A^T v for a tall matrix A and one weight per row (vector of A.shape[1] entries)."""
         return hip.gemv_t(self._mat(A), v)

@@ -736,8 +736,9 @@ def gram_input_grad(ck, z1, z2, W, mode):
     return out
 
 
-def chol_inverse(L):
-    """Lower triangle of (L L^T)^-1 (new matrix) from the Cholesky factor L; triangular-aware (2 n^3 / 3 flops)."""
+def chol_inverse(L, with_x=False):
+    """Lower triangle of (L L^T)^-1 (new matrix) from the Cholesky factor L; triangular-aware (2 n^3 / 3 flops).  `with_x`: also the
+    workspace the call leaves behind, X = L^-T in its upper triangle (the strict lower triangle is scratch)."""
     lib = _lib.load()
     _check_mat(L, "L")
     n = L.shape[0]
@@ -747,4 +748,19 @@ def chol_inverse(L):
         lib.gpar_chol_inverse(L.data_ptr(), n, _ld(L), X.data_ptr(), _ld(X), Kinv.data_ptr(), _ld(Kinv), stream_ptr(L.device)),
         "gpar_chol_inverse",
     )
-    return Kinv
+    return (Kinv, X) if with_x else Kinv
+
+
+def trmv_upper(U, x):
+    """U x for an upper-triangular U (the strict lower triangle is not read) and a single vector x (any shape with n entries, unit or
+    row stride): new contiguous vector of n entries (gpar_trmv_upper)."""
+    lib = _lib.load()
+    _check_mat(U, "U")
+    n = U.shape[0]
+    x = x.reshape(-1)
+    if x.numel() != n or x.dtype != torch.float64 or not x.is_cuda:
+        raise ValueError("x must hold one fp64 device value per row of U")
+    out = torch.empty(n, dtype=torch.float64, device=U.device)
+    _lib.check(lib.gpar_trmv_upper(U.data_ptr(), n, _ld(U), x.data_ptr(), int(x.stride(0)), out.data_ptr(), 1, stream_ptr(U.device)),
+               "gpar_trmv_upper")
+    return out

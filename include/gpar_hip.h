@@ -191,7 +191,7 @@ int gpar_gram_grad(const gpar_kspec_t* ks, const double* z, const double* zd, in
  *   1/2 sum_ab W_ab dK_ab/dtheta (as gpar_gram_grad),  half_diag[a] = 1/2 W_aa (the derivative with respect to noise_diag[a]),
  * with W = alpha alpha^T - (K + D)^-1.  The same launches the separate entry points make, in the same order (same bits):
  * gpar_featurize (+ gpar_featurize_dfreq when zd is non-null), gpar_gram, the augmented factorisation, gpar_chol_inverse,
- * gpar_trsm_rln on the row L^-1 y, the rank-1 update of W, gpar_gram_grad.  Workspaces: z (and zd) n x dz (ldz); A (n + 1) x (n + 1);
+ * gpar_trmv_upper of the inverse's workspace X = L^-T on the row L^-1 y (alpha; a gpar_trsm_rln until ABI v6), the rank-1 update of W, gpar_gram_grad.  Workspaces: z (and zd) n x dz (ldz); A (n + 1) x (n + 1);
  * X and W n x n; alpha n doubles; workspace nblocks * GPAR_GRAD_NACC doubles.  What it removes is the caller's side: a Python host
  * spends ~1 ms per evaluation on ~30 launches and three synchronisations around them, which IS the evaluation below n ~ 1000 - the
  * size the reference's own examples train at.
@@ -395,6 +395,11 @@ int gpar_randn(uint64_t seed, uint64_t offset, double* out, int rows, int cols, 
  * is not read).  [the chol(cov) * z product of Normal.sample for a single draw; a 128-wide GEMM tile for one column is
  * all latency] */
 int gpar_trmv_lower(const double* L, int n, int ldl, const double* x, int incx, double* y, int incy, void* stream);
+/* y[i*incy] = sum_{j>=i} U[i][j] * x[j*incx], i < n: UPPER-triangular matrix times one vector (ABI v7; the strict lower triangle is
+ * not read).  With U = X = L^-T - the workspace gpar_chol_inverse leaves behind - and x = L^-1 y (row n of an augmented factor) it is
+ * alpha = (L L^T)^-1 y, the vector of the gradient's weights W = alpha alpha^T - K^-1, at memory speed instead of a backward
+ * substitution.  [the alpha of the analytic gradient inside varz.minimise_l_bfgs_b, gpar/regression.py:459] */
+int gpar_trmv_upper(const double* U, int n, int ldu, const double* x, int incx, double* y, int incy, void* stream);
 /* y[i*incy] = alpha * sum_j A[i][j] * x[j*incx], i < rows: a general row-major matrix times ONE vector (ABI v5; one wave per row).
  * [posterior means K(x*, X) alpha and K(x*, Z) v: gpar/model.py:298-301 - matrix-vector products that a 128-wide GEMM tile serves badly] */
 int gpar_gemv(const double* A, int rows, int cols, int lda, const double* x, int incx, double alpha, double* y, int incy, void* stream);

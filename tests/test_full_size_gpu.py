@@ -64,6 +64,64 @@ def test_c3_full_size_joint_logpdf_is_the_sum_of_layer_logpdfs(hip):
     assert abs(joint - parts) <= 1e-12 * abs(parts), (joint, parts)
 
 
+def test_c3_full_size_fit_and_predict(hip):
+    """BASELINE config 3's other two legs at full size (n = 16384, m = 4, p = 8, markov = 2; `fit` reference gpar/regression.py:391-459,
+    `predict` :566-597) - until round 6 only TIMED by bench.py.  Checked: the analytic gradient L-BFGS-B is handed for the widest layer
+    against a central finite difference of the objective along a random direction (the inverse, the weights and the fused weighted-sum
+    pass at 16384 rows); two iterations of `fit` raise the log marginal likelihood of the training data and leave every
+    hyper-parameter finite and inside its bounds; `predict` at training inputs returns finite, ordered bounds around a mean that
+    explains the observations (layer 0 to within the noise the model has learnt, every layer better than the prior mean)."""
+    from gpar_amd.model import per_output
+    from gpar_amd.optimise import objective_and_gradient
+    from gpar_amd.regression import GPARRegressor, _construct_gpar
+
+    n, m, p = 16384, 4, 8
+    x, y = _data(n, m, p)
+    kw = dict(scale=0.5, linear=True, nonlinear=True, markov=2, noise=0.1, normalise_y=False)
+    reg = GPARRegressor(**kw)
+    xd, yd = hip.tensor(x), hip.tensor(y)
+    before = float(reg.logpdf(xd, yd))
+    # ---- directional derivative of the last layer's training objective
+    reg.condition(x, y)
+    pi = p - 1
+    wd = hip.tensor(reg.w)
+    y_cached = {k: list(per_output(yd, wd, keep=k)) for k in [True, False]}
+    gpar = _construct_gpar(reg, reg.vs, m, pi + 1)
+    fixed_x, _ = gpar.logpdf(xd, y_cached, None, only_last_layer=True, outputs=list(range(pi)), return_inputs=True)
+
+    def objective(vs):
+        return -_construct_gpar(reg, vs, m, pi + 1).logpdf(fixed_x, y_cached, None, only_last_layer=True, outputs=[pi])
+
+    fg, names, x0 = objective_and_gradient(objective, reg.vs, [f"{pi}/*"])
+    value, grad = fg(x0)
+    d = np.random.default_rng(0).standard_normal(x0.shape)
+    d /= np.linalg.norm(d)
+    h = 1e-4
+    fd = (fg(x0 + h * d)[0] - fg(x0 - h * d)[0]) / (2 * h)
+    assert np.isfinite(value) and np.all(np.isfinite(grad))
+    assert abs(fd - grad @ d) <= 1e-5 * max(abs(fd), np.abs(grad).max()), (fd, grad @ d)
+    reg.vs.set_vector(x0, names)
+    # ---- fit: two L-BFGS-B iterations per layer
+    reg.fit(x, y, iters=2)
+    after = float(reg.logpdf(xd, yd))
+    assert after > before, (before, after)
+    for name, v in reg.get_variables().items():
+        assert np.all(np.isfinite(v)), name
+        if not name.endswith("/const"):
+            assert np.all(v > 0), name
+    # ---- predict at 256 training inputs
+    hip.seed(31)
+    mean, lo, hi = reg.predict(x[:256], num_samples=12, credible_bounds=True)
+    assert np.isfinite(mean).all() and np.isfinite(lo).all() and np.isfinite(hi).all()
+    assert np.all(lo <= hi) and np.all(hi - lo > 0)
+    noise = np.array([float(reg.get_variables()[f"{i}/noise"]) for i in range(p)])
+    rmse = np.sqrt(np.mean((mean - y[:256]) ** 2, axis=0))
+    # layer 0 sees the inputs only: its predictive mean at training inputs explains y_0 to within the learnt noise; later layers are fed
+    # SAMPLED earlier outputs (replace=False), so their predictive law at a training input is broader - every one still beats the prior mean 0
+    assert rmse[0] < 3.0 * np.sqrt(noise[0]) + 0.15, (rmse, np.sqrt(noise))
+    assert np.all(rmse < 0.9 * np.sqrt(np.mean(y[:256] ** 2, axis=0))), (rmse, np.sqrt(np.mean(y[:256] ** 2, axis=0)))
+
+
 def test_c5_full_size_chain_rule_and_factor_of_the_periodic_rq_kernel(hip):
     from gpar_amd import hip as H
     from gpar_amd.kernels import compile_kernel

@@ -270,6 +270,33 @@ def test_trmv_lower(env, n):
     np.testing.assert_allclose(got, L @ x[:, 1:2], rtol=1e-12, atol=1e-12 * np.sqrt(n))
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 300, 2049])
+def test_trmv_upper_and_the_alpha_it_stands_for(env, n):
+    """gpar_trmv_upper (ABI v7): U x for an upper-triangular U whose strict lower triangle is never read; with U = the workspace
+    gpar_chol_inverse leaves (L^-T) and x = L^-1 y it is (L L^T)^-1 y - the alpha of the gradient's weights - to the accuracy of the
+    backward substitution it replaces."""
+    torch, hip, dev, to_dev = env
+    rng = np.random.default_rng(n)
+    U = np.triu(rng.standard_normal((n, n)))
+    x = rng.standard_normal((n, 3))
+    dU = to_dev(U + np.tril(np.full((n, n), np.nan), -1))
+    got = hip.trmv_upper(dU, to_dev(x)[:, 1]).cpu().numpy()   # a strided vector
+    np.testing.assert_allclose(got, U @ x[:, 1], rtol=1e-12, atol=1e-12 * np.sqrt(n))
+    G = rng.standard_normal((n, n + 5))
+    K = G @ G.T / n + 0.5 * np.eye(n)
+    y = rng.standard_normal(n)
+    Ld = to_dev(K)
+    _, info = hip.potrf_(Ld)
+    assert int(info.item()) == 0
+    Kinv, X = hip.chol_inverse(Ld, with_x=True)
+    L = np.linalg.cholesky(K)
+    z = np.linalg.solve(L, y)
+    alpha = hip.trmv_upper(X, to_dev(z)).cpu().numpy()
+    want = np.linalg.solve(K, y)
+    np.testing.assert_allclose(alpha, want, rtol=1e-10, atol=1e-11 * np.abs(want).max())
+    np.testing.assert_allclose(np.tril(Kinv.cpu().numpy()), np.tril(np.linalg.inv(K)), rtol=1e-9, atol=1e-11)
+
+
 def test_reductions(env):
     """gpar_dot, gpar_gemv_t (A^T v for a tall A), gpar_rownorm2: ragged sizes, padded and unpadded storage."""
     torch, hip, dev, to_dev = env
