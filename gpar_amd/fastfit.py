@@ -365,19 +365,35 @@ class DenseLayerObjective:
 
     # ---- one evaluation -----------------------------------------------------------------------------------------------------
     def _write_values(self, x):
-        """Latent vector -> bounded values into the holders (the store's transform: lower + (upper - lower) sigmoid(latent), with
-        torch's sigmoid so that the values are the ones the general route computes); returns the sigmoids for the chain rule."""
-        sig = torch.sigmoid(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))).numpy()
-        for name, kind, lower, upper, sl, shape in self.layout:
+        """Latent vector -> bounded values into the holders (the store's transform: lower + (upper - lower) sigmoid(latent)); returns
+        the sigmoids for the chain rule.  The sigmoid is torch's, taken PER VARIABLE on a tensor of the variable's own shape - exactly the
+        call `vars._Var.value` makes: one call over the whole vector would send some elements down torch's vectorised path and others
+        down its scalar tail, whose exponentials can differ in the last bit, and the general route's values would no longer be
+        reproduced bit for bit (found by tools/r06/fuzz_fastfit.py: 1 evaluation in ~200 differed by 8e-13).  One torch call per
+        variable, on views of two persistent buffers."""
+        views = getattr(self, "_views", None)
+        if views is None:
+            self._latent_np = np.zeros(self.size)
+            self._sig_np = np.zeros(self.size)
+            latent, sig = torch.from_numpy(self._latent_np), torch.from_numpy(self._sig_np)
+            views = self._views = [(latent[sl].reshape(shape), sig[sl].reshape(shape)) if kind in ("bnd", "pos") else None
+                                   for _, kind, _, _, sl, shape in self.layout]
+        self._latent_np[:] = x
+        sig = self._sig_np
+        for (name, kind, lower, upper, sl, shape), view in zip(self.layout, views):
+            if kind == "bnd":
+                torch.sigmoid(view[0], out=view[1])
+            elif kind == "pos":
+                torch.exp(view[0], out=view[1])   # (for "pos" the buffer holds exp(latent): value and derivative at once)
             h = self.holders.get(name)
             if h is None:
                 continue   # (a selected variable the layer does not read: its gradient is zero)
             if kind == "bnd":
                 h[...] = (lower + (upper - lower) * sig[sl]).reshape(shape)
             elif kind == "pos":
-                h[...] = np.exp(x[sl]).reshape(shape)
+                h[...] = sig[sl].reshape(shape)
             else:
-                h[...] = np.asarray(x[sl]).reshape(shape)
+                h[...] = self._latent_np[sl].reshape(shape)
         return sig
 
     def fg(self, x):
@@ -419,7 +435,7 @@ class DenseLayerObjective:
                 s = sig[sl]
                 g = ((g * (upper - lower)) * (1.0 - s)) * s   # (the order autograd multiplies in: same bits as the general route)
             elif kind == "pos":
-                g = g * np.exp(x[sl])
+                g = g * sig[sl]
             grad[sl] = -g
         return -value, grad
 

@@ -347,3 +347,32 @@ def test_lockstep_rendezvous_trains_the_model_of_the_serial_loop(hip_engine, mon
     assert not hasattr(apart, "_lockstep_rounds")
     for k, v in apart.get_variables().items():
         assert np.array_equal(v, b[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(0, 60, 3))
+def test_prepared_objective_on_random_configurations(hip_engine, seed):
+    """The fuzz generator of tests/test_fuzz_parity_gpu.py (random kernel families, Markov orders, missing data, weights,
+    normalisation, sizes 300-3000): wherever the prepared objective applies, its value is the general route's to the bit and its
+    gradient to 1e-9 of the largest component, at the initial point and at a perturbed one.  (This is the test that found the
+    one-call-over-the-whole-vector sigmoid: torch's vectorised and scalar exponentials differ in the last bit.)"""
+    from .test_fuzz_parity_gpu import _case
+
+    kw, x, y, w, xs = _case(seed)
+    if "x_ind" in kw or x.shape[0] > 4096:
+        pytest.skip("inducing points / more rows than the prepared objective takes")
+    reg = GPARRegressor(**kw)
+    reg.condition(x, y, w)
+    for pi in range(reg.p):
+        fast, fg, x0 = _layer_objectives(reg, hip_engine, pi, None)
+        rng = np.random.default_rng(seed * 10 + pi)
+        for trial in range(2):
+            xv = x0 + (0.0 if trial == 0 else 0.25 * rng.standard_normal(x0.shape))
+            v_fast, g_fast = fast.fg(xv)
+            v_ref, g_ref = fg(xv)
+            if np.isnan(v_ref):
+                assert np.isnan(v_fast)
+                continue
+            assert v_fast == v_ref, (seed, pi, trial, v_fast, v_ref)
+            assert np.max(np.abs(g_fast - g_ref)) <= 1e-9 * max(np.abs(g_ref).max(), 1e-3)
+        reg.vs.set_vector(x0, fast.names)
