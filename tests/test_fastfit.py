@@ -353,7 +353,7 @@ def test_lockstep_rendezvous_trains_the_model_of_the_serial_loop(hip_engine, mon
 @pytest.mark.parametrize("seed", range(0, 60, 3))
 def test_prepared_objective_on_random_configurations(hip_engine, seed):
     """The fuzz generator of tests/test_fuzz_parity_gpu.py (random kernel families, Markov orders, missing data, weights,
-    normalisation, sizes 300-3000): wherever the prepared objective applies, its value is the general route's to the bit and its
+    normalisation, tied scales, 2 to 160 rows): wherever the prepared objective applies, its value is the general route's to the bit and its
     gradient to 1e-9 of the largest component, at the initial point and at a perturbed one.  (This is the test that found the
     one-call-over-the-whole-vector sigmoid: torch's vectorised and scalar exponentials differ in the last bit.)"""
     from .test_fuzz_parity_gpu import _case
