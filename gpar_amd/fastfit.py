@@ -117,23 +117,25 @@ def _slots(kernel):
 
 
 def lockstep_rows():
-    """(min, max) rows between which concurrently trained layers factor their matrices TOGETHER (LockstepFactor).  Measured
-    (profiles/r06_lockstep_fit.txt; fit(iters=20), four layers, rendezvous off -> on): n = 1024 37 -> 38 ms, 1536 52 -> 68, 2048
-    61 -> 71, 3072 121 -> 119, 4096 220 -> 210: a round costs every lane the slowest lane's evaluation plus two thread hand-offs, and
-    below ~3000 rows that is more than the queueing of the lone factorisations behind one another costs - so the default starts
-    at 3072 rows; above `gp.one_call_grad_rows()` the prepared objective does not apply.  GPAR_FIT_LOCKSTEP_ROWS=lo[:hi] overrides
-    (0 = never)."""
+    """(min, max) rows between which concurrently trained layers factor their matrices TOGETHER (LockstepFactor).  OFF by default:
+    (1, 0).  Measured on three boxes of the pool (profiles/r06_lockstep_fit.txt; fit(iters=20), four layers, rendezvous off -> on):
+    n = 1024 37 -> 38 / 37 -> 48 ms, 1536 52 -> 68 / 50 -> 56, 2048 61 -> 71 / 60 -> 70 / 60 -> 60, 2560 87 -> 89 / 88 -> 108, 3072 121 -> 119 /
+    111 -> 99 / 113 -> 128, 4096 220 -> 210 / 208 -> 199 / 210 -> 229.  A round costs every lane the slowest lane's evaluation plus two
+    thread hand-offs, whose latency is the host's; free-running lanes hide one lane's factorisation under the others' inverses.  Where the
+    factorisation dominates (from ~3000 rows) the rendezvous wins 5-11 % on two boxes and loses 9-14 % on the third: not a default.
+    GPAR_FIT_LOCKSTEP_ROWS=lo[:hi] switches it on between lo and hi rows (hi at most `gp.one_call_grad_rows()`, above which the
+    prepared objective does not apply; 0 = never)."""
     from .gp import one_call_grad_rows
 
     env = os.environ.get("GPAR_FIT_LOCKSTEP_ROWS")
-    lo, hi = 3072, one_call_grad_rows()
-    if env is not None:
-        parts = env.split(":")
-        lo = int(parts[0])
-        if lo <= 0:
-            return (1, 0)
-        if len(parts) > 1:
-            hi = min(hi, int(parts[1]))
+    if env is None:
+        return (1, 0)
+    parts = env.split(":")
+    lo, hi = int(parts[0]), one_call_grad_rows()
+    if lo <= 0:
+        return (1, 0)
+    if len(parts) > 1:
+        hi = min(hi, int(parts[1]))
     return lo, hi
 
 
@@ -148,7 +150,7 @@ class LockstepFactor:
     in lock-step take 2.7 ms.  Everything else of an evaluation (Gram build before, inverse / weights / gradient pass after) stays
     on the member's own stream and overlaps with the other members'.  What it costs: the lanes now move in step - a round lasts as
     long as its slowest evaluation plus two thread hand-offs - where free-running lanes hide one lane's factorisation under the
-    others' inverses; it pays from ~3000 rows (`lockstep_rows`).
+    others' inverses; whether it pays depends on the host (`lockstep_rows`: off by default).
 
     Protocol (deterministic: the composition of a round depends on the members' evaluation counts, never on timing).  Every lane
     (host thread + stream) owns one slot of a shared (lanes (n + 1)) x (n + 1) buffer.  Per evaluation a lane enqueues its build into

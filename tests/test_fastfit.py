@@ -324,7 +324,7 @@ def test_lockstep_rendezvous_trains_the_model_of_the_serial_loop(hip_engine, mon
     x, y, _ = _data(n=n, m=2, p=p, seed=n)
     kw = dict(scale=0.5, linear=True, nonlinear=True, noise=0.1, normalise_y=False)
     monkeypatch.delenv("GPAR_FIT_THREADS", raising=False)
-    monkeypatch.setenv("GPAR_FIT_LOCKSTEP_ROWS", "1000")   # (the default starts at 3072 rows: see fastfit.lockstep_rows)
+    monkeypatch.setenv("GPAR_FIT_LOCKSTEP_ROWS", "1000")   # (off by default: see fastfit.lockstep_rows)
     before = optimise.evaluation_count()
     together = GPARRegressor(**kw)
     together.fit(x, y, iters=10)
@@ -339,9 +339,9 @@ def test_lockstep_rendezvous_trains_the_model_of_the_serial_loop(hip_engine, mon
     assert sorted(a) == sorted(b)
     for k in a:
         np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=1e-8, err_msg=k)
-    # off by the switch: the lanes factor on their own, bit for bit the serial model
+    # off (the default): the lanes factor on their own, bit for bit the serial model
     monkeypatch.delenv("GPAR_FIT_THREADS")
-    monkeypatch.setenv("GPAR_FIT_LOCKSTEP_ROWS", "0")
+    monkeypatch.delenv("GPAR_FIT_LOCKSTEP_ROWS")
     apart = GPARRegressor(**kw)
     apart.fit(x, y, iters=10)
     assert not hasattr(apart, "_lockstep_rounds")
