@@ -744,7 +744,7 @@ int gpar_grad_nacc(void) { return GRAD_NACC; }
 
 static int gram_grad_launch(const gpar_kspec_t* ks, const double* z1, const double* zd1, int n1, int ldz1, const double* z2,
                             const double* zd2, int n2, int ldz2, int dz, const double* W, int ldw, int mode, double* workspace,
-                            int nblocks, double* out, void* stream) {
+                            int nblocks, double* out, void* stream, bool reduce = true) {
     if (!ks || ks->nterms < 0 || ks->nterms > GPAR_MAX_TERMS || ks->nfactors < 0 || ks->nfactors > GPAR_MAX_FACTORS)
         return GPAR_ARG_ERROR(3);
     if (dz < 0 || dz > GPAR_MAX_DIMS || nblocks <= 0) return GPAR_ARG_ERROR(4);
@@ -765,7 +765,8 @@ static int gram_grad_launch(const gpar_kspec_t* ks, const double* z1, const doub
     if (!grad_jit_launch(ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2, dz, W, ldw, mode, workspace, nblocks, (hipStream_t)stream))
         hipLaunchKernelGGL(gram_grad_kernel, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, *ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2,
                            dz, W, ldw, mode, workspace);
-    hipLaunchKernelGGL(gram_grad_reduce_kernel, dim3(GRAD_NACC), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, nblocks, out);
+    // (`reduce` false: the caller sums the partials itself - dense_grad_epilogue_kernel, in the same order)
+    if (reduce) hipLaunchKernelGGL(gram_grad_reduce_kernel, dim3(GRAD_NACC), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, nblocks, out);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
@@ -783,26 +784,78 @@ int gpar_gram_grad_cross(const gpar_kspec_t* ks, const double* z1, const double*
     return gram_grad_launch(ks, z1, zd1, n1, ldz1, z2, zd2, n2, ldz2, dz, W, ldw, mode, workspace, nblocks, out, stream);
 }
 
+// ---- launches folded together for the one-call training objective (round 6).  Below ~1000 rows an evaluation is a CHAIN of ~23 short
+// kernels and every link costs 8-9 us of latency whatever it computes: the element-wise ones are merged - the same expressions per
+// element, so the same bits as the separate kernels (featurize_kernel, featurize_dfreq_kernel, logpdf_prepare_kernel; logpdf_value_kernel,
+// gram_grad_reduce_kernel, half_diag_kernel).
+__global__ __launch_bounds__(256) void dense_grad_prep_kernel(gpar_fspec_t fs, const double* __restrict__ x, int n, int ldx, double* __restrict__ z,
+                                                              double* __restrict__ zd, int ldz, const double* __restrict__ y, long incy,
+                                                              double* __restrict__ A, int lda, double* __restrict__ logdet, int* __restrict__ info) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dz = fs.dz;
+    if (idx < n * dz) {
+        const int r = idx / dz, q = idx - r * dz;
+        const double v = x[(size_t)r * ldx + fs.col[q]];
+        double e, d = 0.0;
+        if (fs.embed[q] == GPAR_EMBED_SIN) { e = sin(v * fs.freq[q]); d = v * cos(v * fs.freq[q]); }
+        else if (fs.embed[q] == GPAR_EMBED_COS) { e = cos(v * fs.freq[q]); d = -v * sin(v * fs.freq[q]); }
+        else e = v;
+        z[(size_t)r * ldz + q] = e * fs.inv_scale[q];
+        if (zd) zd[(size_t)r * ldz + q] = d * fs.inv_scale[q];
+    }
+    if (idx < n) A[(size_t)n * lda + idx] = y[(size_t)idx * incy];
+    if (idx == n) {
+        A[(size_t)n * lda + n] = 0.0;
+        logdet[0] = 0.0;
+        info[0] = 0;
+    }
+}
+
+// blocks [0, GRAD_NACC): the gradient pass's partial sums in their fixed order (lanes 0-63, as gram_grad_reduce_kernel); blocks
+// [GRAD_NACC, GRAD_NACC + ceil(n / 256)): 1/2 diag W; the last block: the value from the corner of the factor and its log-determinant.
+__global__ __launch_bounds__(256) void dense_grad_epilogue_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out,
+                                                                  const double* __restrict__ W, int ldw, int n, double* __restrict__ half_diag,
+                                                                  const double* __restrict__ A, int lda, double n_log_2pi,
+                                                                  const double* __restrict__ logdet) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (b < GRAD_NACC) {
+        if (t >= 64) return;
+        double s = 0.0;
+        for (int q = t; q < nblocks; q += 64) s += partial[(size_t)q * GRAD_NACC + b];
+        s = wave_sum(s);
+        if (t == 0) out[2 + b] = s;
+        return;
+    }
+    const int hb = b - GRAD_NACC, nh = (n + 255) / 256;
+    if (hb < nh) {
+        const int i = hb * 256 + t;
+        if (i < n) half_diag[i] = 0.5 * W[(size_t)i * ldw + i];
+        return;
+    }
+    if (t == 0) out[0] = -0.5 * ((logdet[0] + n_log_2pi) - A[(size_t)n * lda + n]);
+}
+
 // Everything of gpar_logpdf_dense_grad behind the factorisation: value, K^-1 from L, alpha^T = (L^-1 y)^T L^-1, W = alpha alpha^T - K^-1,
 // the fused weighted-sum pass, 1/2 diag W.  `logdet`: the word the factorisation left (out + 1 itself in the one-call form).
 static int logpdf_grad_finish_run(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, double* z, double* zd,
                                   int ldz, double* A, int lda, const double* logdet, double* X, int ldxw, double* W, int ldw, double* alpha,
-                                  double* workspace, int nblocks, double* out, double* half_diag, void* stream) {
+                                  double* workspace, int nblocks, double* out, double* half_diag, void* stream, bool dfreq = true) {
     hipStream_t st = (hipStream_t)stream;
-    if (zd && fs->dz > 0) {
+    if (dfreq && zd && fs->dz > 0) {
         const long total = (long)n * fs->dz;
         hipLaunchKernelGGL(featurize_dfreq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *fs, x, n, ldx, zd, ldz);
     }
-    hipLaunchKernelGGL(logpdf_value_kernel, dim3(1), dim3(1), 0, st, (const double*)A, lda, n, (double)n * 1.8378770664093453, logdet, out);
     int rc = chol_inverse_run(A, n, lda, X, ldxw, W, ldw, st);
     if (rc) return rc;
     // alpha = (K + D)^-1 y = X (L^-1 y): X = L^-T is what the inverse has just left in its workspace, L^-1 y is row n of the factor
     hipLaunchKernelGGL(trmv_upper_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)X, n, ldxw,
                        (const double*)(A + (size_t)n * lda), 1, alpha, 1);
     rc = gemm_launch(1, 0, n, n, 1, 1.0, alpha, n, alpha, n, -1.0, W, ldw, GPAR_GEMM_C_LOWER, st);
-    if (!rc) rc = gram_grad_launch(ks, z, zd, n, ldz, z, zd, n, ldz, fs->dz, W, ldw, GPAR_GRAD_SYM, workspace, nblocks, out + 2, stream);
+    if (!rc) rc = gram_grad_launch(ks, z, zd, n, ldz, z, zd, n, ldz, fs->dz, W, ldw, GPAR_GRAD_SYM, workspace, nblocks, out + 2, stream, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(half_diag_kernel, dim3(gpar_ceil_div(n, 256)), dim3(256), 0, st, (const double*)W, ldw, n, half_diag);
+    // the partial sums of the gradient pass, 1/2 diag W and the value (from the corner of the factor, untouched since the factorisation)
+    hipLaunchKernelGGL(dense_grad_epilogue_kernel, dim3((unsigned)(GRAD_NACC + (n + 255) / 256 + 1)), dim3(256), 0, st, (const double*)workspace,
+                       nblocks, out, (const double*)W, ldw, n, half_diag, (const double*)A, lda, (double)n * 1.8378770664093453, logdet);
     GPAR_LAUNCH_CHECK();
     return 0;
 }
@@ -815,15 +868,21 @@ int gpar_logpdf_dense_grad(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const
     if (!fs || !ks || !x || !y || !z || !A || !X || !W || !alpha || !workspace || !out || !half_diag || !info || n <= 0 || nblocks <= 0)
         return GPAR_ARG_ERROR(1);
     hipStream_t st = (hipStream_t)stream;
-    // ---- value: what gpar_logpdf_dense does (features, Gram, observations, the augmented factorisation)
-    int rc = featurize_launch(fs, x, n, ldx, z, ldz, st);
-    if (!rc) rc = gram_launch(ks, z, n, ldz, z, n, ldz, fs->dz, A, lda, GPAR_GRAM_LOWER, noise_diag, jitter, nullptr, st);
+    // ---- what gpar_logpdf_dense does up to the factor: features (+ their frequency derivatives) and observations in ONE launch, Gram,
+    // the augmented factorisation
+    if (fs->dz < 0 || fs->dz > GPAR_MAX_DIMS) return GPAR_ARG_ERROR(2);
+    {
+        const long total = (long)n * fs->dz > (long)n + 1 ? (long)n * fs->dz : (long)n + 1;
+        hipLaunchKernelGGL(dense_grad_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *fs, x, n, ldx, z, zd, ldz, y, incy, A, lda,
+                           out + 1, info);
+    }
+    int rc = gram_launch(ks, z, n, ldz, z, n, ldz, fs->dz, A, lda, GPAR_GRAM_LOWER, noise_diag, jitter, nullptr, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(logpdf_prepare_kernel, dim3(gpar_ceil_div(n + 1, 256)), dim3(256), 0, st, y, incy, n, A, lda, out + 1, info);
     rc = potrf_run(A, n + 1, n, lda, out + 1, info, st, potrf_flags);
     if (rc) return rc;
     // ---- value and gradient ingredients from the factor
-    return logpdf_grad_finish_run(fs, ks, x, n, ldx, z, zd, ldz, A, lda, out + 1, X, ldxw, W, ldw, alpha, workspace, nblocks, out, half_diag, stream);
+    return logpdf_grad_finish_run(fs, ks, x, n, ldx, z, zd, ldz, A, lda, out + 1, X, ldxw, W, ldw, alpha, workspace, nblocks, out, half_diag, stream,
+                                  false);
 }
 
 int gpar_logpdf_dense_grad_finish(const gpar_fspec_t* fs, const gpar_kspec_t* ks, const double* x, int n, int ldx, double* z, double* zd,
